@@ -1,0 +1,157 @@
+"""Seeded synthetic fit problems of the shapes in BASELINE.json / SURVEY.md section 8(d).
+
+Hex-packed array (14.6 m spacing, first ``nants`` sites by radius), all ``i < j`` cross baselines, one
+DPSS basis per unique rounded delay (modeling.py:293), truth ``c[k] ~ (N + iN)/(k+1)``,
+``g = 1 + sigma (N + iN)``, data ``= g_i conj(g_j) (A c) + noise``, random flags, weights ``~flags / sum``
+(calibration.py:282-303), data divided by the rms of the unflagged samples (calibration.py:1178-1190),
+start at unity gains and ``c0 = A^T (d * [w != 0])`` (calibration.py:875-902; DPSS columns are orthonormal).
+"""
+import numpy as np
+
+from . import modeling
+from .problem import FitProblem
+
+CONFIGS = {
+    # name: (nants, nfreqs, f0, df)
+    "tutorial": (20, 64, 150e6, 200e3),
+    "hera37": (37, 1024, 100e6, 100e6 / 1024),
+    "hera350": (350, 1024, 100e6, 100e6 / 1024),
+}
+
+
+def hex_positions(nants, spacing=14.6):
+    """First ``nants`` sites of a hexagonal lattice ordered by radius then angle."""
+    n = int(np.ceil(np.sqrt(nants))) + 2
+    pts = []
+    for a in range(-n, n + 1):
+        for b in range(-n, n + 1):
+            x = spacing * (a + 0.5 * b)
+            y = spacing * (np.sqrt(3.0) / 2.0) * b
+            pts.append((np.hypot(x, y), np.arctan2(y, x), x, y))
+    pts.sort(key=lambda p: (round(p[0], 6), p[1]))
+    return np.asarray([(p[2], p[3], 0.0) for p in pts[:nants]])
+
+
+def make_problem(
+    nants,
+    nfreqs,
+    f0=100e6,
+    df=None,
+    seed=0,
+    gain_sigma=0.1,
+    noise_frac=1e-4,
+    flag_frac=0.05,
+    with_sky=False,
+    max_bls=None,
+    operator_cache=None,
+):
+    """Build one (pol, time) fit.  Returns (FitProblem, truth dict, start dict)."""
+    rng = np.random.default_rng(seed)
+    if df is None:
+        df = 100e6 / nfreqs
+    freqs = f0 + df * np.arange(nfreqs)
+    antpos = hex_positions(nants)
+    i_idx, j_idx = np.triu_indices(nants, k=1)
+    if max_bls is not None and len(i_idx) > max_bls:
+        # bounded sample of the same workload: an evenly spaced subset keeps the nvec distribution
+        sel = np.linspace(0, len(i_idx) - 1, max_bls).astype(np.int64)
+        i_idx, j_idx = i_idx[sel], j_idx[sel]
+    lengths = np.linalg.norm(antpos[i_idx] - antpos[j_idx], axis=1)
+    dlys = np.asarray([modeling.dly_ns(L) for L in lengths])
+    if operator_cache is None:
+        operator_cache = {}
+    uniq, inv = np.unique(dlys, return_inverse=True)
+    basis = []
+    for d in uniq:
+        L = lengths[np.where(dlys == d)[0][0]]
+        basis.append(modeling.yield_dpss_model_comps_bl_grp(L, freqs, operator_cache=operator_cache))
+    nbls = len(i_idx)
+    grp_basis = inv.astype(np.int32)
+    nvec = np.asarray([basis[b].shape[1] for b in grp_basis])
+    coff = np.concatenate([[0], np.cumsum(nvec)])
+    # truth
+    k_idx = np.concatenate([np.arange(n) for n in nvec])
+    c_true = (rng.standard_normal(coff[-1]) + 1j * rng.standard_normal(coff[-1])) / (k_idx + 1.0)
+    g_true = 1.0 + gain_sigma * (rng.standard_normal((nants, nfreqs)) + 1j * rng.standard_normal((nants, nfreqs)))
+    vis = np.empty((nbls, nfreqs), dtype=np.complex128)
+    for u in range(len(basis)):
+        bls = np.where(grp_basis == u)[0]
+        cu = np.stack([c_true[coff[b] : coff[b + 1]] for b in bls], axis=1)  # (nvec, nb)
+        vis[bls] = (basis[u] @ cu).T
+    sig_rms = np.sqrt(np.mean(np.abs(vis) ** 2))
+    data = g_true[i_idx] * np.conj(g_true[j_idx]) * vis
+    data += noise_frac * sig_rms * (rng.standard_normal(data.shape) + 1j * rng.standard_normal(data.shape)) / np.sqrt(2.0)
+    flags = rng.random((nbls, nfreqs)) < flag_frac
+    wgts = (~flags).astype(np.float64)
+    wgts /= wgts.sum()
+    rms = np.sqrt(np.mean(np.abs(data[~flags]) ** 2))
+    data = data / rms
+    prob = FitProblem(
+        nants=nants,
+        nfreqs=nfreqs,
+        basis=basis,
+        grp_basis=grp_basis,
+        grp_bl_start=np.arange(nbls + 1, dtype=np.int32),
+        bl_ant0=i_idx.astype(np.int32),
+        bl_ant1=j_idx.astype(np.int32),
+        bl_rowblk=np.zeros(nbls, dtype=np.int32),
+        data_r=np.ascontiguousarray(data.real),
+        data_i=np.ascontiguousarray(data.imag),
+        wgts=wgts,
+    )
+    if with_sky:
+        # sky_model=None path of calibrate_and_model_tensor: data / (g g*) with the initial (unity) gains.
+        prob.sky_r, prob.sky_i = prob.data_r.copy(), prob.data_i.copy()
+    # start: unity gains, c0 = A^T (d * mask)
+    c0 = np.empty(coff[-1], dtype=np.complex128)
+    dm = data * (~flags)
+    for u in range(len(basis)):
+        bls = np.where(grp_basis == u)[0]
+        cu = basis[u].T @ dm[bls].T  # (nvec, nb)
+        for n, b in enumerate(bls):
+            c0[coff[b] : coff[b + 1]] = cu[:, n]
+    truth = dict(c=c_true / rms, g=g_true, rms=rms, freqs=freqs, antpos=antpos, flags=flags)
+    start = dict(
+        g_r=np.ones((nants, nfreqs)),
+        g_i=np.zeros((nants, nfreqs)),
+        c_r=np.ascontiguousarray(c0.real),
+        c_i=np.ascontiguousarray(c0.imag),
+    )
+    return prob, truth, start
+
+
+def make_config(name, seed=None, **kwargs):
+    nants, nfreqs, f0, df = CONFIGS[name]
+    if seed is None:
+        seed = list(CONFIGS).index(name)
+    return make_problem(nants, nfreqs, f0=f0, df=df, seed=seed, **kwargs)
+
+
+def add_redundant_group(prob, start, rng, nred=3):
+    """Merge the first ``nred`` baselines that share basis 0 into ONE fitting group with shared
+    coefficients (the ``use_redundancy`` / B > 1 case of calibration.py:173-184).  Test helper."""
+    cand = np.where(prob.grp_basis == prob.grp_basis[0])[0][:nred]
+    keep = np.setdiff1d(np.arange(prob.nbls), cand)
+    order = np.concatenate([cand, keep])
+    coff = prob.grp_coff
+    nv = prob.grp_nvec[cand[0]]
+    new_c_r = np.concatenate([start["c_r"][coff[cand[0]] : coff[cand[0]] + nv]] + [start["c_r"][coff[g] : coff[g + 1]] for g in keep])
+    new_c_i = np.concatenate([start["c_i"][coff[cand[0]] : coff[cand[0]] + nv]] + [start["c_i"][coff[g] : coff[g + 1]] for g in keep])
+    out = FitProblem(
+        nants=prob.nants,
+        nfreqs=prob.nfreqs,
+        basis=prob.basis,
+        grp_basis=np.concatenate([[prob.grp_basis[cand[0]]], prob.grp_basis[keep]]).astype(np.int32),
+        grp_bl_start=np.concatenate([[0], len(cand) + np.arange(len(keep) + 1)]).astype(np.int32),
+        bl_ant0=prob.bl_ant0[order],
+        bl_ant1=prob.bl_ant1[order],
+        bl_rowblk=np.zeros(prob.nbls, dtype=np.int32),
+        data_r=prob.data_r[order],
+        data_i=prob.data_i[order],
+        wgts=prob.wgts[order],
+        sky_r=None if prob.sky_r is None else prob.sky_r[order],
+        sky_i=None if prob.sky_i is None else prob.sky_i[order],
+    )
+    out.validate()
+    new_start = dict(start, c_r=new_c_r, c_i=new_c_i)
+    return out, new_start

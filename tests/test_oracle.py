@@ -1,0 +1,182 @@
+"""Pins the CPU oracle (oracle/ref_numpy.py) without TensorFlow: forward ops restated in torch (CPU) +
+autograd, central finite differences, orthonormal-basis identities, loop semantics."""
+import numpy as np
+import pytest
+
+from calamity_amd import problem, synthetic
+from oracle import ref_numpy as R
+
+
+def _setup(seed=0, with_sky=False, redundant=False, nants=7, nfreqs=24):
+    p, truth, start = synthetic.make_problem(nants, nfreqs, f0=150e6, df=200e3, seed=seed, with_sky=with_sky)
+    if redundant:
+        p, start = synthetic.add_redundant_group(p, start, np.random.default_rng(seed))
+    ch = problem.chunks_from_problem(p)
+    rng = np.random.default_rng(seed + 100)
+    g_r = 1.0 + 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+    g_i = 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+    fg_r = problem.coeffs_to_chunks(p, start["c_r"], np.float64)
+    fg_i = problem.coeffs_to_chunks(p, start["c_i"], np.float64)
+    return p, ch, g_r, g_i, fg_r, fg_i
+
+
+def _torch_loss(g_r, g_i, fg_r, fg_i, ch, a0, a1, priors):
+    """The reference forward (calibration.py:1587-1656) written with torch ops, gather included."""
+    import torch
+
+    loss = 0.0
+    s_r = 0.0
+    s_i = 0.0
+    for c in range(len(fg_r)):
+        A = torch.as_tensor(ch["fg_comps"][c])
+        vr = torch.sum(fg_r[c] * A, dim=0)
+        vi = torch.sum(fg_i[c] * A, dim=0)
+        i0 = torch.as_tensor(a0[c])
+        i1 = torch.as_tensor(a1[c])
+        gr0, gr1, gi0, gi1 = g_r[i0], g_r[i1], g_i[i0], g_i[i1]
+        grgr, gigi, grgi, gigr = gr0 * gr1, gi0 * gi1, gr0 * gi1, gi0 * gr1
+        mr = (grgr + gigi) * vr + (grgi - gigr) * vi
+        mi = (gigr - grgi) * vr + (grgr + gigi) * vi
+        w = torch.as_tensor(ch["wgts"][c])
+        loss = loss + torch.sum(((torch.as_tensor(ch["data_r"][c]) - mr) ** 2 + (torch.as_tensor(ch["data_i"][c]) - mi) ** 2) * w)
+        s_r = s_r + torch.sum(mr * w)
+        s_i = s_i + torch.sum(mi * w)
+    if priors is not None:
+        loss = loss + (s_r - priors[0]) ** 2 + (s_i - priors[1]) ** 2
+    return loss
+
+
+@pytest.mark.parametrize("reg", [False, True])
+@pytest.mark.parametrize("redundant", [False, True])
+def test_adjoints_match_torch_autograd(reg, redundant):
+    torch = pytest.importorskip("torch")
+    p, ch, g_r, g_i, fg_r, fg_i = _setup(seed=3, with_sky=reg, redundant=redundant)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    priors = R.prior_sums(ch["sky_model_r"], ch["sky_model_i"], ch["wgts"]) if reg else None
+    tg_r = torch.tensor(g_r, requires_grad=True)
+    tg_i = torch.tensor(g_i, requires_grad=True)
+    tf_r = [torch.tensor(a, requires_grad=True) for a in fg_r]
+    tf_i = [torch.tensor(a, requires_grad=True) for a in fg_i]
+    tl = _torch_loss(tg_r, tg_i, tf_r, tf_i, ch, a0, a1, priors)
+    tl.backward()
+    loss, gg_r, gg_i, gf_r, gf_i = R.loss_and_grads(
+        g_r, g_i, fg_r, fg_i, ch["fg_comps"], ch["data_r"], ch["data_i"], ch["wgts"], a0, a1,
+        *(priors if reg else (None, None)),
+    )
+    if reg:
+        ref = R.mse_chunked_sum_regularized(g_r, g_i, fg_r, fg_i, ch["fg_comps"], len(fg_r), ch["data_r"], ch["data_i"], ch["wgts"], a0, a1, *priors)
+    else:
+        ref = R.mse_chunked(g_r, g_i, fg_r, fg_i, ch["fg_comps"], len(fg_r), ch["data_r"], ch["data_i"], ch["wgts"], a0, a1)
+    assert np.isclose(loss, ref, rtol=1e-13)
+    assert np.isclose(loss, tl.item(), rtol=1e-13)
+    np.testing.assert_allclose(gg_r, tg_r.grad.numpy(), rtol=1e-10, atol=1e-16)
+    np.testing.assert_allclose(gg_i, tg_i.grad.numpy(), rtol=1e-10, atol=1e-16)
+    for c in range(len(fg_r)):
+        np.testing.assert_allclose(gf_r[c], tf_r[c].grad.numpy(), rtol=1e-10, atol=1e-16)
+        np.testing.assert_allclose(gf_i[c], tf_i[c].grad.numpy(), rtol=1e-10, atol=1e-16)
+
+
+def test_adjoints_match_finite_differences():
+    p, ch, g_r, g_i, fg_r, fg_i = _setup(seed=5, with_sky=True)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    priors = R.prior_sums(ch["sky_model_r"], ch["sky_model_i"], ch["wgts"])
+    args = (ch["fg_comps"], len(fg_r), ch["data_r"], ch["data_i"], ch["wgts"], a0, a1) + tuple(priors)
+    _, gg_r, gg_i, gf_r, gf_i = R.loss_and_grads(g_r, g_i, fg_r, fg_i, ch["fg_comps"], ch["data_r"], ch["data_i"], ch["wgts"], a0, a1, *priors)
+    rng = np.random.default_rng(0)
+    h = 1e-6
+    for _ in range(6):
+        a, f = rng.integers(p.nants), rng.integers(p.nfreqs)
+        for arr, grad in ((g_r, gg_r), (g_i, gg_i)):
+            old = arr[a, f]
+            arr[a, f] = old + h
+            lp = R.mse_chunked_sum_regularized(g_r, g_i, fg_r, fg_i, *args)
+            arr[a, f] = old - h
+            lm = R.mse_chunked_sum_regularized(g_r, g_i, fg_r, fg_i, *args)
+            arr[a, f] = old
+            assert np.isclose((lp - lm) / (2 * h), grad[a, f], rtol=1e-5, atol=1e-10)
+        g = rng.integers(fg_r[0].shape[1])
+        for arr, grad in ((fg_r[0], gf_r[0]), (fg_i[0], gf_i[0])):
+            old = arr[0, g, 0, 0]
+            arr[0, g, 0, 0] = old + h
+            lp = R.mse_chunked_sum_regularized(g_r, g_i, fg_r, fg_i, *args)
+            arr[0, g, 0, 0] = old - h
+            lm = R.mse_chunked_sum_regularized(g_r, g_i, fg_r, fg_i, *args)
+            arr[0, g, 0, 0] = old
+            assert np.isclose((lp - lm) / (2 * h), grad[0, g, 0, 0], rtol=1e-5, atol=1e-10)
+
+
+def test_padded_vectors_get_zero_gradient():
+    p, ch, g_r, g_i, fg_r, fg_i = _setup(seed=1)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    _, _, _, gf_r, gf_i = R.loss_and_grads(g_r, g_i, fg_r, fg_i, ch["fg_comps"], ch["data_r"], ch["data_i"], ch["wgts"], a0, a1)
+    nvec = p.grp_nvec
+    for g in range(p.ngrps):
+        assert np.all(gf_r[p.chunk_of_grp[g]][nvec[g]:, p.pos_in_chunk[g]] == 0)
+
+
+def test_optimizer_first_steps_known_answer():
+    """Keras semantics known answers: first Adam step is -lr * g/(|g| + eps*...) ~ -lr sign(g); epsilon
+    sits outside the bias correction."""
+    g = np.array([0.5, -2.0, 1e-3])
+    for name in ("Adam", "Adamax"):
+        x = np.zeros(3)
+        opt = R.OPTIMIZERS[name](learning_rate=0.1)
+        opt.apply_gradients([(g, x)])
+        if name == "Adam":
+            lr_t = 0.1 * np.sqrt(1 - 0.999) / (1 - 0.9)
+            expect = -lr_t * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-7)
+        else:
+            expect = -(0.1 / (1 - 0.9)) * (0.1 * g) / (np.abs(g) + 1e-7)
+        np.testing.assert_allclose(x, expect, rtol=1e-14)
+    with pytest.raises(KeyError):
+        R.OPTIMIZERS["NotAnOptimizer"]
+
+
+def test_loop_semantics():
+    p, ch, g_r, g_i, fg_r, fg_i = _setup(seed=2)
+    kw = dict(data_r=ch["data_r"], data_i=ch["data_i"], wgts=ch["wgts"], fg_comps=ch["fg_comps"], corr_inds=ch["corr_inds"], optimizer="Adam", learning_rate=1e-2)
+    out5 = R.fit_gains_and_foregrounds(g_r, g_i, fg_r, fg_i, maxsteps=5, **kw)
+    assert len(out5[4]["loss"]) == 5
+    # recorded loss 0 is evaluated AFTER the unrecorded "graph build" update (calibration.py:693)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    l_init = R.mse_chunked(g_r, g_i, fg_r, fg_i, ch["fg_comps"], 1, ch["data_r"], ch["data_i"], ch["wgts"], a0, a1)
+    assert out5[4]["loss"][0] < l_init
+    # profiled steps are real updates too (calibration.py:681-687)
+    out_p = R.fit_gains_and_foregrounds(g_r, g_i, fg_r, fg_i, maxsteps=3, n_profile_steps=2, **kw)
+    np.testing.assert_allclose(out_p[4]["loss"], out5[4]["loss"][2:5], rtol=1e-12)
+    # tol stop: step >= 1 and |dl| < tol
+    out_t = R.fit_gains_and_foregrounds(g_r, g_i, fg_r, fg_i, maxsteps=50, tol=1e30, **kw)
+    assert len(out_t[4]["loss"]) == 2
+    # freeze_model returns the input coefficient tensors untouched
+    out_f = R.fit_gains_and_foregrounds(g_r, g_i, fg_r, fg_i, maxsteps=3, freeze_model=True, **kw)
+    assert out_f[2] is fg_r and out_f[3] is fg_i
+    # use_min: parameters after the update of the lowest-loss step
+    out_m = R.fit_gains_and_foregrounds(g_r, g_i, fg_r, fg_i, maxsteps=5, use_min=True, **kw)
+    k = int(np.argmin(out_m[4]["loss"]))
+    out_k = R.fit_gains_and_foregrounds(g_r, g_i, fg_r, fg_i, maxsteps=k + 1, **kw)
+    np.testing.assert_allclose(out_m[0], out_k[0], rtol=0, atol=0)
+
+
+def test_init_coeffs_orthonormal_identity():
+    """tensorize_fg_coeffs (calibration.py:828-913) on an orthonormal DPSS basis equals A^T (d * mask)."""
+    p, truth, start = synthetic.make_problem(7, 24, f0=150e6, df=200e3, seed=4)
+    ch = problem.chunks_from_problem(p)
+    c_r = R.tensorize_fg_coeffs(ch["data_r"], ch["wgts"], ch["fg_comps"])
+    c_i = R.tensorize_fg_coeffs(ch["data_i"], ch["wgts"], ch["fg_comps"])
+    np.testing.assert_allclose(problem.coeffs_from_chunks(p, c_r), start["c_r"], atol=1e-9)
+    np.testing.assert_allclose(problem.coeffs_from_chunks(p, c_i), start["c_i"], atol=1e-9)
+
+
+def test_fit_quality_reference_criterion():
+    """The reference's acceptance criterion (test_calibration.py:593-596): rms(data) >= 100 rms(resid)."""
+    p, truth, start = synthetic.make_config("tutorial")
+    ch = problem.chunks_from_problem(p)
+    fg_r = problem.coeffs_to_chunks(p, start["c_r"], np.float64)
+    fg_i = problem.coeffs_to_chunks(p, start["c_i"], np.float64)
+    out = R.fit_gains_and_foregrounds(start["g_r"], start["g_i"], fg_r, fg_i, ch["data_r"], ch["data_i"], ch["wgts"], ch["fg_comps"], ch["corr_inds"], maxsteps=1500, optimizer="Adam", learning_rate=1e-2)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    mr, mi = R.data_model(out[0], out[1], out[2][0], out[3][0], ch["fg_comps"][0], a0[0], a1[0])
+    w = ch["wgts"][0] > 0
+    resid = np.sqrt(np.mean(((ch["data_r"][0] - mr) ** 2 + (ch["data_i"][0] - mi) ** 2)[w]))
+    rms_data = np.sqrt(np.mean((ch["data_r"][0] ** 2 + ch["data_i"][0] ** 2)[w]))
+    assert rms_data >= 100 * resid
