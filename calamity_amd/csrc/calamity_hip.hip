@@ -1,0 +1,989 @@
+// calamity_hip.hip -- C-ABI (include/calamity_hip.h) and host orchestration of the gfx950 fit kernels.
+// No PyTorch, no TensorFlow, no CPU fallback: every compute entry point launches the HIP kernels of fit_kernels.hpp.
+#include "../../include/calamity_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "fit_kernels.hpp"
+
+using namespace calk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+  do {                                                                                                         \
+    hipError_t _e = (expr);                                                                                    \
+    if (_e != hipSuccess) return fail(CAL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define NCCL_TRY(expr)                                                                                         \
+  do {                                                                                                         \
+    ncclResult_t _e = (expr);                                                                                  \
+    if (_e != ncclSuccess) return fail(CAL_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define CAL_TRY(expr)      \
+  do {                     \
+    int _r = (expr);       \
+    if (_r != CAL_OK) return _r; \
+  } while (0)
+
+struct DevBuf {  // owning device allocation
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  int alloc(size_t n, bool zero = true) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(CAL_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    if (zero) {
+      e = hipMemset(p, 0, n);
+      if (e != hipSuccess) return fail(CAL_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    return CAL_OK;
+  }
+  template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+inline int grid_for(long long n, int block = 256, int cap = 16384) {
+  long long g = (n + block - 1) / block;
+  return (int)std::max<long long>(1, std::min<long long>(g, cap));
+}
+
+}  // namespace
+
+// ================================================================================================================
+struct cal_solver {
+  virtual ~cal_solver() {}
+  int device = 0;
+  int dtype = CAL_F32;
+  virtual int set_problem(const cal_problem_desc* d) = 0;
+  virtual int set_data(const void* dr, const void* di, const void* w) = 0;
+  virtual int set_regularization(int mode, double pr, double pi) = 0;
+  virtual int set_optimizer(const cal_optimizer_desc* d) = 0;
+  virtual int set_params(const void* g_r, const void* g_i, const void* c_r, const void* c_i) = 0;
+  virtual int get_params(int which, void* g_r, void* g_i, void* c_r, void* c_i) = 0;
+  virtual int get_moments(void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i, void* cv_r, void* cv_i,
+                          int64_t* t) = 0;
+  virtual int set_moments(const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i, const void* cm_r,
+                          const void* cm_i, const void* cv_r, const void* cv_i, int64_t t) = 0;
+  virtual int eval(bool grads, double* loss, void* gg_r, void* gg_i, void* gc_r, void* gc_i) = 0;
+  virtual int run(const cal_run_desc* r, double* losses_out, cal_run_result* res) = 0;
+  virtual int model(void* mr, void* mi) = 0;
+  virtual int init_coeffs(const void* sr, const void* si) = 0;
+  virtual int synchronize() = 0;
+  virtual int timing_enable(int e) = 0;
+  virtual int timing_get(cal_kernel_timing* out) = 0;
+  virtual int memory_bytes(int64_t* b) = 0;
+  virtual int comm_init(const void* id, int rank, int nranks) = 0;
+};
+
+template <typename T>
+struct SolverT final : cal_solver {
+  using T2 = vec2_t<T>;
+  hipStream_t stream = nullptr;
+  bool has_problem = false, has_data = false, has_params = false, has_opt = false;
+  // problem
+  int nants = 0, nfreqs = 0, fpad = 0, ngrps = 0, nbls = 0, ncoef = 0, nitems = 0, layout = 0;
+  bool gc_direct = true;
+  size_t lds_bytes = 0;
+  long long gcp_len = 0;
+  std::vector<int> h_grp_coff;
+  double basis_bytes = 0;
+  // device buffers
+  DevBuf tiles, bl_tile, bl_ant, items, ant_ptr, ant_ent, coef_grp, grp_coff, grp_item_ptr, item_goff;
+  DevBuf data_r, data_i, wgts;
+  DevBuf gains, gains_m, gains_v, gains_snap;  // [nants][fpad] T2
+  DevBuf coef, coef_m, coef_v, coef_snap;      // [2][ncoef] T (r plane then i plane)
+  DevBuf q0, q1, comm;                         // comm: r0 | r1 | r2 (gain gradient parts), contiguous for the all-reduce
+  DevBuf scal;                                 // 4 doubles: loss, s_r, s_i
+  DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
+  DevBuf part, state, losses, scratch, model_buf;
+  DevState* h_state = nullptr;                 // pinned mirror
+  // settings
+  cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7};
+  int reg = CAL_REG_NONE;
+  double prior_r = 0, prior_i = 0;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  long long t_launches = 0;
+  double t_total_ms = 0;
+  // comm
+  ncclComm_t nccl = nullptr;
+  int nranks = 1, rank = 0;
+
+  ~SolverT() override {
+    (void)hipSetDevice(device);
+    if (nccl) (void)ncclCommDestroy(nccl);
+    for (auto& e : ev_pool) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    if (h_state) (void)hipHostFree(h_state);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  int init() {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void**)&h_state, sizeof(DevState), hipHostMallocDefault));
+    memset(h_state, 0, sizeof(DevState));
+    CAL_TRY(state.alloc(sizeof(DevState)));
+    CAL_TRY(scal.alloc(4 * sizeof(double)));
+    return CAL_OK;
+  }
+
+  static int choose_fb(int nvec, int nfreqs) {
+    // widest channel block whose tile (nvec x FB) still fits the staging budget; never wider than the band needs
+    int cap = FbSet<T>::fb_min;
+    while (cap < FbSet<T>::fb_max && cap < nfreqs) cap *= 2;
+    for (int fb = std::min(cap, FbSet<T>::fb_max); fb >= FbSet<T>::fb_min; fb /= 2)
+      if ((long long)nvec * fb * (long long)sizeof(T) <= kTileBytes) return fb;
+    return -1;
+  }
+  static size_t lds_for(int fb) {
+    constexpr int M = FbSet<T>::fb_max;
+    if (fb == M) return TileCfg<T, M>::lds_bytes();
+    if (fb == M / 2) return TileCfg<T, M / 2>::lds_bytes();
+    if (fb == M / 4) return TileCfg<T, M / 4>::lds_bytes();
+    return TileCfg<T, M / 8>::lds_bytes();
+  }
+
+  // ------------------------------------------------------------------------------------------------------------
+  int set_problem(const cal_problem_desc* d) override {
+    HIP_TRY(hipSetDevice(device));
+    has_problem = has_data = has_params = false;
+    if (!d || d->nants <= 0 || d->nfreqs <= 0 || d->ngrps <= 0 || d->nbls <= 0 || d->nbasis <= 0)
+      return fail(CAL_ERR_INVALID, "set_problem: non-positive dimension");
+    if (!d->basis_offset || !d->basis_nvec || !d->basis_nrowblk || !d->basis_data || !d->grp_basis || !d->grp_bl_start ||
+        !d->bl_ant0 || !d->bl_ant1)
+      return fail(CAL_ERR_INVALID, "set_problem: null pointer in problem description");
+    if (d->layout != CAL_LAYOUT_STREAM && d->layout != CAL_LAYOUT_SHARED) return fail(CAL_ERR_INVALID, "set_problem: bad layout");
+    if (d->grp_bl_start[0] != 0 || d->grp_bl_start[d->ngrps] != d->nbls)
+      return fail(CAL_ERR_INVALID, "set_problem: grp_bl_start must run from 0 to nbls");
+    nants = d->nants; nfreqs = d->nfreqs; ngrps = d->ngrps; nbls = d->nbls; layout = d->layout;
+    const int nbasis = d->nbasis;
+    std::vector<int> fb_u(nbasis);
+    int fb_used_max = 0;
+    for (int u = 0; u < nbasis; ++u) {
+      if (d->basis_nvec[u] <= 0 || d->basis_nrowblk[u] <= 0) return fail(CAL_ERR_INVALID, "set_problem: empty basis block %d", u);
+      const long long want = (long long)d->basis_nvec[u] * d->basis_nrowblk[u] * nfreqs;
+      if (d->basis_offset[u + 1] - d->basis_offset[u] != want)
+        return fail(CAL_ERR_INVALID, "set_problem: basis block %d has %lld elements, expected %lld", u,
+                    (long long)(d->basis_offset[u + 1] - d->basis_offset[u]), want);
+      fb_u[u] = choose_fb(d->basis_nvec[u], nfreqs);
+      if (fb_u[u] < 0)
+        return fail(CAL_ERR_UNSUPPORTED, "set_problem: basis block %d has %d vectors; at most %d are supported for this dtype", u,
+                    d->basis_nvec[u], (int)(kTileBytes / sizeof(T) / FbSet<T>::fb_min));
+      fb_used_max = std::max(fb_used_max, fb_u[u]);
+    }
+    fpad = (nfreqs + fb_used_max - 1) / fb_used_max * fb_used_max;
+    lds_bytes = 0;
+    for (int u = 0; u < nbasis; ++u) lds_bytes = std::max(lds_bytes, lds_for(fb_u[u]));
+    for (int b = 0; b < d->nbls; ++b) {
+      if (d->bl_ant0[b] < 0 || d->bl_ant0[b] >= nants || d->bl_ant1[b] < 0 || d->bl_ant1[b] >= nants)
+        return fail(CAL_ERR_INVALID, "set_problem: baseline %d has an antenna index outside [0, %d)", b, nants);
+    }
+    // ---- groups, coefficient offsets
+    h_grp_coff.assign(ngrps + 1, 0);
+    std::vector<int> grp_of_bl(nbls);
+    for (int g = 0; g < ngrps; ++g) {
+      const int u = d->grp_basis[g];
+      if (u < 0 || u >= nbasis) return fail(CAL_ERR_INVALID, "set_problem: group %d points at basis %d", g, u);
+      if (d->grp_bl_start[g + 1] <= d->grp_bl_start[g]) return fail(CAL_ERR_INVALID, "set_problem: group %d has no baselines", g);
+      h_grp_coff[g + 1] = h_grp_coff[g] + d->basis_nvec[u];
+      for (int b = d->grp_bl_start[g]; b < d->grp_bl_start[g + 1]; ++b) {
+        grp_of_bl[b] = g;
+        const int rb = d->bl_rowblk ? d->bl_rowblk[b] : 0;
+        if (rb < 0 || rb >= d->basis_nrowblk[u]) return fail(CAL_ERR_INVALID, "set_problem: baseline %d row block %d out of range", b, rb);
+      }
+    }
+    ncoef = h_grp_coff[ngrps];
+
+    // ---- unique basis blocks -> tile-major device layout
+    const long long raw_elems = d->basis_offset[nbasis];
+    DevBuf raw, utiles;
+    CAL_TRY(raw.alloc((size_t)raw_elems * sizeof(T), false));
+    HIP_TRY(hipMemcpyAsync(raw.p, d->basis_data, (size_t)raw_elems * sizeof(T), hipMemcpyHostToDevice, stream));
+    std::vector<long long> uoff(nbasis + 1, 0);
+    for (int u = 0; u < nbasis; ++u) uoff[u + 1] = uoff[u] + (long long)d->basis_nrowblk[u] * fpad * d->basis_nvec[u];
+    CAL_TRY(utiles.alloc((size_t)uoff[nbasis] * sizeof(T), false));
+    for (int u = 0; u < nbasis; ++u) {
+      const long long n = uoff[u + 1] - uoff[u];
+      hipLaunchKernelGGL(retile_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, raw.as<T>() + d->basis_offset[u],
+                         utiles.as<T>() + uoff[u], nfreqs, fpad, d->basis_nvec[u], d->basis_nrowblk[u], fb_u[u]);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<long long> h_bl_tile(nbls);
+    basis_bytes = 0;
+    if (layout == CAL_LAYOUT_SHARED) {
+      for (int b = 0; b < nbls; ++b) {
+        const int u = d->grp_basis[grp_of_bl[b]];
+        const int rb = d->bl_rowblk ? d->bl_rowblk[b] : 0;
+        h_bl_tile[b] = uoff[u] + (long long)rb * fpad * d->basis_nvec[u];
+      }
+      HIP_TRY(hipStreamSynchronize(stream));
+      tiles.release();
+      tiles.p = utiles.p; tiles.bytes = utiles.bytes;
+      utiles.p = nullptr; utiles.bytes = 0;
+      basis_bytes = (double)uoff[nbasis] / fpad * nfreqs * sizeof(T);
+    } else {
+      std::vector<CopyJob> jobs(nbls);
+      long long off = 0;
+      for (int b = 0; b < nbls; ++b) {
+        const int u = d->grp_basis[grp_of_bl[b]];
+        const int rb = d->bl_rowblk ? d->bl_rowblk[b] : 0;
+        const long long n = (long long)fpad * d->basis_nvec[u];
+        jobs[b] = CopyJob{uoff[u] + (long long)rb * n, off, n};
+        h_bl_tile[b] = off;
+        off += n;
+      }
+      CAL_TRY(tiles.alloc((size_t)off * sizeof(T), false));
+      DevBuf djobs;
+      CAL_TRY(djobs.alloc(jobs.size() * sizeof(CopyJob), false));
+      HIP_TRY(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(CopyJob), hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(tile_copy_kernel<T>, dim3(nbls), dim3(256), 0, stream, utiles.as<T>(), tiles.as<T>(), djobs.as<CopyJob>());
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(stream));
+      basis_bytes = (double)off / fpad * nfreqs * sizeof(T);
+    }
+    raw.release();
+    CAL_TRY(bl_tile.alloc(nbls * sizeof(long long), false));
+    HIP_TRY(hipMemcpy(bl_tile.p, h_bl_tile.data(), nbls * sizeof(long long), hipMemcpyHostToDevice));
+    std::vector<int2> h_ant(nbls);
+    for (int b = 0; b < nbls; ++b) h_ant[b] = make_int2(d->bl_ant0[b], d->bl_ant1[b]);
+    CAL_TRY(bl_ant.alloc(nbls * sizeof(int2), false));
+    HIP_TRY(hipMemcpy(bl_ant.p, h_ant.data(), nbls * sizeof(int2), hipMemcpyHostToDevice));
+
+    // ---- work items: whole groups when that already fills the chip, otherwise split along tiles
+    long long total_tiles = 0;
+    for (int g = 0; g < ngrps; ++g)
+      total_tiles += (long long)(d->grp_bl_start[g + 1] - d->grp_bl_start[g]) * (fpad / fb_u[d->grp_basis[g]]);
+    // one item per group when the groups alone fill the chip (256 CUs x ~4 resident workgroups, several waves of them);
+    // otherwise split groups along their tiles (partial coefficient gradients are summed by coeff_partial_reduce_kernel)
+    const long long target_items = 8192;
+    const bool groups_fill_chip = ngrps >= 2048;
+    const long long tiles_per_item = groups_fill_chip ? std::max<long long>(64, 4 * total_tiles / ngrps)
+                                                      : std::max<long long>(4, total_tiles / target_items);
+    std::vector<Item> h_items;
+    std::vector<int> h_grp_item_ptr(ngrps + 1, 0);
+    gc_direct = true;
+    for (int g = 0; g < ngrps; ++g) {
+      const int u = d->grp_basis[g];
+      const int ntpb = fpad / fb_u[u];
+      const long long nt = (long long)(d->grp_bl_start[g + 1] - d->grp_bl_start[g]) * ntpb;
+      const int nparts = (int)std::max<long long>(1, (nt + tiles_per_item - 1) / tiles_per_item);
+      if (nparts > 1) gc_direct = false;
+      int fl = 0;
+      while ((1 << fl) < fb_u[u]) ++fl;
+      for (int p = 0; p < nparts; ++p) {
+        Item it{};
+        it.bl0 = d->grp_bl_start[g];
+        it.tile0 = (int)(nt * p / nparts);
+        it.tile1 = (int)(nt * (p + 1) / nparts);
+        it.nvec = d->basis_nvec[u];
+        it.coff = h_grp_coff[g];
+        it.fb_log2 = fl;
+        it.pad = g;
+        h_items.push_back(it);
+      }
+      h_grp_item_ptr[g + 1] = (int)h_items.size();
+    }
+    nitems = (int)h_items.size();
+    // heaviest first: the hardware dispatches workgroups in index order, so the tail is made of the lightest items
+    std::vector<int> order(nitems);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      const long long wa = (long long)(h_items[a].tile1 - h_items[a].tile0) * h_items[a].nvec * (1 << h_items[a].fb_log2);
+      const long long wb = (long long)(h_items[b].tile1 - h_items[b].tile0) * h_items[b].nvec * (1 << h_items[b].fb_log2);
+      return wa > wb;
+    });
+    std::vector<int> h_item_goff(nitems);
+    gcp_len = 0;
+    if (gc_direct) {
+      for (int q = 0; q < nitems; ++q) h_item_goff[q] = h_items[q].coff;
+      gcp_len = ncoef;
+    } else {
+      for (int q = 0; q < nitems; ++q) {
+        h_item_goff[q] = (int)gcp_len;
+        gcp_len += h_items[q].nvec;
+      }
+    }
+    std::vector<Item> sorted(nitems);
+    for (int q = 0; q < nitems; ++q) {
+      sorted[q] = h_items[order[q]];
+      sorted[q].goff = h_item_goff[order[q]];
+      sorted[q].pad = 0;
+    }
+    CAL_TRY(items.alloc(nitems * sizeof(Item), false));
+    HIP_TRY(hipMemcpy(items.p, sorted.data(), nitems * sizeof(Item), hipMemcpyHostToDevice));
+    if (!gc_direct) {
+      std::vector<int> h_coef_grp(ncoef);
+      for (int g = 0; g < ngrps; ++g)
+        for (int n = h_grp_coff[g]; n < h_grp_coff[g + 1]; ++n) h_coef_grp[n] = g;
+      CAL_TRY(coef_grp.alloc(ncoef * sizeof(int), false));
+      HIP_TRY(hipMemcpy(coef_grp.p, h_coef_grp.data(), ncoef * sizeof(int), hipMemcpyHostToDevice));
+      CAL_TRY(grp_coff.alloc((ngrps + 1) * sizeof(int), false));
+      HIP_TRY(hipMemcpy(grp_coff.p, h_grp_coff.data(), (ngrps + 1) * sizeof(int), hipMemcpyHostToDevice));
+      CAL_TRY(grp_item_ptr.alloc((ngrps + 1) * sizeof(int), false));
+      HIP_TRY(hipMemcpy(grp_item_ptr.p, h_grp_item_ptr.data(), (ngrps + 1) * sizeof(int), hipMemcpyHostToDevice));
+      CAL_TRY(item_goff.alloc(nitems * sizeof(int), false));
+      HIP_TRY(hipMemcpy(item_goff.p, h_item_goff.data(), nitems * sizeof(int), hipMemcpyHostToDevice));
+      CAL_TRY(gc0.alloc(2 * (size_t)ncoef * sizeof(T)));
+    }
+
+    // ---- per-antenna CSR of (baseline, role, other antenna), in baseline order: a fixed summation order
+    std::vector<int> h_ant_ptr(nants + 1, 0);
+    for (int b = 0; b < nbls; ++b) {
+      h_ant_ptr[d->bl_ant0[b] + 1]++;
+      h_ant_ptr[d->bl_ant1[b] + 1]++;
+    }
+    for (int a = 0; a < nants; ++a) h_ant_ptr[a + 1] += h_ant_ptr[a];
+    std::vector<int2> h_ent(2 * (size_t)nbls);
+    std::vector<int> fill(h_ant_ptr.begin(), h_ant_ptr.end() - 1);
+    for (int b = 0; b < nbls; ++b) {
+      h_ent[fill[d->bl_ant0[b]]++] = make_int2(b * 2 + 0, d->bl_ant1[b]);
+      h_ent[fill[d->bl_ant1[b]]++] = make_int2(b * 2 + 1, d->bl_ant0[b]);
+    }
+    CAL_TRY(ant_ptr.alloc((nants + 1) * sizeof(int), false));
+    HIP_TRY(hipMemcpy(ant_ptr.p, h_ant_ptr.data(), (nants + 1) * sizeof(int), hipMemcpyHostToDevice));
+    CAL_TRY(ant_ent.alloc(h_ent.size() * sizeof(int2), false));
+    HIP_TRY(hipMemcpy(ant_ent.p, h_ent.data(), h_ent.size() * sizeof(int2), hipMemcpyHostToDevice));
+
+    // ---- state arrays
+    const size_t rowbytes = (size_t)nbls * fpad * sizeof(T);
+    CAL_TRY(data_r.alloc(rowbytes));
+    CAL_TRY(data_i.alloc(rowbytes));
+    CAL_TRY(wgts.alloc(rowbytes));
+    const size_t gbytes = (size_t)nants * fpad * sizeof(T2);
+    CAL_TRY(gains.alloc(gbytes));
+    CAL_TRY(gains_m.alloc(gbytes));
+    CAL_TRY(gains_v.alloc(gbytes));
+    gains_snap.release();
+    const size_t cbytes = 2 * (size_t)ncoef * sizeof(T);
+    CAL_TRY(coef.alloc(cbytes));
+    CAL_TRY(coef_m.alloc(cbytes));
+    CAL_TRY(coef_v.alloc(cbytes));
+    coef_snap.release();
+    CAL_TRY(q0.alloc((size_t)nbls * fpad * sizeof(T2)));
+    q1.release();
+    CAL_TRY(comm.alloc(3 * gbytes));
+    CAL_TRY(gcp0.alloc(2 * (size_t)gcp_len * sizeof(T)));
+    gcp1.release();
+    gc1.release();
+    CAL_TRY(part.alloc((size_t)nitems * 4 * sizeof(double)));
+    model_buf.release();
+    scratch.release();
+    has_problem = true;
+    reg = CAL_REG_NONE;
+    return CAL_OK;
+  }
+
+  // ---- padded copies ------------------------------------------------------------------------------------------
+  int ensure_scratch(size_t bytes) {
+    if (scratch.bytes < bytes) CAL_TRY(scratch.alloc(bytes, false));
+    return CAL_OK;
+  }
+  // host [rows][nfreqs] -> device [rows][fpad] * stride + off
+  int upload_rows(const void* src, T* dst, long long rows, int stride, int off) {
+    const size_t bytes = (size_t)rows * nfreqs * sizeof(T);
+    if (stride == 1 && fpad == nfreqs) {
+      HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      return CAL_OK;
+    }
+    CAL_TRY(ensure_scratch(bytes));
+    HIP_TRY(hipMemcpyAsync(scratch.p, src, bytes, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(pad_rows_kernel<T>, dim3(grid_for(rows * fpad)), dim3(256), 0, stream, scratch.as<T>(), dst, rows, nfreqs, fpad,
+                       stride, off);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    return CAL_OK;
+  }
+  int download_rows(void* dst, const T* src, long long rows, int stride, int off) {
+    const size_t bytes = (size_t)rows * nfreqs * sizeof(T);
+    if (stride == 1 && fpad == nfreqs) {
+      HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      return CAL_OK;
+    }
+    CAL_TRY(ensure_scratch(bytes));
+    hipLaunchKernelGGL(unpad_rows_kernel<T>, dim3(grid_for(rows * nfreqs)), dim3(256), 0, stream, src, scratch.as<T>(), rows, nfreqs,
+                       fpad, stride, off);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dst, scratch.p, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return CAL_OK;
+  }
+
+  int set_data(const void* dr, const void* di, const void* w) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem) return fail(CAL_ERR_STATE, "set_data before set_problem");
+    if (!dr || !di || !w) return fail(CAL_ERR_INVALID, "set_data: null pointer");
+    CAL_TRY(upload_rows(dr, data_r.as<T>(), nbls, 1, 0));
+    CAL_TRY(upload_rows(di, data_i.as<T>(), nbls, 1, 0));
+    CAL_TRY(upload_rows(w, wgts.as<T>(), nbls, 1, 0));
+    has_data = true;
+    return CAL_OK;
+  }
+
+  int set_regularization(int mode, double pr, double pi) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem) return fail(CAL_ERR_STATE, "set_regularization before set_problem");
+    if (mode != CAL_REG_NONE && mode != CAL_REG_SUM) return fail(CAL_ERR_INVALID, "set_regularization: unknown mode %d", mode);
+    reg = mode;
+    prior_r = pr;
+    prior_i = pi;
+    if (reg == CAL_REG_SUM) {
+      if (!q1.p) CAL_TRY(q1.alloc((size_t)nbls * fpad * sizeof(T2)));
+      if (!gcp1.p) CAL_TRY(gcp1.alloc(2 * (size_t)gcp_len * sizeof(T)));
+      if (!gc_direct && !gc1.p) CAL_TRY(gc1.alloc(2 * (size_t)ncoef * sizeof(T)));
+    }
+    return CAL_OK;
+  }
+
+  int set_optimizer(const cal_optimizer_desc* d) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem) return fail(CAL_ERR_STATE, "set_optimizer before set_problem");
+    if (!d) return fail(CAL_ERR_INVALID, "set_optimizer: null");
+    if (d->optimizer != CAL_OPT_ADAM && d->optimizer != CAL_OPT_ADAMAX)
+      return fail(CAL_ERR_INVALID, "set_optimizer: unknown optimizer id %d", d->optimizer);
+    opt = *d;
+    HIP_TRY(hipMemsetAsync(gains_m.p, 0, gains_m.bytes, stream));
+    HIP_TRY(hipMemsetAsync(gains_v.p, 0, gains_v.bytes, stream));
+    HIP_TRY(hipMemsetAsync(coef_m.p, 0, coef_m.bytes, stream));
+    HIP_TRY(hipMemsetAsync(coef_v.p, 0, coef_v.bytes, stream));
+    // a new fit begins: loop state of calibration.py:573-574
+    h_state->t = 0;
+    h_state->min_loss = 9e99;
+    h_state->prev_loss = 0;
+    h_state->n_recorded_total = 0;
+    h_state->nonfinite = 0;
+    has_opt = true;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return CAL_OK;
+  }
+
+  int set_params(const void* g_r, const void* g_i, const void* c_r, const void* c_i) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem) return fail(CAL_ERR_STATE, "set_params before set_problem");
+    if (g_r) CAL_TRY(upload_rows(g_r, gains.as<T>(), nants, 2, 0));
+    if (g_i) CAL_TRY(upload_rows(g_i, gains.as<T>(), nants, 2, 1));
+    if (c_r) HIP_TRY(hipMemcpy(coef.as<T>(), c_r, (size_t)ncoef * sizeof(T), hipMemcpyHostToDevice));
+    if (c_i) HIP_TRY(hipMemcpy(coef.as<T>() + ncoef, c_i, (size_t)ncoef * sizeof(T), hipMemcpyHostToDevice));
+    has_params = true;
+    return CAL_OK;
+  }
+
+  int get_params(int which, void* g_r, void* g_i, void* c_r, void* c_i) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem) return fail(CAL_ERR_STATE, "get_params before set_problem");
+    const T* g = gains.as<T>();
+    const T* c = coef.as<T>();
+    if (which == 1) {
+      if (!gains_snap.p) return fail(CAL_ERR_STATE, "get_params(which=1): no use_min snapshot was taken");
+      g = gains_snap.as<T>();
+      c = coef_snap.as<T>();
+    } else if (which != 0) {
+      return fail(CAL_ERR_INVALID, "get_params: which must be 0 or 1");
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (g_r) CAL_TRY(download_rows(g_r, g, nants, 2, 0));
+    if (g_i) CAL_TRY(download_rows(g_i, g, nants, 2, 1));
+    if (c_r) HIP_TRY(hipMemcpy(c_r, c, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
+    if (c_i) HIP_TRY(hipMemcpy(c_i, c + ncoef, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
+    return CAL_OK;
+  }
+
+  int get_moments(void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i, void* cv_r, void* cv_i,
+                  int64_t* t) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem) return fail(CAL_ERR_STATE, "get_moments before set_problem");
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (gm_r) CAL_TRY(download_rows(gm_r, gains_m.as<T>(), nants, 2, 0));
+    if (gm_i) CAL_TRY(download_rows(gm_i, gains_m.as<T>(), nants, 2, 1));
+    if (gv_r) CAL_TRY(download_rows(gv_r, gains_v.as<T>(), nants, 2, 0));
+    if (gv_i) CAL_TRY(download_rows(gv_i, gains_v.as<T>(), nants, 2, 1));
+    const size_t cb = (size_t)ncoef * sizeof(T);
+    if (cm_r) HIP_TRY(hipMemcpy(cm_r, coef_m.as<T>(), cb, hipMemcpyDeviceToHost));
+    if (cm_i) HIP_TRY(hipMemcpy(cm_i, coef_m.as<T>() + ncoef, cb, hipMemcpyDeviceToHost));
+    if (cv_r) HIP_TRY(hipMemcpy(cv_r, coef_v.as<T>(), cb, hipMemcpyDeviceToHost));
+    if (cv_i) HIP_TRY(hipMemcpy(cv_i, coef_v.as<T>() + ncoef, cb, hipMemcpyDeviceToHost));
+    if (t) *t = h_state->t;
+    return CAL_OK;
+  }
+
+  int set_moments(const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i, const void* cm_r, const void* cm_i,
+                  const void* cv_r, const void* cv_i, int64_t t) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem) return fail(CAL_ERR_STATE, "set_moments before set_problem");
+    if (t < 0) return fail(CAL_ERR_INVALID, "set_moments: negative iteration count");
+    if (gm_r) CAL_TRY(upload_rows(gm_r, gains_m.as<T>(), nants, 2, 0));
+    if (gm_i) CAL_TRY(upload_rows(gm_i, gains_m.as<T>(), nants, 2, 1));
+    if (gv_r) CAL_TRY(upload_rows(gv_r, gains_v.as<T>(), nants, 2, 0));
+    if (gv_i) CAL_TRY(upload_rows(gv_i, gains_v.as<T>(), nants, 2, 1));
+    const size_t cb = (size_t)ncoef * sizeof(T);
+    if (cm_r) HIP_TRY(hipMemcpy(coef_m.as<T>(), cm_r, cb, hipMemcpyHostToDevice));
+    if (cm_i) HIP_TRY(hipMemcpy(coef_m.as<T>() + ncoef, cm_i, cb, hipMemcpyHostToDevice));
+    if (cv_r) HIP_TRY(hipMemcpy(coef_v.as<T>(), cv_r, cb, hipMemcpyHostToDevice));
+    if (cv_i) HIP_TRY(hipMemcpy(coef_v.as<T>() + ncoef, cv_i, cb, hipMemcpyHostToDevice));
+    h_state->t = t;
+    return CAL_OK;
+  }
+
+  // ---- one pass of the hot path -------------------------------------------------------------------------------
+  FusedArgs<T> fused_args() {
+    FusedArgs<T> a{};
+    a.tiles = tiles.as<T>();
+    a.bl_tile = bl_tile.as<long long>();
+    a.bl_ant = bl_ant.as<int2>();
+    a.data_r = data_r.as<T>();
+    a.data_i = data_i.as<T>();
+    a.wgts = wgts.as<T>();
+    a.gains = gains.as<T2>();
+    a.c_r = coef.as<T>();
+    a.c_i = coef.as<T>() + ncoef;
+    a.items = items.as<Item>();
+    a.q0 = q0.as<T2>();
+    a.q1 = q1.as<T2>();
+    a.gcp0_r = gcp0.as<T>();
+    a.gcp0_i = gcp0.as<T>() + gcp_len;
+    a.gcp1_r = gcp1.as<T>();
+    a.gcp1_i = gcp1.p ? gcp1.as<T>() + gcp_len : nullptr;
+    a.part = part.as<double>();
+    a.model_r = nullptr;
+    a.model_i = nullptr;
+    a.state = state.as<DevState>();
+    a.fpad = fpad;
+    return a;
+  }
+  template <int MODE> void launch_fused(const FusedArgs<T>& a, bool with_reg) {
+    if (with_reg)
+      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems), dim3(kThreads), lds_bytes, stream, a);
+    else
+      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems), dim3(kThreads), lds_bytes, stream, a);
+  }
+  T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
+  T* grad_c1() { return gc_direct ? gcp1.as<T>() : gc1.as<T>(); }
+
+  // enqueue: loss (+ gradients) of the current parameters; leaves loss in state, final gradients in comm[0] / grad_c0()
+  int enqueue_pass(bool grads, bool apply_update, int losses_cap) {
+    const bool R = reg == CAL_REG_SUM;
+    FusedArgs<T> a = fused_args();
+    DevState* st = state.as<DevState>();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+      if (ev_used == ev_pool.size()) {
+        hipEvent_t x, y;
+        HIP_TRY(hipEventCreate(&x));
+        HIP_TRY(hipEventCreate(&y));
+        ev_pool.push_back({x, y});
+      }
+      e0 = ev_pool[ev_used].first;
+      e1 = ev_pool[ev_used].second;
+      ++ev_used;
+      HIP_TRY(hipEventRecord(e0, stream));
+    }
+    if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
+    if (timing) HIP_TRY(hipEventRecord(e1, stream));
+    const size_t gn = (size_t)nants * fpad;
+    T2* r0 = comm.as<T2>();
+    T2* r1 = r0 + gn;
+    T2* r2 = r1 + gn;
+    if (grads) {
+      if (!gc_direct) {
+        hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
+                           gcp0.as<T>() + gcp_len, gc0.as<T>(), gc0.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
+                           grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
+        if (R)
+          hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp1.as<T>(),
+                             gcp1.as<T>() + gcp_len, gc1.as<T>(), gc1.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
+                             grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
+      }
+      const int nb = (int)((gn + 255) / 256) + 1;
+      if (R)
+        hipLaunchKernelGGL((gain_grad_kernel<T, true>), dim3(nb), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
+                           ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), nitems,
+                           scal.as<double>(), st);
+      else
+        hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(nb), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
+                           ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), nitems,
+                           scal.as<double>(), st);
+    } else {
+      // loss only: just the partial-sum block of the gain kernel (nants = 0 -> no antenna work)
+      hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
+                         ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, 0, fpad, part.as<double>(), nitems, scal.as<double>(), st);
+    }
+    if (nccl && nranks > 1) {
+      // the one exchange step of the sharded fit: sum gain-gradient parts and loss scalars over ranks
+      NCCL_TRY(ncclGroupStart());
+      if (grads)
+        NCCL_TRY(ncclAllReduce(r0, r0, (R ? 3 : 1) * gn * 2, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, nccl, stream));
+      NCCL_TRY(ncclAllReduce(scal.p, scal.p, 4, ncclDouble, ncclSum, nccl, stream));
+      NCCL_TRY(ncclGroupEnd());
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>(), losses.as<double>(), losses_cap,
+                       apply_update ? 1 : 0);
+    if (grads && R) {
+      hipLaunchKernelGGL(combine_gain_kernel<T>, dim3((int)((gn + 255) / 256)), dim3(256), 0, stream, r0, r1, r2, (int)gn, st);
+      hipLaunchKernelGGL(combine_coeff_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, grad_c0(), grad_c0() + ncoef,
+                         grad_c1(), grad_c1() + ncoef, ncoef, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return CAL_OK;
+  }
+
+  int enqueue_update(bool freeze_model) {
+    DevState* st = state.as<DevState>();
+    const long long gn = 2LL * nants * fpad;
+    T* gsnap = gains_snap.p ? gains_snap.as<T>() : gains.as<T>();
+    T* csnap = coef_snap.p ? coef_snap.as<T>() : coef.as<T>();
+    if (opt.optimizer == CAL_OPT_ADAM) {
+      hipLaunchKernelGGL((adam_kernel<T, 0>), dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, stream, gains.as<T>(), comm.as<T>(),
+                         gains_m.as<T>(), gains_v.as<T>(), gsnap, gn, st);
+      if (!freeze_model)
+        hipLaunchKernelGGL((adam_kernel<T, 0>), dim3((unsigned)((2LL * ncoef + 255) / 256)), dim3(256), 0, stream, coef.as<T>(),
+                           grad_c0(), coef_m.as<T>(), coef_v.as<T>(), csnap, 2LL * ncoef, st);
+    } else {
+      hipLaunchKernelGGL((adam_kernel<T, 1>), dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, stream, gains.as<T>(), comm.as<T>(),
+                         gains_m.as<T>(), gains_v.as<T>(), gsnap, gn, st);
+      if (!freeze_model)
+        hipLaunchKernelGGL((adam_kernel<T, 1>), dim3((unsigned)((2LL * ncoef + 255) / 256)), dim3(256), 0, stream, coef.as<T>(),
+                           grad_c0(), coef_m.as<T>(), coef_v.as<T>(), csnap, 2LL * ncoef, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return CAL_OK;
+  }
+
+  int push_state() {
+    h_state->lr = opt.learning_rate;
+    h_state->beta1 = opt.beta_1;
+    h_state->beta2 = opt.beta_2;
+    h_state->eps = opt.epsilon;
+    h_state->reg = reg == CAL_REG_SUM;
+    h_state->prior_r = prior_r;
+    h_state->prior_i = prior_i;
+    HIP_TRY(hipMemcpyAsync(state.p, h_state, sizeof(DevState), hipMemcpyHostToDevice, stream));
+    return CAL_OK;
+  }
+  int pull_state() {
+    HIP_TRY(hipMemcpyAsync(h_state, state.p, sizeof(DevState), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return CAL_OK;
+  }
+  int collect_timing() {
+    for (size_t i = 0; i < ev_used; ++i) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
+      t_total_ms += ms;
+      ++t_launches;
+    }
+    ev_used = 0;
+    return CAL_OK;
+  }
+  int ready() {
+    if (!has_problem) return fail(CAL_ERR_STATE, "no problem set (cal_solver_set_problem)");
+    if (!has_data) return fail(CAL_ERR_STATE, "no data set (cal_solver_set_data)");
+    if (!has_params) return fail(CAL_ERR_STATE, "no parameters set (cal_solver_set_params)");
+    return CAL_OK;
+  }
+
+  int eval(bool grads, double* loss, void* gg_r, void* gg_i, void* gc_r, void* gc_i) override {
+    HIP_TRY(hipSetDevice(device));
+    CAL_TRY(ready());
+    h_state->done = h_state->done_after = 0;
+    CAL_TRY(push_state());
+    CAL_TRY(enqueue_pass(grads, false, 0));
+    CAL_TRY(pull_state());
+    if (timing) CAL_TRY(collect_timing());
+    if (loss) *loss = h_state->loss;
+    if (grads) {
+      if (gg_r) CAL_TRY(download_rows(gg_r, comm.as<T>(), nants, 2, 0));
+      if (gg_i) CAL_TRY(download_rows(gg_i, comm.as<T>(), nants, 2, 1));
+      if (gc_r) HIP_TRY(hipMemcpy(gc_r, grad_c0(), (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
+      if (gc_i) HIP_TRY(hipMemcpy(gc_i, grad_c0() + ncoef, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
+    }
+    return CAL_OK;
+  }
+
+  int run(const cal_run_desc* r, double* losses_out, cal_run_result* res) override {
+    HIP_TRY(hipSetDevice(device));
+    CAL_TRY(ready());
+    if (!has_opt) return fail(CAL_ERR_STATE, "no optimizer set (cal_solver_set_optimizer)");
+    if (!r || r->nsteps < 0) return fail(CAL_ERR_INVALID, "run: bad run description");
+    if (res) memset(res, 0, sizeof(*res));
+    if (r->nsteps == 0) return CAL_OK;
+    if (r->use_min && !gains_snap.p) {
+      CAL_TRY(gains_snap.alloc(gains.bytes));
+      CAL_TRY(coef_snap.alloc(coef.bytes));
+    }
+    if (r->record && losses.bytes < (size_t)r->nsteps * sizeof(double)) CAL_TRY(losses.alloc((size_t)r->nsteps * sizeof(double)));
+    if (!losses.p) CAL_TRY(losses.alloc(sizeof(double)));
+    h_state->done = h_state->done_after = 0;
+    h_state->n_recorded = 0;
+    h_state->nupdates = 0;
+    h_state->improved = 0;
+    h_state->record = r->record ? 1 : 0;
+    h_state->use_min = r->use_min ? 1 : 0;
+    h_state->tol = r->tol;
+    CAL_TRY(push_state());
+    // steps are enqueued in chunks; the device decides when the loop ends (finalize_kernel) and later steps of a
+    // chunk fall through at once, so the host only synchronises once per chunk instead of once per step (:701)
+    const double work = (double)basis_bytes + 1.0;
+    int chunk = (int)std::max(1.0, std::min(256.0, 2.0e11 / work));  // ~ tens of milliseconds of GPU time per chunk
+    int issued = 0;
+    while (issued < r->nsteps) {
+      const int n = std::min(chunk, r->nsteps - issued);
+      for (int s = 0; s < n; ++s) {
+        CAL_TRY(enqueue_pass(true, true, r->record ? r->nsteps : 0));
+        CAL_TRY(enqueue_update(r->freeze_model != 0));
+      }
+      issued += n;
+      CAL_TRY(pull_state());
+      if (timing) CAL_TRY(collect_timing());
+      if (h_state->done || h_state->done_after || h_state->nonfinite) break;
+    }
+    if (res) {
+      res->nrecorded = h_state->n_recorded;
+      res->stopped = (h_state->done || h_state->done_after) && !h_state->nonfinite ? 1 : 0;
+      res->nupdates = h_state->nupdates;
+    }
+    if (r->record && losses_out && h_state->n_recorded > 0)
+      HIP_TRY(hipMemcpy(losses_out, losses.p, (size_t)std::min(h_state->n_recorded, r->nsteps) * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_state->nonfinite) return fail(CAL_ERR_NONFINITE, "loss became non-finite after %d updates", h_state->nupdates);
+    return CAL_OK;
+  }
+
+  int model(void* mr, void* mi) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem || !has_params) return fail(CAL_ERR_STATE, "model: problem and parameters must be set");
+    if (!mr || !mi) return fail(CAL_ERR_INVALID, "model: null output");
+    const size_t rowbytes = (size_t)nbls * fpad * sizeof(T);
+    if (model_buf.bytes < 2 * rowbytes) CAL_TRY(model_buf.alloc(2 * rowbytes));
+    h_state->done = h_state->done_after = 0;
+    CAL_TRY(push_state());
+    FusedArgs<T> a = fused_args();
+    a.model_r = model_buf.as<T>();
+    a.model_i = model_buf.as<T>() + (size_t)nbls * fpad;
+    launch_fused<MODE_MODEL>(a, false);
+    HIP_TRY(hipGetLastError());
+    CAL_TRY(download_rows(mr, a.model_r, nbls, 1, 0));
+    CAL_TRY(download_rows(mi, a.model_i, nbls, 1, 0));
+    return CAL_OK;
+  }
+
+  int init_coeffs(const void* sr, const void* si) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!has_problem || !has_data) return fail(CAL_ERR_STATE, "init_coeffs: problem and data (weights) must be set");
+    if (!sr || !si) return fail(CAL_ERR_INVALID, "init_coeffs: null source");
+    const size_t rowbytes = (size_t)nbls * fpad * sizeof(T);
+    if (model_buf.bytes < 2 * rowbytes) CAL_TRY(model_buf.alloc(2 * rowbytes));
+    T* s_r = model_buf.as<T>();
+    T* s_i = s_r + (size_t)nbls * fpad;
+    CAL_TRY(upload_rows(sr, s_r, nbls, 1, 0));
+    CAL_TRY(upload_rows(si, s_i, nbls, 1, 0));
+    h_state->done = h_state->done_after = 0;
+    CAL_TRY(push_state());
+    FusedArgs<T> a = fused_args();
+    a.data_r = s_r;
+    a.data_i = s_i;
+    launch_fused<MODE_INIT>(a, false);
+    if (!gc_direct)
+      hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
+                         gcp0.as<T>() + gcp_len, gc0.as<T>(), gc0.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
+                         grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, state.as<DevState>());
+    HIP_TRY(hipGetLastError());
+    // A^T b becomes the coefficient vector (orthonormal-column bases; the host applies the Gram solve otherwise)
+    HIP_TRY(hipMemcpyAsync(coef.p, grad_c0(), 2 * (size_t)ncoef * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return CAL_OK;
+  }
+
+  int synchronize() override {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return CAL_OK;
+  }
+  int timing_enable(int e) override {
+    timing = e != 0;
+    t_launches = 0;
+    t_total_ms = 0;
+    ev_used = 0;
+    return CAL_OK;
+  }
+  int timing_get(cal_kernel_timing* out) override {
+    if (!out) return fail(CAL_ERR_INVALID, "timing_get: null");
+    if (!has_problem) return fail(CAL_ERR_STATE, "timing_get before set_problem");
+    out->launches = t_launches;
+    out->total_ms = t_total_ms;
+    // B_step = s [F sum nvec (A) + 3 F Nbl (d_r, d_i, w) + 2 sum nvec (c) + 2 Na F (g)] + s [10 sum nvec + 10 Na F]
+    const double s = sizeof(T);
+    out->basis_bytes_per_launch = basis_bytes;
+    out->algorithmic_bytes_per_launch =
+        basis_bytes + s * (3.0 * nfreqs * nbls + 2.0 * ncoef + 2.0 * nants * nfreqs) + s * (10.0 * ncoef + 10.0 * nants * nfreqs);
+    return CAL_OK;
+  }
+  int memory_bytes(int64_t* b) override {
+    if (!b) return fail(CAL_ERR_INVALID, "memory_bytes: null");
+    const DevBuf* all[] = {&tiles, &bl_tile, &bl_ant, &items, &ant_ptr, &ant_ent, &coef_grp, &grp_coff, &grp_item_ptr, &item_goff,
+                           &data_r, &data_i, &wgts, &gains, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
+                           &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf};
+    int64_t n = 0;
+    for (auto* d : all) n += (int64_t)d->bytes;
+    *b = n;
+    return CAL_OK;
+  }
+  int comm_init(const void* id, int rk, int nr) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!id || nr < 1 || rk < 0 || rk >= nr) return fail(CAL_ERR_INVALID, "comm_init: bad rank/nranks");
+    if (nccl) {
+      (void)ncclCommDestroy(nccl);
+      nccl = nullptr;
+    }
+    ncclUniqueId uid;
+    static_assert(sizeof(ncclUniqueId) <= CAL_COMM_ID_BYTES, "unique id does not fit");
+    memcpy(&uid, id, sizeof(uid));
+    NCCL_TRY(ncclCommInitRank(&nccl, nr, uid, rk));
+    nranks = nr;
+    rank = rk;
+    return CAL_OK;
+  }
+};
+
+// ================================================================================================================
+extern "C" {
+
+const char* cal_last_error(void) { return g_err.c_str(); }
+const char* cal_version(void) { return "calamity_hip 0.1 (gfx950)"; }
+
+int cal_device_count(int* count) {
+  if (!count) return fail(CAL_ERR_INVALID, "cal_device_count: null");
+  *count = 0;
+  HIP_TRY(hipGetDeviceCount(count));
+  return CAL_OK;
+}
+
+int cal_device_info(int device, char* name, size_t name_len, int64_t* total_mem_bytes, int32_t* compute_units) {
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, device));
+  if (name && name_len) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+  if (total_mem_bytes) *total_mem_bytes = (int64_t)p.totalGlobalMem;
+  if (compute_units) *compute_units = p.multiProcessorCount;
+  return CAL_OK;
+}
+
+int cal_solver_create(cal_solver** out, int device, int dtype) {
+  if (!out) return fail(CAL_ERR_INVALID, "cal_solver_create: null");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(CAL_ERR_HIP, "no usable HIP device (%s); this library has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(CAL_ERR_INVALID, "cal_solver_create: device %d out of range [0, %d)", device, n);
+  std::unique_ptr<cal_solver> s;
+  if (dtype == CAL_F32) {
+    auto* p = new SolverT<float>();
+    s.reset(p);
+    p->device = device;
+    p->dtype = dtype;
+    CAL_TRY(p->init());
+  } else if (dtype == CAL_F64) {
+    auto* p = new SolverT<double>();
+    s.reset(p);
+    p->device = device;
+    p->dtype = dtype;
+    CAL_TRY(p->init());
+  } else {
+    return fail(CAL_ERR_INVALID, "cal_solver_create: unknown dtype %d", dtype);
+  }
+  *out = s.release();
+  return CAL_OK;
+}
+
+int cal_solver_destroy(cal_solver* s) {
+  delete s;
+  return CAL_OK;
+}
+
+#define NEED(s) \
+  if (!(s)) return fail(CAL_ERR_INVALID, "%s: null solver handle", __func__)
+
+int cal_solver_set_problem(cal_solver* s, const cal_problem_desc* d) { NEED(s); return s->set_problem(d); }
+int cal_solver_set_data(cal_solver* s, const void* dr, const void* di, const void* w) { NEED(s); return s->set_data(dr, di, w); }
+int cal_solver_set_regularization(cal_solver* s, int mode, double pr, double pi) { NEED(s); return s->set_regularization(mode, pr, pi); }
+int cal_solver_set_optimizer(cal_solver* s, const cal_optimizer_desc* d) { NEED(s); return s->set_optimizer(d); }
+int cal_solver_set_params(cal_solver* s, const void* g_r, const void* g_i, const void* c_r, const void* c_i) {
+  NEED(s);
+  return s->set_params(g_r, g_i, c_r, c_i);
+}
+int cal_solver_get_params(cal_solver* s, int which, void* g_r, void* g_i, void* c_r, void* c_i) {
+  NEED(s);
+  return s->get_params(which, g_r, g_i, c_r, c_i);
+}
+int cal_solver_get_moments(cal_solver* s, void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i, void* cv_r,
+                           void* cv_i, int64_t* t) {
+  NEED(s);
+  return s->get_moments(gm_r, gm_i, gv_r, gv_i, cm_r, cm_i, cv_r, cv_i, t);
+}
+int cal_solver_set_moments(cal_solver* s, const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i, const void* cm_r,
+                           const void* cm_i, const void* cv_r, const void* cv_i, int64_t t) {
+  NEED(s);
+  return s->set_moments(gm_r, gm_i, gv_r, gv_i, cm_r, cm_i, cv_r, cv_i, t);
+}
+int cal_solver_eval_loss(cal_solver* s, double* loss) { NEED(s); return s->eval(false, loss, nullptr, nullptr, nullptr, nullptr); }
+int cal_solver_eval_grads(cal_solver* s, double* loss, void* gg_r, void* gg_i, void* gc_r, void* gc_i) {
+  NEED(s);
+  return s->eval(true, loss, gg_r, gg_i, gc_r, gc_i);
+}
+int cal_solver_run(cal_solver* s, const cal_run_desc* r, double* losses_out, cal_run_result* res) { NEED(s); return s->run(r, losses_out, res); }
+int cal_solver_model(cal_solver* s, void* mr, void* mi) { NEED(s); return s->model(mr, mi); }
+int cal_solver_init_coeffs(cal_solver* s, const void* sr, const void* si) { NEED(s); return s->init_coeffs(sr, si); }
+int cal_solver_synchronize(cal_solver* s) { NEED(s); return s->synchronize(); }
+int cal_solver_timing_enable(cal_solver* s, int e) { NEED(s); return s->timing_enable(e); }
+int cal_solver_timing_get(cal_solver* s, cal_kernel_timing* out) { NEED(s); return s->timing_get(out); }
+int cal_solver_memory_bytes(cal_solver* s, int64_t* b) { NEED(s); return s->memory_bytes(b); }
+
+int cal_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(CAL_ERR_INVALID, "cal_comm_unique_id: null");
+  ncclUniqueId uid;
+  NCCL_TRY(ncclGetUniqueId(&uid));
+  memset(id_out, 0, CAL_COMM_ID_BYTES);
+  memcpy(id_out, &uid, sizeof(uid));
+  return CAL_OK;
+}
+int cal_solver_comm_init(cal_solver* s, const void* id, int rank, int nranks) { NEED(s); return s->comm_init(id, rank, nranks); }
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+"""Thin object wrapper over the C-ABI handle (include/calamity_hip.h).  NumPy in, NumPy out."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .problem import FitProblem
+
+# OPTIMIZERS of /root/reference/calamity/calibration.py:17-27 that the HIP fitter implements; any other name raises
+# KeyError exactly like ``OPTIMIZERS[optimizer]`` at calibration.py:571.
+OPTIMIZERS = {"Adam": _lib.CAL_OPT_ADAM, "Adamax": _lib.CAL_OPT_ADAMAX}
+_OPT_KEYS = ("learning_rate", "beta_1", "beta_2", "epsilon")
+_OPT_DEFAULTS = dict(learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)  # Keras defaults
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HipFitSolver:
+    """One gain + foreground fit resident on one MI355X."""
+
+    def __init__(self, dtype=np.float32, device=0):
+        self._lib = _lib.load()
+        self.dtype = np.dtype(dtype)
+        if self.dtype == np.float32:
+            code = _lib.CAL_F32
+        elif self.dtype == np.float64:
+            code = _lib.CAL_F64
+        else:
+            raise ValueError(f"dtype must be float32 or float64, got {dtype}")
+        self._h = C.c_void_p()
+        _lib.check(self._lib.cal_solver_create(C.byref(self._h), int(device), code))
+        self.problem = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cal_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _real(self, a, shape=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if shape is not None and a.shape != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+        return a
+
+    # ---- problem -------------------------------------------------------------------------------------------
+    def set_problem(self, prob: FitProblem, layout="stream"):
+        prob.validate()
+        basis = [np.ascontiguousarray(b, dtype=self.dtype) for b in prob.basis]
+        sizes = np.asarray([b.size for b in basis], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        flat = np.concatenate([b.ravel() for b in basis]) if len(basis) > 1 else basis[0].ravel()
+        nvec = np.asarray([b.shape[1] for b in basis], dtype=np.int32)
+        nrb = np.asarray([b.shape[0] // prob.nfreqs for b in basis], dtype=np.int32)
+        keep = [
+            flat, offs, nvec, nrb,
+            np.ascontiguousarray(prob.grp_basis, dtype=np.int32),
+            np.ascontiguousarray(prob.grp_bl_start, dtype=np.int32),
+            np.ascontiguousarray(prob.bl_ant0, dtype=np.int32),
+            np.ascontiguousarray(prob.bl_ant1, dtype=np.int32),
+            np.ascontiguousarray(prob.bl_rowblk, dtype=np.int32),
+        ]
+        d = _lib.ProblemDesc(
+            nants=prob.nants, nfreqs=prob.nfreqs, ngrps=prob.ngrps, nbls=prob.nbls, nbasis=len(basis),
+            basis_offset=_ptr(offs), basis_nvec=_ptr(nvec), basis_nrowblk=_ptr(nrb), basis_data=_ptr(flat),
+            grp_basis=_ptr(keep[4]), grp_bl_start=_ptr(keep[5]), bl_ant0=_ptr(keep[6]), bl_ant1=_ptr(keep[7]),
+            bl_rowblk=_ptr(keep[8]),
+            layout={"stream": _lib.CAL_LAYOUT_STREAM, "shared": _lib.CAL_LAYOUT_SHARED}[layout],
+        )
+        _lib.check(self._lib.cal_solver_set_problem(self._h, C.byref(d)))
+        self.problem = prob
+        self.nants, self.nfreqs, self.nbls, self.ncoeffs = prob.nants, prob.nfreqs, prob.nbls, prob.ncoeffs
+        if prob.data_r is not None:
+            self.set_data(prob.data_r, prob.data_i, prob.wgts)
+        return self
+
+    def set_data(self, data_r, data_i, wgts):
+        shp = (self.nbls, self.nfreqs)
+        a, b, c = self._real(data_r, shp), self._real(data_i, shp), self._real(wgts, shp)
+        _lib.check(self._lib.cal_solver_set_data(self._h, _ptr(a), _ptr(b), _ptr(c)))
+
+    def set_regularization(self, mode=None, prior_r_sum=0.0, prior_i_sum=0.0):
+        code = _lib.CAL_REG_SUM if mode == "sum" else _lib.CAL_REG_NONE
+        _lib.check(self._lib.cal_solver_set_regularization(self._h, code, float(prior_r_sum), float(prior_i_sum)))
+
+    def set_optimizer(self, optimizer="Adamax", **opt_kwargs):
+        opt_id = OPTIMIZERS[optimizer]  # KeyError for anything else, like calibration.py:571
+        unknown = set(opt_kwargs) - set(_OPT_KEYS)
+        if unknown:
+            raise TypeError(f"Unexpected keyword argument(s) passed to optimizer: {sorted(unknown)}")
+        kw = dict(_OPT_DEFAULTS, **opt_kwargs)
+        d = _lib.OptimizerDesc(opt_id, kw["learning_rate"], kw["beta_1"], kw["beta_2"], kw["epsilon"])
+        _lib.check(self._lib.cal_solver_set_optimizer(self._h, C.byref(d)))
+
+    # ---- parameters ----------------------------------------------------------------------------------------
+    def set_params(self, g_r=None, g_i=None, c_r=None, c_i=None):
+        gs, cs = (self.nants, self.nfreqs), (self.ncoeffs,)
+        arrs = [None if a is None else self._real(a, s) for a, s in ((g_r, gs), (g_i, gs), (c_r, cs), (c_i, cs))]
+        _lib.check(self._lib.cal_solver_set_params(self._h, *[_ptr(a) for a in arrs]))
+
+    def get_params(self, which=0):
+        g_r = np.empty((self.nants, self.nfreqs), dtype=self.dtype)
+        g_i = np.empty_like(g_r)
+        c_r = np.empty(self.ncoeffs, dtype=self.dtype)
+        c_i = np.empty_like(c_r)
+        _lib.check(self._lib.cal_solver_get_params(self._h, int(which), _ptr(g_r), _ptr(g_i), _ptr(c_r), _ptr(c_i)))
+        return g_r, g_i, c_r, c_i
+
+    def get_moments(self):
+        g = [np.empty((self.nants, self.nfreqs), dtype=self.dtype) for _ in range(4)]
+        c = [np.empty(self.ncoeffs, dtype=self.dtype) for _ in range(4)]
+        t = C.c_int64(0)
+        _lib.check(self._lib.cal_solver_get_moments(self._h, *[_ptr(a) for a in g + c], C.byref(t)))
+        return dict(gm_r=g[0], gm_i=g[1], gv_r=g[2], gv_i=g[3], cm_r=c[0], cm_i=c[1], cv_r=c[2], cv_i=c[3], t=t.value)
+
+    def set_moments(self, gm_r, gm_i, gv_r, gv_i, cm_r, cm_i, cv_r, cv_i, t):
+        gs, cs = (self.nants, self.nfreqs), (self.ncoeffs,)
+        arrs = [self._real(a, gs) for a in (gm_r, gm_i, gv_r, gv_i)] + [self._real(a, cs) for a in (cm_r, cm_i, cv_r, cv_i)]
+        _lib.check(self._lib.cal_solver_set_moments(self._h, *[_ptr(a) for a in arrs], int(t)))
+
+    # ---- compute -------------------------------------------------------------------------------------------
+    def eval_loss(self):
+        loss = C.c_double(0)
+        _lib.check(self._lib.cal_solver_eval_loss(self._h, C.byref(loss)))
+        return loss.value
+
+    def eval_grads(self):
+        gg_r = np.empty((self.nants, self.nfreqs), dtype=self.dtype)
+        gg_i = np.empty_like(gg_r)
+        gc_r = np.empty(self.ncoeffs, dtype=self.dtype)
+        gc_i = np.empty_like(gc_r)
+        loss = C.c_double(0)
+        _lib.check(self._lib.cal_solver_eval_grads(self._h, C.byref(loss), _ptr(gg_r), _ptr(gg_i), _ptr(gc_r), _ptr(gc_i)))
+        return loss.value, gg_r, gg_i, gc_r, gc_i
+
+    def run(self, nsteps, record=True, tol=1e-14, use_min=False, freeze_model=False):
+        """``nsteps`` train steps at most.  Returns (recorded losses, stopped, nupdates)."""
+        d = _lib.RunDesc(int(nsteps), int(bool(record)), int(bool(use_min)), int(bool(freeze_model)), float(tol))
+        losses = np.zeros(max(int(nsteps), 1), dtype=np.float64)
+        res = _lib.RunResult()
+        _lib.check(self._lib.cal_solver_run(self._h, C.byref(d), _ptr(losses), C.byref(res)))
+        return losses[: res.nrecorded], bool(res.stopped), res.nupdates
+
+    def model(self):
+        m_r = np.empty((self.nbls, self.nfreqs), dtype=self.dtype)
+        m_i = np.empty_like(m_r)
+        _lib.check(self._lib.cal_solver_model(self._h, _ptr(m_r), _ptr(m_i)))
+        return m_r, m_i
+
+    def init_coeffs(self, src_r, src_i):
+        shp = (self.nbls, self.nfreqs)
+        a, b = self._real(src_r, shp), self._real(src_i, shp)
+        _lib.check(self._lib.cal_solver_init_coeffs(self._h, _ptr(a), _ptr(b)))
+
+    def synchronize(self):
+        _lib.check(self._lib.cal_solver_synchronize(self._h))
+
+    def timing_enable(self, enable=True):
+        _lib.check(self._lib.cal_solver_timing_enable(self._h, int(bool(enable))))
+
+    def timing_get(self):
+        t = _lib.KernelTiming()
+        _lib.check(self._lib.cal_solver_timing_get(self._h, C.byref(t)))
+        return dict(launches=t.launches, total_ms=t.total_ms, algorithmic_bytes_per_launch=t.algorithmic_bytes_per_launch,
+                    basis_bytes_per_launch=t.basis_bytes_per_launch)
+
+    def memory_bytes(self):
+        n = C.c_int64(0)
+        _lib.check(self._lib.cal_solver_memory_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        buf = C.create_string_buffer(bytes(unique_id), _lib.CAL_COMM_ID_BYTES)
+        _lib.check(self._lib.cal_solver_comm_init(self._h, buf, int(rank), int(nranks)))
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(_lib.CAL_COMM_ID_BYTES)
+    _lib.check(_lib.load().cal_comm_unique_id(buf))
+    return buf.raw

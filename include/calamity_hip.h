@@ -1,0 +1,162 @@
+/* calamity_hip.h -- C-ABI of the MI355X (gfx950) gain + foreground gradient-descent fitter.
+ *
+ * The reference (aewallwi/calamity) has no FFI: its seam is the Python function
+ *   fit_gains_and_foregrounds(...)            /root/reference/calamity/calibration.py:447-738
+ * whose arithmetic is issued as TensorFlow ops (fg_model/data_model/mse/mse_chunked[_sum_regularized],
+ * calibration.py:1587-1656; tf.GradientTape :664-666; tf.optimizers.* apply_gradients :667).  The entry
+ * points below are what a ctypes binding for that seam needs; each one cites the reference code it
+ * replaces.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative cal_status on failure; cal_last_error() returns a
+ *    thread-local message.  Nothing throws across the boundary.
+ *  - all host pointers are caller-owned, C-contiguous, and are only read/written inside the call.
+ *  - "real" arrays (void*) are float when the solver was created with CAL_F32 and double with CAL_F64.
+ *  - the library owns every byte of device memory.  One handle is not re-entrant; distinct handles may be
+ *    driven from distinct threads.
+ *  - there is NO CPU fallback: without a usable HIP device cal_solver_create() fails.
+ */
+#ifndef CALAMITY_HIP_H
+#define CALAMITY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cal_solver cal_solver;
+
+enum cal_status {
+  CAL_OK = 0,
+  CAL_ERR_INVALID = -1, /* bad argument / inconsistent problem description */
+  CAL_ERR_HIP = -2,     /* HIP runtime failure */
+  CAL_ERR_RCCL = -3,    /* RCCL failure */
+  CAL_ERR_STATE = -4,   /* call made in the wrong state (e.g. run before set_problem) */
+  CAL_ERR_UNSUPPORTED = -5,
+  CAL_ERR_NONFINITE = -6 /* loss became NaN/Inf; parameters are left as they were at that step */
+};
+
+enum cal_dtype { CAL_F32 = 0, CAL_F64 = 1 };                 /* dtype kwarg, calibration.py:464, :974 */
+enum cal_optimizer { CAL_OPT_ADAM = 0, CAL_OPT_ADAMAX = 1 }; /* OPTIMIZERS, calibration.py:17-27 */
+enum cal_regularization { CAL_REG_NONE = 0, CAL_REG_SUM = 1 }; /* model_regularization, calibration.py:619-661 */
+enum cal_layout {
+  CAL_LAYOUT_STREAM = 0, /* every baseline owns its basis tiles in HBM (the reference's per-baseline tensor,
+                            calibration.py:167-184, minus the zero padding): HBM-streaming kernel */
+  CAL_LAYOUT_SHARED = 1  /* baselines alias the unique basis blocks (one per distinct delay, the operator_cache
+                            of modeling.py:291-301): cache-resident basis */
+};
+
+/* Ragged description of one fit (replaces the zero-padded chunk tensors built by
+ * tensorize_fg_model_comps_dict / tensorize_data, calibration.py:104-310).
+ * A fitting group g shares ONE coefficient vector of basis_nvec[grp_basis[g]] complex numbers; its baselines are
+ * bl in [grp_bl_start[g], grp_bl_start[g+1]).  Basis block u is row-major
+ * [basis_nrowblk[u] * nfreqs][basis_nvec[u]] starting at basis_data + basis_offset[u] elements
+ * ("Nfreqs x Ncomponents", modeling.py:288-289); baseline bl uses rows
+ * [bl_rowblk[bl] * nfreqs, (bl_rowblk[bl] + 1) * nfreqs). */
+typedef struct cal_problem_desc {
+  int32_t nants;
+  int32_t nfreqs;
+  int32_t ngrps;
+  int32_t nbls;
+  int32_t nbasis;
+  const int64_t* basis_offset;   /* [nbasis + 1] */
+  const int32_t* basis_nvec;     /* [nbasis] */
+  const int32_t* basis_nrowblk;  /* [nbasis] */
+  const void* basis_data;        /* real */
+  const int32_t* grp_basis;      /* [ngrps] */
+  const int32_t* grp_bl_start;   /* [ngrps + 1] */
+  const int32_t* bl_ant0;        /* [nbls]  corr_inds[..][..][bl][0], calibration.py:176-177 */
+  const int32_t* bl_ant1;        /* [nbls] */
+  const int32_t* bl_rowblk;      /* [nbls] */
+  int32_t layout;                /* cal_layout */
+} cal_problem_desc;
+
+typedef struct cal_optimizer_desc { /* **opt_kwargs -> tf.optimizers.X(...), calibration.py:571 */
+  int32_t optimizer;              /* cal_optimizer */
+  double learning_rate;           /* Keras defaults: 1e-3, 0.9, 0.999, 1e-7 */
+  double beta_1;
+  double beta_2;
+  double epsilon;
+} cal_optimizer_desc;
+
+typedef struct cal_run_desc { /* loop controls of fit_gains_and_foregrounds, calibration.py:457-461 */
+  int32_t nsteps;           /* number of train steps to issue at most */
+  int32_t record;           /* 0: unrecorded updates (profile steps :681-687 and the "graph build" step :693);
+                               1: recorded steps of the main loop :699-717 */
+  int32_t use_min;          /* :702-710 */
+  int32_t freeze_model;     /* :598-603 */
+  double tol;               /* :712 (only consulted when record != 0) */
+} cal_run_desc;
+
+typedef struct cal_run_result {
+  int32_t nrecorded; /* losses written to losses_out by this call */
+  int32_t stopped;   /* 1 if the tolerance test ended the loop */
+  int32_t nupdates;  /* optimizer updates applied by this call */
+  int32_t reserved;
+} cal_run_result;
+
+typedef struct cal_kernel_timing { /* HIP-event timing of the fused basis-streaming kernel (bench.py roofline) */
+  int64_t launches;
+  double total_ms;
+  double algorithmic_bytes_per_launch; /* SURVEY.md 8(d) B_step figure restated for this problem */
+  double basis_bytes_per_launch;
+} cal_kernel_timing;
+
+const char* cal_last_error(void);
+const char* cal_version(void);
+int cal_device_count(int* count);
+int cal_device_info(int device, char* name, size_t name_len, int64_t* total_mem_bytes, int32_t* compute_units);
+
+/* tf.device / GPU selection of read_calibrate_and_model_dpss, calibration.py:1741-1753, :1796-1804 */
+int cal_solver_create(cal_solver** out, int device, int dtype);
+int cal_solver_destroy(cal_solver* s);
+
+/* tensorize_fg_model_comps_dict, calibration.py:104-190 (called once per dataset, :1143-1152) */
+int cal_solver_set_problem(cal_solver* s, const cal_problem_desc* desc);
+/* tensorize_data, calibration.py:193-310 (per pol/time): [nbls][nfreqs] real each; weights already normalised */
+int cal_solver_set_data(cal_solver* s, const void* data_r, const void* data_i, const void* wgts);
+/* model_regularization="sum": priors of calibration.py:619-625; mode = cal_regularization */
+int cal_solver_set_regularization(cal_solver* s, int mode, double prior_r_sum, double prior_i_sum);
+int cal_solver_set_optimizer(cal_solver* s, const cal_optimizer_desc* desc); /* also zeroes moments and t */
+
+/* tf.Variable(g_r), ... calibration.py:596-603.  gains [nants][nfreqs]; coefficients flat in group order,
+ * sum_g nvec_g reals each.  Any pointer may be NULL to leave that array untouched. */
+int cal_solver_set_params(cal_solver* s, const void* g_r, const void* g_i, const void* c_r, const void* c_i);
+/* .value() snapshots, calibration.py:706-710, :724-728.  which = 0: current parameters; 1: use_min snapshot */
+int cal_solver_get_params(cal_solver* s, int which, void* g_r, void* g_i, void* c_r, void* c_i);
+/* optimizer slots (checkpoint / resume; no counterpart in the reference): m and v (Adam) / u (Adamax) */
+int cal_solver_get_moments(cal_solver* s, void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i,
+                           void* cv_r, void* cv_i, int64_t* t);
+int cal_solver_set_moments(cal_solver* s, const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i,
+                           const void* cm_r, const void* cm_i, const void* cv_r, const void* cv_i, int64_t t);
+
+/* loss_function() alone: mse_chunked / mse_chunked_sum_regularized, calibration.py:1612-1656 */
+int cal_solver_eval_loss(cal_solver* s, double* loss);
+/* tape.gradient(loss, vars), calibration.py:664-666, without the update (parity tests) */
+int cal_solver_eval_grads(cal_solver* s, double* loss, void* gg_r, void* gg_i, void* gc_r, void* gc_i);
+/* train_step() x nsteps with the loop semantics of calibration.py:681-717; losses_out: [nsteps] doubles or NULL */
+int cal_solver_run(cal_solver* s, const cal_run_desc* run, double* losses_out, cal_run_result* result);
+/* yield_fg_model_array, calibration.py:402-444, per baseline instead of a nants x nants cube: [nbls][nfreqs] */
+int cal_solver_model(cal_solver* s, void* model_r, void* model_i);
+/* tensorize_fg_coeffs, calibration.py:828-913: per group least squares of src on the basis with samples of zero
+ * weight zeroed; the result becomes the current coefficients.  src_*: [nbls][nfreqs] real. */
+int cal_solver_init_coeffs(cal_solver* s, const void* src_r, const void* src_i);
+
+int cal_solver_synchronize(cal_solver* s);
+int cal_solver_timing_enable(cal_solver* s, int enable);
+int cal_solver_timing_get(cal_solver* s, cal_kernel_timing* out);
+int cal_solver_memory_bytes(cal_solver* s, int64_t* device_bytes);
+
+/* Baseline-sharded data parallelism (no counterpart in the reference, which is single-device,
+ * calibration.py:1796-1804): one process per GPU, one RCCL all-reduce of the per-antenna gain gradients and the
+ * loss scalars per step.  id: CAL_COMM_ID_BYTES bytes produced on rank 0 and shared out of band. */
+#define CAL_COMM_ID_BYTES 128
+int cal_comm_unique_id(void* id_out);
+int cal_solver_comm_init(cal_solver* s, const void* id, int rank, int nranks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALAMITY_HIP_H */
