@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- Adam steps/s (+ chi^2 evals/s) of the gain + foreground fitter on synthetic HERA-350 x 1024-channel
+per-baseline DPSS visibilities, with the HBM roofline of the fused basis-streaming kernel and a CPU baseline.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one train step of /root/reference/calamity/calibration.py:663-668 (loss + all adjoints + optimizer update
+of gains and coefficients) for every time slice of the job.  N = 1: one time slice on one GPU.  N > 1 (launched by
+torch.distributed.run, one rank per GPU): N time slices, every slice's baselines sharded over the N ranks, one RCCL
+all-reduce of the per-antenna gain gradients + loss scalars per slice-step -- per-GPU work is constant (weak scaling)
+and value = N slice-steps per wall step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="hera350", choices=["hera350", "hera37", "tutorial"])
+    ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
+    ap.add_argument("--layout", default="stream", choices=["stream", "shared"])
+    ap.add_argument("--optimizer", default="Adam")
+    ap.add_argument("--reg", default="none", choices=["none", "sum"])
+    ap.add_argument("--max-bls", type=int, default=None, help="bounded sample of the baselines (debugging)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-bls", type=int, default=192)
+    return ap.parse_args()
+
+
+def cpu_baseline(prob, start, dtype, optimizer, sample_bls, reg):
+    """Reference-faithful CPU port (oracle/ref_numpy.py: the op sequence of calibration.py:1587-1609 on the
+    zero-padded (nvecs, ngrps, nbls, nfreqs) tensor + hand adjoints + Keras Adam), timed on a bounded sample."""
+    from calamity_amd import problem as P
+    from oracle import ref_numpy as R
+
+    nb = prob.nbls
+    sel = np.linspace(0, nb - 1, min(sample_bls, nb)).astype(np.int64)
+    coff = prob.grp_coff
+    sub = P.FitProblem(
+        nants=prob.nants, nfreqs=prob.nfreqs, basis=prob.basis, grp_basis=prob.grp_basis[sel],
+        grp_bl_start=np.arange(len(sel) + 1, dtype=np.int32), bl_ant0=prob.bl_ant0[sel], bl_ant1=prob.bl_ant1[sel],
+        bl_rowblk=prob.bl_rowblk[sel], data_r=prob.data_r[sel], data_i=prob.data_i[sel], wgts=prob.wgts[sel],
+    )
+    c_r = np.concatenate([start["c_r"][coff[g] : coff[g + 1]] for g in sel])
+    c_i = np.concatenate([start["c_i"][coff[g] : coff[g + 1]] for g in sel])
+    ch = P.chunks_from_problem(sub, dtype=dtype)
+    fg_r = P.coeffs_to_chunks(sub, c_r, dtype)
+    fg_i = P.coeffs_to_chunks(sub, c_i, dtype)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    g_r, g_i = start["g_r"].astype(dtype), start["g_i"].astype(dtype)
+    opt = R.OPTIMIZERS[optimizer](learning_rate=1e-2)
+
+    def step():
+        loss, gg_r, gg_i, gf_r, gf_i = R.loss_and_grads(g_r, g_i, fg_r, fg_i, ch["fg_comps"], ch["data_r"], ch["data_i"], ch["wgts"], a0, a1)
+        opt.apply_gradients([(gg_r, g_r), (gg_i, g_i)] + list(zip(gf_r, fg_r)) + list(zip(gf_i, fg_i)))
+        return loss
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 50):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    # the sample holds len(sel)/nb of the job's baselines; the full job costs nb/len(sel) as much per step
+    full_rate = 1.0 / (dt * nb / len(sel))
+    padded_bytes = ch["fg_comps"][0].nbytes
+    return dict(
+        value=full_rate, unit="steps/s", cores=1, kind="port",
+        sample=f"{len(sel)} of {nb} baselines (evenly spaced), {n} Adam steps of the NumPy restatement on the zero-padded "
+               f"({ch['fg_comps'][0].shape[0]} x {len(sel)} x 1 x {prob.nfreqs}) tensor ({padded_bytes / 1e6:.0f} MB, {np.dtype(dtype).name}); "
+               f"{dt * 1e3:.1f} ms per sample step, scaled by {nb}/{len(sel)}",
+    )
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    from calamity_amd import synthetic
+    from calamity_amd.solver import HipFitSolver, comm_unique_id
+
+    dtype = {"f32": np.float32, "f64": np.float64, None: np.float64 if args.config == "hera37" else np.float32}[args.dtype]
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rendezvous + barrier only (gloo, CPU); the data path is RCCL inside the library
+
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    t_setup = time.perf_counter()
+    ntimes = world
+    prob, truth, start = synthetic.make_config(args.config, max_bls=args.max_bls, with_sky=args.reg == "sum")
+    solvers = []
+    if world == 1:
+        s = HipFitSolver(dtype=dtype, device=0)
+        s.set_problem(prob, layout=args.layout)
+        s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        solvers.append(s)
+    else:
+        from calamity_amd import distributed as D
+
+        shard = D.shard_problem(prob, start, rank, world)
+        ids = [None] * ntimes
+        if rank == 0:
+            ids = [comm_unique_id() for _ in range(ntimes)]
+        dist.broadcast_object_list(ids, src=0)
+        for t in range(ntimes):
+            s = HipFitSolver(dtype=dtype, device=local_rank)
+            sp, ss = shard
+            if t > 0:
+                # further time slices: same array and bases, independent noise realisation
+                sp, ss = D.reseed_shard(shard, seed=1000 + t)
+            s.set_problem(sp, layout=args.layout)
+            s.set_params(ss["g_r"], ss["g_i"], ss["c_r"], ss["c_i"])
+            s.comm_init(ids[t], rank, world)
+            solvers.append(s)
+    for s in solvers:
+        if args.reg == "sum":
+            s.set_regularization("sum", float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts)))
+        s.set_optimizer(args.optimizer, learning_rate=1e-2)
+    t_setup = time.perf_counter() - t_setup
+
+    def sync():
+        for s in solvers:
+            s.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def run_steps(n, record):
+        for s in solvers:
+            s.run(n, record=record, tol=0.0)
+
+    run_steps(args.warmup, False) if args.warmup > 0 else None
+    for s in solvers:
+        s.timing_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    run_steps(args.steps, True)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    tim = solvers[0].timing_get()
+    for s in solvers:
+        s.timing_enable(False)
+    # chi^2 evaluations per second (forward only), untimed part of the contract
+    sync()
+    t1 = time.perf_counter()
+    nev = max(3, args.steps // 2)
+    for _ in range(nev):
+        for s in solvers:
+            s.eval_loss()
+    sync()
+    chi2_rate = nev * ntimes / (time.perf_counter() - t1)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = args.steps * ntimes / dt
+        kern_ms = tim["total_ms"] / max(tim["launches"], 1)
+        achieved = tim["algorithmic_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "Adam steps/sec (chi2 eval/sec in extra), HERA-350 1024ch DPSS; %HBM roofline",
+            "value": value,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == np.float32 else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: {prob.nants} antennas, {prob.nbls} baselines x {prob.nfreqs} channels, per-baseline DPSS "
+                            f"(sum nvec = {prob.ncoeffs}), {ntimes} time slice(s), optimizer {args.optimizer} lr 1e-2, "
+                            f"model_regularization {args.reg}",
+                "layout": args.layout,
+                "parallelism": f"baselines sharded over {world} GPU(s), gain-gradient all-reduce per slice-step" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "fused_basis_kernel<MODE_GRAD>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": kern_ms,
+                "algorithmic_bytes_per_launch": tim["algorithmic_bytes_per_launch"],
+            },
+            "extra": {
+                "chi2_evals_per_s": chi2_rate,
+                "setup_s": t_setup,
+                "device_memory_GB": solvers[0].memory_bytes() / 1e9 * len(solvers),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, start, dtype, args.optimizer, args.cpu_sample_bls, args.reg)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,9 @@ TOL = {np.float64: dict(loss=1e-10, grad=1e-10, traj=1e-8), np.float32: dict(los
 
 
 def relnorm(a, b):
-    return np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / max(np.linalg.norm(b), 1e-300)
+    a = np.asarray(a)
+    a = a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
 def make_case(nants=9, nfreqs=40, seed=0, with_sky=False, redundant=False, perturb=True):
