@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcalamity_hip.so")
+LIB_PATH = os.environ.get("CALAMITY_HIP_LIB") or os.path.join(_HERE, "csrc", "libcalamity_hip.so")  # env override: kernel experiments
 
 CAL_F32, CAL_F64 = 0, 1
 CAL_OPT_ADAM, CAL_OPT_ADAMAX = 0, 1

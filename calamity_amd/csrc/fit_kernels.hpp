@@ -24,7 +24,10 @@ namespace calk {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kTileBytes = 28672;  // 7 x (256 threads x 16 B)
+#ifndef CAL_TILE_LOADS
+#define CAL_TILE_LOADS 7
+#endif
+constexpr int kTileBytes = CAL_TILE_LOADS * 4096;  // loads per thread x (256 threads x 16 B)
 constexpr int kMaxLoads = kTileBytes / (kThreads * 16);
 
 template <typename T> struct Vec2;
@@ -174,6 +177,12 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
 #pragma unroll
   for (int j = 0; j < C::KCH; ++j) acc0_r[j] = acc0_i[j] = acc1_r[j] = acc1_i[j] = 0;
   double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
+  // gbar_G of the previous tile, stored one tile late: CDNA4 retires loads and stores of a wave in issue order
+  // (vmcnt), so a store issued mid-tile would sit in front of the wait for the next tile's loads; issued just
+  // before those loads it completes under their latency instead
+  T2 q0_prev, q1_prev;
+  q0_prev.x = q0_prev.y = q1_prev.x = q1_prev.y = 0;
+  long long o_prev = -1;
 
   issue_tile(it.tile0);
   for (int tau = it.tile0; tau < it.tile1; ++tau) {
@@ -192,9 +201,14 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     const int bl = p_bl;
     const int fbk = tau % ntpb;
     __syncthreads();
+    if (MODE == MODE_GRAD && tid < FB && o_prev >= 0) {
+      A.q0[o_prev] = q0_prev;
+      if (REG) A.q1[o_prev] = q1_prev;
+    }
     if (tau + 1 < it.tile1) issue_tile(tau + 1);
 
     // ---- forward: v[f] = sum_k A[k][f] c[k]; thread = (channel f, k-slice ks)
+#ifndef CAL_X_NOFWD
     if (MODE != MODE_INIT) {
       const int f = tid % FB;
       const int ks = tid / FB;
@@ -209,6 +223,7 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       s_pv[tid] = vr;
       s_pv[kThreads + tid] = vi;
     }
+#endif
     __syncthreads();
     if (tid < FB) {
       T vr = 0, vi = 0;
@@ -249,15 +264,14 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
           T2 q;
           q.x = vr * e_r + vi * e_i;
           q.y = vr * e_i - vi * e_r;
-          A.q0[o] = q;
+          q0_prev = q;
+          o_prev = o;
           if (REG) {
             // the part of e that multiplies alpha: w (real)
             s_gv[2 * FB + tid] = G_r * w;
             s_gv[3 * FB + tid] = -G_i * w;
-            T2 q1;
-            q1.x = vr * w;
-            q1.y = -vi * w;
-            A.q1[o] = q1;
+            q1_prev.x = vr * w;
+            q1_prev.y = -vi * w;
           }
         }
       }
@@ -265,6 +279,7 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     if (BWD) {
       __syncthreads();
       // ---- adjoint: gc[k] += sum_f A[k][f] gbar_v[f]; wave = channel quarter, lane = vector (64 per chunk)
+#ifndef CAL_X_NOBWD
       const int f_lo = wave * C::CW;
 #pragma unroll
       for (int j = 0; j < C::KCH; ++j) {
@@ -293,10 +308,15 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
           }
         }
       }
+#endif
     }
     __syncthreads();  // tile and gbar_v fully consumed before the next tile overwrites them
   }
 
+  if (MODE == MODE_GRAD && tid < FB && o_prev >= 0) {
+    A.q0[o_prev] = q0_prev;
+    if (REG) A.q1[o_prev] = q1_prev;
+  }
   // ---- item epilogue: loss partials (double), coefficient-gradient partials
   if (MODE == MODE_LOSS || MODE == MODE_GRAD) {
     double* s_red = reinterpret_cast<double*>(s_pv);  // reuse: 3 x kWaves doubles

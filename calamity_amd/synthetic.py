@@ -6,6 +6,8 @@ DPSS basis per unique rounded delay (modeling.py:293), truth ``c[k] ~ (N + iN)/(
 (calibration.py:282-303), data divided by the rms of the unflagged samples (calibration.py:1178-1190),
 start at unity gains and ``c0 = A^T (d * [w != 0])`` (calibration.py:875-902; DPSS columns are orthonormal).
 """
+import os
+
 import numpy as np
 
 from . import modeling
@@ -61,10 +63,11 @@ def make_problem(
     if operator_cache is None:
         operator_cache = {}
     uniq, inv = np.unique(dlys, return_inverse=True)
-    basis = []
-    for d in uniq:
-        L = lengths[np.where(dlys == d)[0][0]]
-        basis.append(modeling.yield_dpss_model_comps_bl_grp(L, freqs, operator_cache=operator_cache))
+    from concurrent.futures import ThreadPoolExecutor
+
+    rep_len = [lengths[np.where(dlys == d)[0][0]] for d in uniq]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:  # LAPACK/BLAS release the GIL
+        basis = list(ex.map(lambda L: modeling.yield_dpss_model_comps_bl_grp(L, freqs, operator_cache=operator_cache), rep_len))
     nbls = len(i_idx)
     grp_basis = inv.astype(np.int32)
     nvec = np.asarray([basis[b].shape[1] for b in grp_basis])
@@ -76,8 +79,8 @@ def make_problem(
     vis = np.empty((nbls, nfreqs), dtype=np.complex128)
     for u in range(len(basis)):
         bls = np.where(grp_basis == u)[0]
-        cu = np.stack([c_true[coff[b] : coff[b + 1]] for b in bls], axis=1)  # (nvec, nb)
-        vis[bls] = (basis[u] @ cu).T
+        idx = coff[bls][None, :] + np.arange(basis[u].shape[1])[:, None]  # (nvec, nb)
+        vis[bls] = (basis[u] @ c_true[idx]).T
     sig_rms = np.sqrt(np.mean(np.abs(vis) ** 2))
     data = g_true[i_idx] * np.conj(g_true[j_idx]) * vis
     data += noise_frac * sig_rms * (rng.standard_normal(data.shape) + 1j * rng.standard_normal(data.shape)) / np.sqrt(2.0)
@@ -107,9 +110,8 @@ def make_problem(
     dm = data * (~flags)
     for u in range(len(basis)):
         bls = np.where(grp_basis == u)[0]
-        cu = basis[u].T @ dm[bls].T  # (nvec, nb)
-        for n, b in enumerate(bls):
-            c0[coff[b] : coff[b + 1]] = cu[:, n]
+        idx = coff[bls][None, :] + np.arange(basis[u].shape[1])[:, None]
+        c0[idx] = basis[u].T @ dm[bls].T  # (nvec, nb)
     truth = dict(c=c_true / rms, g=g_true, rms=rms, freqs=freqs, antpos=antpos, flags=flags)
     start = dict(
         g_r=np.ones((nants, nfreqs)),
