@@ -1,0 +1,650 @@
+"""Drop-in counterparts of the fit path of /root/reference/calamity/calibration.py, running on the MI355X HIP
+library (include/calamity_hip.h) instead of TensorFlow.
+
+Same function names, argument meaning and error behaviour as the reference for the gain + foreground
+gradient-descent fitter: ``calibrate_and_model_dpss`` (:1503-1584) -> ``calibrate_and_model_tensor`` (:963-1331)
+-> ``fit_gains_and_foregrounds`` (:447-738).  Differences a user can observe:
+
+* tensors are NumPy arrays, and the foreground components are kept ragged (``problem.FitProblem``: true vector counts,
+  identical basis blocks stored once) instead of one zero-padded ``(nvecs, ngrps, nbls, nfreqs)`` tensor per chunk
+  (:140-146, :167); ``fg_comps`` arguments accept either form;
+* ``graph_mode`` / ``graph_args_dict`` are accepted and ignored (there is no tracing compiler on this path);
+* ``n_profile_steps`` writes HIP-event kernel timings as JSON into ``profile_log_dir`` instead of a TF profile;
+* optimizers: "Adam" and "Adamax" (Keras semantics); every other name raises ``KeyError`` like ``OPTIMIZERS[...]`` (:571).
+
+There is no CPU fallback: without the HIP library / a GPU these functions raise.
+"""
+import copy
+import datetime
+import json
+import os
+
+import numpy as np
+
+from . import cal_utils, modeling
+from .problem import FitProblem, coeffs_from_chunks, coeffs_to_chunks, problem_from_chunks
+from .solver import OPTIMIZERS, HipFitSolver
+from .utils import PBARS, echo
+from .uvcompat import is_uvcal, is_uvdata, polstr2num
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# layout: calibration.py:30-190
+# ------------------------------------------------------------------------------------------------------------------
+def chunk_fg_comp_dict_by_nbls(fg_model_comps_dict, use_redundancy=False, grp_size_threshold=5):
+    """Group fitting groups into chunks keyed ``(nbl, maxvecs)`` -- behaviour of calibration.py:30-101.
+
+    Without ``use_redundancy`` a fitting group whose redundant groups all have the same length (and that has fewer
+    than ``grp_size_threshold`` of them) is split into one fitting group per redundant copy, all sharing the same
+    modeling vectors (:69-81).
+    """
+    comps = dict(fg_model_comps_dict)
+    if not use_redundancy:
+        for fit_grp in list(comps.keys()):
+            rlens = np.asarray([len(red_grp) for red_grp in fit_grp])
+            if np.allclose(rlens, np.mean(rlens)) and len(rlens) < grp_size_threshold:
+                vectors = comps.pop(fit_grp)
+                for rednum in range(int(rlens[0])):
+                    comps[tuple((red_grp[rednum],) for red_grp in fit_grp)] = vectors
+    by_nbl, maxvecs = {}, {}
+    for fit_grp, vectors in comps.items():
+        nbl = sum(len(red_grp) for red_grp in fit_grp)
+        by_nbl.setdefault(nbl, []).append(fit_grp)
+        maxvecs[nbl] = max(maxvecs.get(nbl, 0), vectors.shape[1])
+    return {(nbl, maxvecs[nbl]): {k: comps[k] for k in grps} for nbl, grps in by_nbl.items()}
+
+
+def tensorize_fg_model_comps_dict(
+    fg_model_comps_dict,
+    ants_map,
+    nfreqs,
+    use_redundancy=False,
+    dtype=np.float32,
+    notebook_progressbar=False,
+    verbose=False,
+    grp_size_threshold=5,
+):
+    """Modeling-component dictionary -> (ragged ``FitProblem`` without data, ``corr_inds``).
+
+    Counterpart of calibration.py:104-190.  ``corr_inds[chunk][group][baseline] = (i, j)`` is built exactly like the
+    reference (:169-188); the components are NOT expanded into the zero-padded ``(nvecs, ngrps, nbls, nfreqs)``
+    tensor (:167): each group keeps its own vector count and arrays that are the same object in the dictionary
+    (the operator cache of modeling.py:291-301) are stored once.
+    """
+    echo(f"{datetime.datetime.now()} Computing foreground components matrices...\n", verbose=verbose)
+    chunked = chunk_fg_comp_dict_by_nbls(fg_model_comps_dict, use_redundancy=use_redundancy, grp_size_threshold=grp_size_threshold)
+    basis, basis_id = [], {}
+    grp_basis, grp_bl_start = [], [0]
+    bl_ant0, bl_ant1, bl_rowblk = [], [], []
+    corr_inds, chunk_of_grp, pos_in_chunk, chunk_shapes = [], [], [], []
+    for cnum, (nbls, nvecs) in enumerate(chunked):
+        corr_inds_chunk = []
+        for grpnum, (modeling_grp, vectors) in enumerate(chunked[(nbls, nvecs)].items()):
+            if vectors.shape[0] != len(modeling_grp) * nfreqs:
+                raise ValueError(
+                    f"modeling vectors of a fitting group with {len(modeling_grp)} redundant groups must have "
+                    f"{len(modeling_grp) * nfreqs} rows, got {vectors.shape[0]}"
+                )
+            if id(vectors) not in basis_id:
+                basis_id[id(vectors)] = len(basis)
+                basis.append(np.ascontiguousarray(vectors, dtype=np.float64))
+            grp_basis.append(basis_id[id(vectors)])
+            corr_inds_grp = []
+            for rgrpnum, red_grp in enumerate(modeling_grp):
+                for ap in red_grp:
+                    i, j = ants_map[ap[0]], ants_map[ap[1]]
+                    corr_inds_grp.append((i, j))
+                    bl_ant0.append(i)
+                    bl_ant1.append(j)
+                    bl_rowblk.append(rgrpnum)
+            grp_bl_start.append(grp_bl_start[-1] + len(corr_inds_grp))
+            corr_inds_chunk.append(corr_inds_grp)
+            chunk_of_grp.append(cnum)
+            pos_in_chunk.append(grpnum)
+        corr_inds.append(corr_inds_chunk)
+        chunk_shapes.append((nvecs, len(corr_inds_chunk), nbls))
+    nbl_total = len(bl_ant0)
+    fg_model_comps = FitProblem(
+        nants=len(ants_map),
+        nfreqs=int(nfreqs),
+        basis=basis,
+        grp_basis=np.asarray(grp_basis, dtype=np.int32),
+        grp_bl_start=np.asarray(grp_bl_start, dtype=np.int32),
+        bl_ant0=np.asarray(bl_ant0, dtype=np.int32),
+        bl_ant1=np.asarray(bl_ant1, dtype=np.int32),
+        bl_rowblk=np.asarray(bl_rowblk, dtype=np.int32),
+        data_r=None,
+        data_i=None,
+        wgts=None,
+        chunk_of_grp=np.asarray(chunk_of_grp, dtype=np.int32),
+        pos_in_chunk=np.asarray(pos_in_chunk, dtype=np.int32),
+        chunk_shapes=chunk_shapes,
+    )
+    assert nbl_total == fg_model_comps.nbls
+    return fg_model_comps, corr_inds
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# data / gains <-> arrays: calibration.py:193-399
+# ------------------------------------------------------------------------------------------------------------------
+def _time_ind(times, inds, time):
+    return inds[np.where(np.isclose(np.asarray(times)[inds], time, rtol=0.0, atol=1e-7))[0][0]]
+
+
+def tensorize_data(
+    uvdata,
+    corr_inds,
+    ants_map,
+    polarization,
+    time,
+    data_scale_factor=1.0,
+    weights=None,
+    nsamples_in_weights=False,
+    dtype=np.float32,
+):
+    """UVData -> per-chunk ``(ngrps, nbls, nfreqs)`` arrays ``data_r, data_i, wgts`` -- calibration.py:193-310.
+
+    Data of a pair that only exists in reversed order are conjugated (:263-278); weights are ``~flags``
+    (``* nsamples`` / ``* UVFlag.weights``) divided by their sum over ALL baselines and channels (:282-303).
+    """
+    ants_map_inv = {ants_map[i]: i for i in ants_map}
+    data_r, data_i, wgts = [], [], []
+    wgtsum = 0.0
+    for chunk in corr_inds:
+        ngrps, nbls = len(chunk), len(chunk[0])
+        dr = np.zeros((ngrps, nbls, uvdata.Nfreqs), dtype=dtype)
+        di = np.zeros_like(dr)
+        w = np.zeros_like(dr)
+        for gnum, fitgrp in enumerate(chunk):
+            for bnum, (i, j) in enumerate(fitgrp):
+                ap = ants_map_inv[i], ants_map_inv[j]
+                dinds1, dinds2, pol_ind = uvdata._key2inds(ap + (polarization,))
+                if len(dinds1) > 0:
+                    dinds, conjugate, pind = dinds1, False, pol_ind[0]
+                else:
+                    dinds, conjugate, pind = dinds2, True, pol_ind[1]
+                pind = int(np.atleast_1d(pind)[0])
+                dind = _time_ind(uvdata.time_array, dinds, time)
+                data = uvdata.data_array[dind, 0, :, pind] / data_scale_factor
+                iflags = ~uvdata.flag_array[dind, 0, :, pind]
+                nsamples = uvdata.nsample_array[dind, 0, :, pind]
+                if conjugate:
+                    data = np.conj(data)
+                dr[gnum, bnum] = data.real.astype(dtype)
+                di[gnum, bnum] = data.imag.astype(dtype)
+                if weights is None:
+                    wrow = iflags.astype(dtype)
+                else:
+                    winds = weights.antpair2ind(*ap) if ap in weights.get_antpairs() else weights.antpair2ind(*ap[::-1])
+                    wind = _time_ind(weights.time_array, winds, time)
+                    polnum = np.where(weights.polarization_array == polstr2num(polarization, x_orientation=weights.x_orientation))[0][0]
+                    wrow = weights.weights_array[wind, 0, :, polnum].astype(dtype) * iflags
+                if nsamples_in_weights:
+                    wrow = wrow * nsamples
+                w[gnum, bnum] = wrow
+                wgtsum += np.sum(w[gnum, bnum])
+        data_r.append(dr)
+        data_i.append(di)
+        wgts.append(w)
+    wgts = [(w / wgtsum).astype(dtype) for w in wgts]
+    return data_r, data_i, wgts
+
+
+def tensorize_gains(uvcal, polarization, time, dtype=np.float32):
+    """UVCal -> ``(Nants, Nfreqs)`` real and imaginary gain arrays -- calibration.py:369-399."""
+    polnum = np.where(np.asarray(uvcal.jones_array) == polstr2num(polarization, x_orientation=uvcal.x_orientation))[0][0]
+    gindt = np.where(np.isclose(uvcal.time_array, time, atol=1e-7, rtol=0.0))[0][0]
+    g = uvcal.gain_array[:, 0, :, gindt, polnum]
+    return np.ascontiguousarray(g.real, dtype=dtype), np.ascontiguousarray(g.imag, dtype=dtype)
+
+
+def renormalize(uvdata_reference_model, uvdata_deconv, gains, polarization, time, additional_flags=None):
+    """Remove the arbitrary amplitude of the deconvolved model and gains -- calibration.py:313-366 (the phase factor is
+    computed by the reference but deliberately not applied, :359).  Modifies ``uvdata_deconv`` and ``gains``."""
+    polnum_data = np.where(uvdata_deconv.polarization_array == polstr2num(polarization, x_orientation=uvdata_deconv.x_orientation))[0][0]
+    bltsel = np.isclose(uvdata_deconv.time_array, time, atol=1e-7, rtol=0.0)
+    selection = ~uvdata_deconv.flag_array[bltsel, :, :, polnum_data] & ~uvdata_reference_model.flag_array[bltsel, :, :, polnum_data]
+    if additional_flags is not None:
+        selection = selection & ~additional_flags[bltsel, :, :, polnum_data]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        data_ratio = (
+            uvdata_reference_model.data_array[bltsel, :, :, polnum_data][selection]
+            / uvdata_deconv.data_array[bltsel, :, :, polnum_data][selection]
+        )
+    data_ratio[~np.isfinite(data_ratio)] = np.nan
+    scale_factor = np.sqrt(np.nanmean(np.abs(data_ratio) ** 2.0))
+    uvdata_deconv.data_array[bltsel, :, :, polnum_data] *= scale_factor
+    polnum_gains = np.where(np.asarray(gains.jones_array) == polstr2num(polarization, x_orientation=uvdata_deconv.x_orientation))[0][0]
+    gindt = np.where(np.isclose(gains.time_array, time, atol=1e-7, rtol=0.0))[0][0]
+    gains.gain_array[:, :, :, gindt, polnum_gains] *= (scale_factor) ** -0.5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the solver behind a set of components
+# ------------------------------------------------------------------------------------------------------------------
+def _as_problem(fg_comps, corr_inds, nants):
+    """Accept the ragged FitProblem or the reference's list of zero-padded chunk tensors."""
+    if isinstance(fg_comps, FitProblem):
+        return fg_comps
+    if corr_inds is None:  # antenna indices are irrelevant to the caller (coefficient initialisation)
+        corr_inds = [[[(0, 0)] * np.asarray(c).shape[2] for _ in range(np.asarray(c).shape[1])] for c in fg_comps]
+        nants = 1
+    dummy = [np.zeros(np.asarray(c).shape[1:]) for c in fg_comps]
+    prob = problem_from_chunks(nants, fg_comps, corr_inds, dummy, dummy, dummy)
+    prob.data_r = prob.data_i = prob.wgts = None
+    return prob
+
+
+def _flatten(chunks, prob):
+    """Per-chunk ``(ngrps, nbls, nfreqs)`` arrays -> ``(nbls_total, nfreqs)`` in the ragged baseline order."""
+    return np.concatenate([np.asarray(c).reshape(-1, prob.nfreqs) for c in chunks])
+
+
+def get_solver(fg_model_comps, dtype=np.float32, layout=None, device=None):
+    """The HipFitSolver that holds these components on the GPU (created once per component set and dtype)."""
+    dtype = np.dtype(dtype)
+    cache = fg_model_comps.__dict__.setdefault("_solvers", {})
+    layout = layout or os.environ.get("CALAMITY_AMD_LAYOUT", "shared")
+    device = int(os.environ.get("CALAMITY_AMD_DEVICE", "0")) if device is None else device
+    key = (dtype.str, layout, device)
+    if key not in cache:
+        shell = copy.copy(fg_model_comps)
+        shell.data_r = shell.data_i = shell.wgts = None
+        solver = HipFitSolver(dtype=dtype, device=device)
+        solver.set_problem(shell, layout=layout)
+        cache[key] = solver
+    return cache[key]
+
+
+def _gram_factors(prob):
+    """Per fitting-group Gram matrices ``sum_bl A_bl^T A_bl`` that are not the identity (DPSS columns are orthonormal,
+    so for per-baseline DPSS this is empty).  Keyed by (basis, row blocks)."""
+    cache = prob.__dict__.setdefault("_gram", None)
+    if cache is not None:
+        return cache
+    F = prob.nfreqs
+    keys, out = {}, {}
+    for g in range(prob.ngrps):
+        rbs = tuple(prob.bl_rowblk[prob.grp_bl_start[g] : prob.grp_bl_start[g + 1]].tolist())
+        keys.setdefault((int(prob.grp_basis[g]), rbs), []).append(g)
+    for (u, rbs), grps in keys.items():
+        blk = prob.basis[u]
+        gram = sum(blk[rb * F : (rb + 1) * F].T @ blk[rb * F : (rb + 1) * F] for rb in rbs)
+        if not np.allclose(gram, np.eye(gram.shape[0]), atol=1e-9):
+            out[(u, rbs)] = (gram, np.asarray(grps))
+    prob.__dict__["_gram"] = out
+    return out
+
+
+def _init_coeffs(solver, prob, src_r, src_i):
+    """tensorize_fg_coeffs for both components at once: ``A^T (src * [w != 0])`` on the GPU, then the (rarely needed)
+    small Gram solves on the host.  Returns flat (c_r, c_i)."""
+    solver.init_coeffs(src_r, src_i)
+    _, _, c_r, c_i = solver.get_params()
+    grams = _gram_factors(prob)
+    if grams:
+        c_r = c_r.astype(np.float64)
+        c_i = c_i.astype(np.float64)
+        coff = prob.grp_coff
+        for (u, rbs), (gram, grps) in grams.items():
+            idx = coff[grps][None, :] + np.arange(gram.shape[0])[:, None]
+            c_r[idx] = np.linalg.solve(gram, c_r[idx])
+            c_i[idx] = np.linalg.solve(gram, c_i[idx])
+        solver.set_params(c_r=c_r, c_i=c_i)
+    return c_r, c_i
+
+
+def tensorize_fg_coeffs(data, wgts, fg_model_comps, notebook_progressbar=False, verbose=False, dtype=None):
+    """Initial foreground coefficients of ONE real component by per-group linear least squares on ``data`` with
+    zero-weight samples zeroed -- calibration.py:828-913.  Returns the reference's list of ``(nvecs, ngrps, 1, 1)``
+    zero-padded arrays."""
+    echo(f"{datetime.datetime.now()} Computing initial foreground coefficient guesses using linear-leastsq...\n", verbose=verbose)
+    dtype = np.dtype(dtype or np.asarray(data[0]).dtype)
+    prob = _as_problem(fg_model_comps, None, None)
+    solver = get_solver(prob, dtype)
+    src = _flatten(data, prob)
+    zeros = np.zeros_like(src)
+    solver.set_data(zeros, zeros, _flatten(wgts, prob))
+    c_r, _ = _init_coeffs(solver, prob, src, zeros)
+    echo(f"{datetime.datetime.now()} Finished initial foreground coefficient guesses...\n", verbose=verbose)
+    return coeffs_to_chunks(prob, c_r, dtype)
+
+
+def yield_fg_model_array(nants, nfreqs, fg_model_comps, fg_coeffs, corr_inds, dtype=np.float32):
+    """Foreground model ``sum_k c_k A_k`` of ONE real component as a ``(nants, nants, nfreqs)`` float64 cube --
+    calibration.py:402-444 (the A c product runs on the GPU)."""
+    prob = _as_problem(fg_model_comps, corr_inds, nants)
+    solver = get_solver(prob, dtype)
+    c = coeffs_from_chunks(prob, fg_coeffs)
+    solver.set_params(c_r=c, c_i=np.zeros_like(c))
+    m_r, _ = solver.model()
+    model = np.zeros((nants, nants, nfreqs))
+    model[prob.bl_ant0, prob.bl_ant1] = m_r
+    return model
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the fit loop: calibration.py:447-738
+# ------------------------------------------------------------------------------------------------------------------
+def fit_gains_and_foregrounds(
+    g_r,
+    g_i,
+    fg_r,
+    fg_i,
+    data_r,
+    data_i,
+    wgts,
+    fg_comps,
+    corr_inds,
+    use_min=False,
+    tol=1e-14,
+    maxsteps=10000,
+    optimizer="Adamax",
+    freeze_model=False,
+    verbose=False,
+    notebook_progressbar=False,
+    dtype=np.float32,
+    graph_mode=False,
+    n_profile_steps=0,
+    profile_log_dir="./logdir",
+    sky_model_r=None,
+    sky_model_i=None,
+    model_regularization=None,
+    graph_args_dict=None,
+    **opt_kwargs,
+):
+    """Run the optimization loop that fits gains and foreground coefficients -- calibration.py:447-738.
+
+    Same arguments and returns as the reference (arrays are NumPy).  Loop semantics kept: ``n_profile_steps``
+    profiled steps and one more step are real, unrecorded updates (:681-693); recorded loss k is evaluated before
+    update k (:700-701); ``use_min`` returns the parameters held right after the update of the lowest-loss step
+    (:702-710); the loop ends when ``step >= 1 and |l_k - l_{k-1}| < tol`` (:712-717); ``freeze_model`` optimises
+    gains only and returns ``fg_r, fg_i`` untouched (:598-603, :730-732).  The whole loop runs on the GPU; losses come
+    back once at the end instead of once per step (:701).
+    """
+    echo(f"Using {str(dtype)} precision.")
+    echo(f"{datetime.datetime.now()} Provided the following opt_kwargs")
+    for k in opt_kwargs:
+        echo(f"{k}: {opt_kwargs[k]}")
+    OPTIMIZERS[optimizer]  # unknown optimizer -> KeyError, like calibration.py:571
+    dtype = np.dtype(dtype)
+    g_r = np.asarray(g_r)
+    nants = g_r.shape[0]
+    prob = _as_problem(fg_comps, corr_inds, nants)
+    solver = get_solver(prob, dtype)
+    w_flat = _flatten(wgts, prob)
+    solver.set_data(_flatten(data_r, prob), _flatten(data_i, prob), w_flat)
+    solver.set_params(g_r, np.asarray(g_i), coeffs_from_chunks(prob, fg_r), coeffs_from_chunks(prob, fg_i))
+    echo(f"{datetime.datetime.now()} Performing gradient descent on {np.prod(g_r.shape)} complex gain parameters...", verbose=verbose)
+    if not freeze_model:
+        echo(f"Performing gradient descent on total of {prob.ncoeffs} complex foreground parameters", verbose=verbose)
+    if model_regularization == "sum":
+        # priors of calibration.py:619-625 (accumulated in float64 on the host)
+        w64 = w_flat.astype(np.float64)
+        solver.set_regularization("sum", float(np.sum(_flatten(sky_model_r, prob) * w64)), float(np.sum(_flatten(sky_model_i, prob) * w64)))
+    else:
+        solver.set_regularization(None)
+    solver.set_optimizer(optimizer, **opt_kwargs)
+    fit_history = {"loss": []}
+    if n_profile_steps > 0:
+        echo(f"{datetime.datetime.now()} Profiling with {n_profile_steps}. And writing output to {profile_log_dir}...")
+        solver.timing_enable(True)
+        solver.run(n_profile_steps, record=False, freeze_model=freeze_model)
+        os.makedirs(profile_log_dir, exist_ok=True)
+        with open(os.path.join(profile_log_dir, f"calamity_amd_profile_{datetime.datetime.now():%Y%m%d_%H%M%S_%f}.json"), "w") as f:
+            json.dump(dict(n_profile_steps=n_profile_steps, fused_basis_kernel=solver.timing_get()), f)
+        solver.timing_enable(False)
+    echo(f"{datetime.datetime.now()} Building Computational Graph...\n", verbose=verbose)
+    solver.run(1, record=False, freeze_model=freeze_model)  # the unrecorded step of calibration.py:693
+    echo(f"{datetime.datetime.now()} Performing Gradient Descent...\n", verbose=verbose)
+    losses, stopped, _ = solver.run(maxsteps, record=True, tol=tol, use_min=use_min, freeze_model=freeze_model)
+    fit_history["loss"] = [dtype.type(l) for l in losses]
+    if stopped:
+        echo(f"Tolerance thresshold met with delta of {np.abs(losses[-1] - losses[-2]):.2e}. Terminating...\n ", verbose=verbose)
+    g_r_opt, g_i_opt, c_r, c_i = solver.get_params(which=1 if (use_min and len(losses) > 0) else 0)
+    if freeze_model:
+        fg_r_opt, fg_i_opt = fg_r, fg_i
+    else:
+        fg_r_opt = coeffs_to_chunks(prob, c_r, dtype)
+        fg_i_opt = coeffs_to_chunks(prob, c_i, dtype)
+    min_loss = np.min(losses) if (use_min and len(losses)) else (losses[-1] if len(losses) else np.nan)
+    echo(f"{datetime.datetime.now()} Finished Gradient Descent. MSE of {min_loss:.2e}...\n", verbose=verbose)
+    return g_r_opt, g_i_opt, fg_r_opt, fg_i_opt, fit_history
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# write-back: calibration.py:741-825, :1334-1350
+# ------------------------------------------------------------------------------------------------------------------
+def insert_model_into_uvdata_tensor(uvdata, time, polarization, ants_map, red_grps, model_r, model_i, scale_factor=1.0):
+    """Insert ``(Nants, Nants, Nfreqs)`` model cubes back into a UVData object, conjugating pairs stored in reversed
+    order and multiplying by ``scale_factor`` -- calibration.py:741-795.  Modifies ``uvdata``."""
+    antpairs_data = set(uvdata.get_antpairs())
+    polnum = np.where(uvdata.polarization_array == polstr2num(polarization, x_orientation=uvdata.x_orientation))[0][0]
+    for red_grp in red_grps:
+        for ap in red_grp:
+            i, j = ants_map[ap[0]], ants_map[ap[1]]
+            if ap in antpairs_data:
+                dind = _time_ind(uvdata.time_array, uvdata.antpair2ind(ap), time)
+                model = model_r[i, j] + 1j * model_i[i, j]
+            else:
+                dind = _time_ind(uvdata.time_array, uvdata.antpair2ind(ap[::-1]), time)
+                model = model_r[i, j] - 1j * model_i[i, j]
+            uvdata.data_array[dind, 0, :, polnum] = model * scale_factor
+
+
+def insert_gains_into_uvcal(uvcal, time, polarization, gains_re, gains_im):
+    """Insert ``(Nants, Nfreqs)`` gain arrays back into a UVCal object -- calibration.py:798-825."""
+    polnum = np.where(np.asarray(uvcal.jones_array) == polstr2num(polarization, x_orientation=uvcal.x_orientation))[0][0]
+    gindt = np.where(np.isclose(uvcal.time_array, time, atol=1e-7, rtol=0.0))[0][0]
+    uvcal.gain_array[:, 0, :, gindt, polnum] = np.asarray(gains_re) + 1j * np.asarray(gains_im)
+
+
+def flag_poltime(data_object, time, polarization):
+    """Flag (and zero / set to unity) one polarization-time of a UVData or UVCal -- calibration.py:1334-1350."""
+    if is_uvdata(data_object):
+        bltsel = np.isclose(data_object.time_array, time, atol=1e-7, rtol=0.0)
+        polnum = np.where(data_object.polarization_array == polstr2num(polarization, x_orientation=data_object.x_orientation))[0][0]
+        data_object.flag_array[bltsel, :, :, polnum] = True
+        data_object.data_array[bltsel, :, :, polnum] = 0.0
+    elif is_uvcal(data_object):
+        polnum = np.where(np.asarray(data_object.jones_array) == polstr2num(polarization, x_orientation=data_object.x_orientation))[0][0]
+        gindt = np.where(np.isclose(data_object.time_array, time, atol=1e-7, rtol=0.0))[0][0]
+        data_object.gain_array[:, 0, :, gindt, polnum] = 1.0
+        data_object.flag_array[:, 0, :, gindt, polnum] = True
+    else:
+        raise ValueError("only supports data_object that is UVCal or UVData.")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# orchestration: calibration.py:963-1331, :1503-1584
+# ------------------------------------------------------------------------------------------------------------------
+def calibrate_and_model_tensor(
+    uvdata,
+    fg_model_comps_dict,
+    gains=None,
+    freeze_model=False,
+    optimizer="Adamax",
+    tol=1e-14,
+    maxsteps=10000,
+    include_autos=False,
+    verbose=False,
+    sky_model=None,
+    dtype=np.float32,
+    use_min=False,
+    use_redundancy=False,
+    notebook_progressbar=False,
+    correct_resid=False,
+    correct_model=True,
+    weights=None,
+    nsamples_in_weights=True,
+    graph_mode=False,
+    grp_size_threshold=5,
+    n_profile_steps=0,
+    profile_log_dir="./logdir",
+    model_regularization="sum",
+    init_guesses_from_previous_time_step=False,
+    skip_threshold=0.5,
+    use_model_snr_weights=False,
+    **opt_kwargs,
+):
+    """Simultaneous calibration and foreground fitting -- calibration.py:963-1331, same arguments, defaults and
+    returns ``(model, resid, gains, fit_history)``.  See SURVEY.md Appendix A for the behaviours kept (the input
+    ``uvdata`` is not modified; a supplied ``gains`` object IS modified in place and returned)."""
+    antpairs_data = uvdata.get_antpairs()
+    if not include_autos:
+        antpairs_data = set([ap for ap in antpairs_data if ap[0] != ap[1]])
+    uvdata = uvdata.select(inplace=False, bls=[ap for ap in antpairs_data])
+    resid = copy.deepcopy(uvdata)
+    model = copy.deepcopy(uvdata)
+    model.data_array[:] = 0.0
+    model.flag_array[:] = False
+    red_grps = []
+    for fit_grp in fg_model_comps_dict.keys():
+        for red_grp in fit_grp:
+            red_grps.append(red_grp)
+    if gains is None:
+        echo(f"{datetime.datetime.now()} Gains are None. Initializing gains starting with unity...\n", verbose=verbose)
+        gains = cal_utils.blank_uvcal_from_uvdata(uvdata)
+    if sky_model is None and model_regularization is not None:
+        echo(f"{datetime.datetime.now()} Sky model is None. Initializing from data...\n", verbose=verbose)
+        sky_model = cal_utils.apply_gains(uvdata, gains)
+    else:
+        # the reference dereferences sky_model here even when it is None (calibration.py:1137-1138)
+        sky_model = sky_model.select(inplace=False, bls=[ap for ap in antpairs_data])
+    fit_history = {}
+    ants_map = {ant: i for i, ant in enumerate(np.asarray(gains.ant_array).tolist())}
+    fg_model_comps, corr_inds = tensorize_fg_model_comps_dict(
+        fg_model_comps_dict=fg_model_comps_dict,
+        ants_map=ants_map,
+        dtype=dtype,
+        nfreqs=sky_model.Nfreqs,
+        verbose=verbose,
+        notebook_progressbar=notebook_progressbar,
+        use_redundancy=use_redundancy,
+        grp_size_threshold=grp_size_threshold,
+    )
+    echo(f"{datetime.datetime.now()}Finished Converting Foreground Modeling Components to Tensors...\n", verbose=verbose)
+    del fg_model_comps_dict
+    solver = get_solver(fg_model_comps, dtype)
+    prob = fg_model_comps
+    for polnum, pol in enumerate(uvdata.get_pols()):
+        echo(f"{datetime.datetime.now()} Working on pol {pol}, {polnum + 1} of {uvdata.Npols}...\n", verbose=verbose)
+        fit_history_p = {}
+        first_time = True
+        for time_index, time in enumerate(np.unique(uvdata.time_array)):
+            echo(f"{datetime.datetime.now()} Working on time {time_index + 1} of {uvdata.Ntimes}...\n", verbose=verbose)
+            bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
+            frac_unflagged = np.count_nonzero(~uvdata.flag_array[bltsel, 0, :, polnum]) / (uvdata.Nbls * uvdata.Nfreqs)
+            if frac_unflagged >= skip_threshold:
+                rmsdata = np.sqrt(np.mean(np.abs(uvdata.data_array[bltsel, 0, :, polnum][~uvdata.flag_array[bltsel, 0, :, polnum]]) ** 2.0))
+                echo(f"{datetime.datetime.now()} Tensorizing data...\n", verbose=verbose)
+                data_r, data_i, wgts = tensorize_data(
+                    uvdata, corr_inds=corr_inds, ants_map=ants_map, polarization=pol, time=time, data_scale_factor=rmsdata,
+                    weights=weights, nsamples_in_weights=nsamples_in_weights, dtype=dtype,
+                )
+                if sky_model is not None:
+                    echo(f"{datetime.datetime.now()} Tensorizing sky model...\n", verbose=verbose)
+                    sky_model_r, sky_model_i, _ = tensorize_data(
+                        sky_model, corr_inds=corr_inds, ants_map=ants_map, polarization=pol, time=time, data_scale_factor=rmsdata,
+                        weights=weights, dtype=dtype,
+                    )
+                else:
+                    sky_model_r, sky_model_i = None, None
+                if first_time or not init_guesses_from_previous_time_step:
+                    first_time = False
+                    echo(f"{datetime.datetime.now()} Tensorizing Gains...\n", verbose=verbose)
+                    g_r, g_i = tensorize_gains(gains, dtype=dtype, time=time, polarization=pol)
+                    echo(f"{datetime.datetime.now()} Tensorizing Foreground coeffs...\n", verbose=verbose)
+                    # tensorize_fg_coeffs x 2 (calibration.py:1219-1233): one device pass gives both components
+                    w_flat = _flatten(wgts, prob)
+                    zeros = np.zeros_like(w_flat)
+                    solver.set_data(zeros, zeros, w_flat)
+                    c_r, c_i = _init_coeffs(solver, prob, _flatten(sky_model_r, prob), _flatten(sky_model_i, prob))
+                    fg_r = coeffs_to_chunks(prob, c_r, dtype)
+                    fg_i = coeffs_to_chunks(prob, c_i, dtype)
+                    if use_model_snr_weights:
+                        m_r, m_i = solver.model()
+                        w_new = (np.square(m_r.astype(np.float64)) + np.square(m_i.astype(np.float64))) * w_flat
+                        w_new = w_new / np.sum(w_new)
+                        start = 0
+                        new_wgts = []
+                        for w in wgts:
+                            n = w.shape[0] * w.shape[1]
+                            new_wgts.append(w_new[start : start + n].reshape(w.shape).astype(dtype))
+                            start += n
+                        wgts = new_wgts
+                (g_r, g_i, fg_r, fg_i, fit_history_p[time_index]) = fit_gains_and_foregrounds(
+                    g_r=g_r, g_i=g_i, fg_r=fg_r, fg_i=fg_i, data_r=data_r, data_i=data_i, wgts=wgts, fg_comps=fg_model_comps,
+                    corr_inds=corr_inds, optimizer=optimizer, use_min=use_min, freeze_model=freeze_model,
+                    notebook_progressbar=notebook_progressbar, verbose=verbose, tol=tol, dtype=dtype, maxsteps=maxsteps,
+                    graph_mode=graph_mode, n_profile_steps=n_profile_steps, profile_log_dir=profile_log_dir,
+                    sky_model_r=sky_model_r, sky_model_i=sky_model_i, model_regularization=model_regularization, **opt_kwargs,
+                )
+                # yield_fg_model_array x 2 + insert_model_into_uvdata_tensor (calibration.py:1271-1292) without the
+                # nants x nants cubes: one A c pass for both components, rows written straight back
+                solver.set_params(c_r=coeffs_from_chunks(prob, fg_r), c_i=coeffs_from_chunks(prob, fg_i))
+                m_r, m_i = solver.model()
+                _insert_model_rows(model, time, pol, ants_map, prob, m_r, m_i, scale_factor=rmsdata)
+                insert_gains_into_uvcal(uvcal=gains, time=time, polarization=pol, gains_re=g_r, gains_im=g_i)
+            else:
+                echo(f"{datetime.datetime.now()}: Only {frac_unflagged * 100}-percent of data unflagged. Skipping...\n", verbose=verbose)
+                flag_poltime(resid, time=time, polarization=pol)
+                flag_poltime(gains, time=time, polarization=pol)
+                flag_poltime(model, time=time, polarization=pol)
+                fit_history[polnum] = "skipped!"
+            if not freeze_model and model_regularization == "post_hoc" and np.any(~model.flag_array[bltsel]):
+                renormalize(
+                    uvdata_reference_model=sky_model, uvdata_deconv=model, gains=gains, polarization=pol, time=time,
+                    additional_flags=uvdata.flag_array,
+                )
+        fit_history[polnum] = fit_history_p
+    model_with_gains = cal_utils.apply_gains(model, gains, inverse=True)
+    if not correct_model:
+        model = model_with_gains
+    resid.data_array -= model_with_gains.data_array
+    resid.data_array[model_with_gains.flag_array] = 0.0
+    resid.data_array[uvdata.flag_array] = 0.0
+    if correct_resid:
+        resid = cal_utils.apply_gains(resid, gains)
+    return model, resid, gains, fit_history
+
+
+def _insert_model_rows(uvdata, time, polarization, ants_map, prob, m_r, m_i, scale_factor):
+    """insert_model_into_uvdata_tensor (calibration.py:741-795) from per-baseline rows instead of cubes."""
+    ants_inv = {v: k for k, v in ants_map.items()}
+    antpairs_data = set(uvdata.get_antpairs())
+    polnum = np.where(uvdata.polarization_array == polstr2num(polarization, x_orientation=uvdata.x_orientation))[0][0]
+    for b in range(prob.nbls):
+        ap = (ants_inv[int(prob.bl_ant0[b])], ants_inv[int(prob.bl_ant1[b])])
+        if ap in antpairs_data:
+            dind = _time_ind(uvdata.time_array, uvdata.antpair2ind(ap), time)
+            row = m_r[b] + 1j * m_i[b]
+        else:
+            dind = _time_ind(uvdata.time_array, uvdata.antpair2ind(ap[::-1]), time)
+            row = m_r[b] - 1j * m_i[b]
+        uvdata.data_array[dind, 0, :, polnum] = row * scale_factor
+
+
+def calibrate_and_model_dpss(
+    uvdata,
+    horizon=1.0,
+    min_dly=0.0,
+    offset=0.0,
+    include_autos=False,
+    verbose=False,
+    red_tol=1.0,
+    notebook_progressbar=False,
+    fg_model_comps_dict=None,
+    **fitting_kwargs,
+):
+    """Simultaneously solve for gains and model foregrounds with per-baseline DPSS vectors -- the kept entry point,
+    calibration.py:1503-1584.  ``fg_model_comps_dict`` is accepted and ignored, as in the reference (:1564)."""
+    dpss_model_comps_dict = modeling.yield_pbl_dpss_model_comps(
+        uvdata, horizon=horizon, min_dly=min_dly, offset=offset, include_autos=include_autos, red_tol=red_tol,
+        notebook_progressbar=notebook_progressbar, verbose=verbose,
+    )
+    (model, resid, gains, fitted_info) = calibrate_and_model_tensor(
+        uvdata=uvdata, fg_model_comps_dict=dpss_model_comps_dict, include_autos=include_autos, verbose=verbose,
+        notebook_progressbar=notebook_progressbar, **fitting_kwargs,
+    )
+    return model, resid, gains, fitted_info

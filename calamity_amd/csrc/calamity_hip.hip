@@ -68,7 +68,10 @@ struct DevBuf {  // owning device allocation
     }
     bytes = n;
     if (zero) {
+      // hipMemset runs on the null stream and may still be in flight when it returns; the solver works on a
+      // non-blocking stream, so drain it here or the zero fill can land on top of a later upload
       e = hipMemset(p, 0, n);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
       if (e != hipSuccess) return fail(CAL_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
     }
     return CAL_OK;
@@ -113,7 +116,7 @@ template <typename T>
 struct SolverT final : cal_solver {
   using T2 = vec2_t<T>;
   hipStream_t stream = nullptr;
-  bool has_problem = false, has_data = false, has_params = false, has_opt = false;
+  bool has_problem = false, has_data = false, has_gains = false, has_coef = false, has_opt = false;
   // problem
   int nants = 0, nfreqs = 0, fpad = 0, ngrps = 0, nbls = 0, ncoef = 0, nitems = 0, layout = 0;
   bool gc_direct = true;
@@ -185,7 +188,7 @@ struct SolverT final : cal_solver {
   // ------------------------------------------------------------------------------------------------------------
   int set_problem(const cal_problem_desc* d) override {
     HIP_TRY(hipSetDevice(device));
-    has_problem = has_data = has_params = false;
+    has_problem = has_data = has_gains = has_coef = false;
     if (!d || d->nants <= 0 || d->nfreqs <= 0 || d->ngrps <= 0 || d->nbls <= 0 || d->nbasis <= 0)
       return fail(CAL_ERR_INVALID, "set_problem: non-positive dimension");
     if (!d->basis_offset || !d->basis_nvec || !d->basis_nrowblk || !d->basis_data || !d->grp_basis || !d->grp_bl_start ||
@@ -504,7 +507,8 @@ struct SolverT final : cal_solver {
     if (g_i) CAL_TRY(upload_rows(g_i, gains.as<T>(), nants, 2, 1));
     if (c_r) HIP_TRY(hipMemcpy(coef.as<T>(), c_r, (size_t)ncoef * sizeof(T), hipMemcpyHostToDevice));
     if (c_i) HIP_TRY(hipMemcpy(coef.as<T>() + ncoef, c_i, (size_t)ncoef * sizeof(T), hipMemcpyHostToDevice));
-    has_params = true;
+    if (g_r && g_i) has_gains = true;
+    if (c_r && c_i) has_coef = true;
     return CAL_OK;
   }
 
@@ -717,7 +721,7 @@ struct SolverT final : cal_solver {
   int ready() {
     if (!has_problem) return fail(CAL_ERR_STATE, "no problem set (cal_solver_set_problem)");
     if (!has_data) return fail(CAL_ERR_STATE, "no data set (cal_solver_set_data)");
-    if (!has_params) return fail(CAL_ERR_STATE, "no parameters set (cal_solver_set_params)");
+    if (!has_gains || !has_coef) return fail(CAL_ERR_STATE, "gains and coefficients must both be set (cal_solver_set_params)");
     return CAL_OK;
   }
 
@@ -789,7 +793,7 @@ struct SolverT final : cal_solver {
 
   int model(void* mr, void* mi) override {
     HIP_TRY(hipSetDevice(device));
-    if (!has_problem || !has_params) return fail(CAL_ERR_STATE, "model: problem and parameters must be set");
+    if (!has_problem || !has_coef) return fail(CAL_ERR_STATE, "model: problem and coefficients must be set");
     if (!mr || !mi) return fail(CAL_ERR_INVALID, "model: null output");
     const size_t rowbytes = (size_t)nbls * fpad * sizeof(T);
     if (model_buf.bytes < 2 * rowbytes) CAL_TRY(model_buf.alloc(2 * rowbytes));
@@ -829,6 +833,7 @@ struct SolverT final : cal_solver {
     // A^T b becomes the coefficient vector (orthonormal-column bases; the host applies the Gram solve otherwise)
     HIP_TRY(hipMemcpyAsync(coef.p, grad_c0(), 2 * (size_t)ncoef * sizeof(T), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    has_coef = true;
     return CAL_OK;
   }
 

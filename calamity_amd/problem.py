@@ -60,7 +60,7 @@ class FitProblem:
         assert self.grp_bl_start[0] == 0 and self.grp_bl_start[-1] == self.nbls
         assert np.all(np.diff(self.grp_bl_start) >= 1)
         for arr in (self.data_r, self.data_i, self.wgts):
-            assert arr.shape == (self.nbls, self.nfreqs)
+            assert arr is None or arr.shape == (self.nbls, self.nfreqs)
         assert self.bl_ant0.min() >= 0 and self.bl_ant0.max() < self.nants
         assert self.bl_ant1.min() >= 0 and self.bl_ant1.max() < self.nants
         for g in range(self.ngrps):
@@ -203,7 +203,8 @@ def chunks_from_problem(prob, dtype=np.float64):
         out["fg_comps"].append(comps)
         out["corr_inds"].append(ci)
         for name, arr in (("data_r", prob.data_r), ("data_i", prob.data_i), ("wgts", prob.wgts)):
-            out[name].append(arr[sel].reshape(len(grps), nb, F).astype(dtype))
+            if arr is not None:
+                out[name].append(arr[sel].reshape(len(grps), nb, F).astype(dtype))
         if prob.sky_r is not None:
             out["sky_model_r"].append(prob.sky_r[sel].reshape(len(grps), nb, F).astype(dtype))
             out["sky_model_i"].append(prob.sky_i[sel].reshape(len(grps), nb, F).astype(dtype))
