@@ -87,6 +87,22 @@ def cpu_baseline(prob, start, dtype, optimizer, sample_bls, reg):
     )
 
 
+def torch_sum_int(dist, vals):
+    import torch
+
+    t = torch.tensor(vals, dtype=torch.int64)
+    dist.all_reduce(t)
+    return [int(v) for v in t]
+
+
+def torch_sum_float(dist, vals):
+    import torch
+
+    t = torch.tensor(np.asarray(vals, dtype=np.float64))
+    dist.all_reduce(t)
+    return t.numpy()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -94,8 +110,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    from calamity_amd import synthetic
+    from calamity_amd import _lib, synthetic
     from calamity_amd.solver import HipFitSolver, comm_unique_id
+
+    # load the HIP library (and through it /opt/rocm's HIP runtime + RCCL, the ones it was built against) BEFORE torch:
+    # torch is only used for the gloo rendezvous/barrier and bundles its own, older ROCm libraries
+    _lib.load()
 
     dtype = {"f32": np.float32, "f64": np.float64, None: np.float64 if args.config == "hera37" else np.float32}[args.dtype]
     dist = None
@@ -106,9 +126,10 @@ def main():
 
     t_setup = time.perf_counter()
     ntimes = world
-    prob, truth, start = synthetic.make_config(args.config, max_bls=args.max_bls, with_sky=args.reg == "sum")
     solvers = []
     if world == 1:
+        prob, truth, start = synthetic.make_config(args.config, max_bls=args.max_bls, with_sky=args.reg == "sum")
+        full_nbls, full_ncoeffs, full_nants = prob.nbls, prob.ncoeffs, prob.nants
         s = HipFitSolver(dtype=dtype, device=0)
         s.set_problem(prob, layout=args.layout)
         s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
@@ -116,24 +137,34 @@ def main():
     else:
         from calamity_amd import distributed as D
 
-        shard = D.shard_problem(prob, start, rank, world)
-        ids = [None] * ntimes
-        if rank == 0:
-            ids = [comm_unique_id() for _ in range(ntimes)]
-        dist.broadcast_object_list(ids, src=0)
+        # N time slices; this rank owns the same 1/N of the baselines (balanced by basis bytes) of every slice and fits
+        # them in ONE solver (slice t keeps its own gains: antenna index + t * nants) -> one all-reduce per step
+        cache = {}
+        sel = lambda nvec, gb: D.partition_groups(nvec, gb, np.ones(len(nvec)), world)[rank]  # noqa: E731
+        cfg_seed = list(synthetic.CONFIGS).index(args.config)
+        parts = []
         for t in range(ntimes):
-            s = HipFitSolver(dtype=dtype, device=local_rank)
-            sp, ss = shard
-            if t > 0:
-                # further time slices: same array and bases, independent noise realisation
-                sp, ss = D.reseed_shard(shard, seed=1000 + t)
-            s.set_problem(sp, layout=args.layout)
-            s.set_params(ss["g_r"], ss["g_i"], ss["c_r"], ss["c_i"])
-            s.comm_init(ids[t], rank, world)
-            solvers.append(s)
+            p_t, _, s_t = synthetic.make_config(args.config, seed=cfg_seed + 100 * t, data_seed=100000 * (t + 1) + rank, bl_sel=sel,
+                                                operator_cache=cache, with_sky=args.reg == "sum", max_bls=args.max_bls)
+            parts.append((p_t, s_t))
+        full_nants = parts[0][0].nants
+        prob, start = D.batch_time_slices(parts)
+        tot = torch_sum_int(dist, [prob.nbls // ntimes, prob.ncoeffs // ntimes])
+        full_nbls, full_ncoeffs = tot
+        uid = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        # CALAMITY_BENCH_DEVICE: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+        s = HipFitSolver(dtype=dtype, device=int(os.environ.get("CALAMITY_BENCH_DEVICE", local_rank)))
+        s.set_problem(prob, layout=args.layout)
+        s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        s.comm_init(uid[0], rank, world)
+        solvers.append(s)
     for s in solvers:
         if args.reg == "sum":
-            s.set_regularization("sum", float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts)))
+            pri = np.asarray([float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts))])
+            if dist is not None:
+                pri = torch_sum_float(dist, pri)
+            s.set_regularization("sum", float(pri[0]), float(pri[1]))
         s.set_optimizer(args.optimizer, learning_rate=1e-2)
     t_setup = time.perf_counter() - t_setup
 
@@ -193,11 +224,11 @@ def main():
             "dtype": "f32" if dtype == np.float32 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: {prob.nants} antennas, {prob.nbls} baselines x {prob.nfreqs} channels, per-baseline DPSS "
-                            f"(sum nvec = {prob.ncoeffs}), {ntimes} time slice(s), optimizer {args.optimizer} lr 1e-2, "
+                "workload": f"{args.config}: {full_nants} antennas, {full_nbls} baselines x {prob.nfreqs} channels, per-baseline DPSS "
+                            f"(sum nvec = {full_ncoeffs}) per time slice, {ntimes} time slice(s), optimizer {args.optimizer} lr 1e-2, "
                             f"model_regularization {args.reg}",
                 "layout": args.layout,
-                "parallelism": f"baselines sharded over {world} GPU(s), gain-gradient all-reduce per slice-step" if world > 1 else "single GPU",
+                "parallelism": f"every slice's baselines sharded over {world} GPUs (one process each), one RCCL all-reduce of the gain gradients + loss scalars per step" if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",

@@ -651,8 +651,9 @@ struct SolverT final : cal_solver {
       hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                          ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, 0, fpad, part.as<double>(), nitems, scal.as<double>(), st);
     }
-    if (nccl && nranks > 1) {
+    if (nccl) {
       // the one exchange step of the sharded fit: sum gain-gradient parts and loss scalars over ranks
+      // (issued for a 1-rank communicator too, so the path can be exercised on a single GPU)
       NCCL_TRY(ncclGroupStart());
       if (grads)
         NCCL_TRY(ncclAllReduce(r0, r0, (R ? 3 : 1) * gn * 2, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, nccl, stream));

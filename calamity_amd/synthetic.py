@@ -46,8 +46,15 @@ def make_problem(
     with_sky=False,
     max_bls=None,
     operator_cache=None,
+    bl_sel=None,
+    data_seed=None,
 ):
-    """Build one (pol, time) fit.  Returns (FitProblem, truth dict, start dict)."""
+    """Build one (pol, time) fit.  Returns (FitProblem, truth dict, start dict).
+
+    ``bl_sel`` (indices into the ``i < j`` baseline list, or a callable ``(nvec_per_baseline) -> indices``) keeps only
+    some baselines -- the shard of one rank; gains always come from ``seed`` so every shard of a time slice sees the
+    same antennas, while coefficients / noise / flags come from ``data_seed`` (default ``seed``).  Weights stay
+    normalised by the sum over ALL baselines of the slice (calibration.py:300-303), not over the shard."""
     rng = np.random.default_rng(seed)
     if df is None:
         df = 100e6 / nfreqs
@@ -60,6 +67,10 @@ def make_problem(
         i_idx, j_idx = i_idx[sel], j_idx[sel]
     lengths = np.linalg.norm(antpos[i_idx] - antpos[j_idx], axis=1)
     dlys = np.asarray([modeling.dly_ns(L) for L in lengths])
+    nbls_slice = len(i_idx)
+    g_true = 1.0 + gain_sigma * (rng.standard_normal((nants, nfreqs)) + 1j * rng.standard_normal((nants, nfreqs)))
+    if data_seed is not None:
+        rng = np.random.default_rng(data_seed)
     if operator_cache is None:
         operator_cache = {}
     uniq, inv = np.unique(dlys, return_inverse=True)
@@ -68,14 +79,21 @@ def make_problem(
     rep_len = [lengths[np.where(dlys == d)[0][0]] for d in uniq]
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:  # LAPACK/BLAS release the GIL
         basis = list(ex.map(lambda L: modeling.yield_dpss_model_comps_bl_grp(L, freqs, operator_cache=operator_cache), rep_len))
-    nbls = len(i_idx)
     grp_basis = inv.astype(np.int32)
     nvec = np.asarray([basis[b].shape[1] for b in grp_basis])
+    if bl_sel is not None:
+        sel = np.asarray(bl_sel(nvec, grp_basis) if callable(bl_sel) else bl_sel, dtype=np.int64)
+        i_idx, j_idx, grp_basis, nvec = i_idx[sel], j_idx[sel], grp_basis[sel], nvec[sel]
+        used = np.unique(grp_basis)
+        remap = -np.ones(len(basis), dtype=np.int64)
+        remap[used] = np.arange(len(used))
+        basis = [basis[u] for u in used]
+        grp_basis = remap[grp_basis].astype(np.int32)
+    nbls = len(i_idx)
     coff = np.concatenate([[0], np.cumsum(nvec)])
     # truth
     k_idx = np.concatenate([np.arange(n) for n in nvec])
     c_true = (rng.standard_normal(coff[-1]) + 1j * rng.standard_normal(coff[-1])) / (k_idx + 1.0)
-    g_true = 1.0 + gain_sigma * (rng.standard_normal((nants, nfreqs)) + 1j * rng.standard_normal((nants, nfreqs)))
     vis = np.empty((nbls, nfreqs), dtype=np.complex128)
     for u in range(len(basis)):
         bls = np.where(grp_basis == u)[0]
@@ -86,7 +104,8 @@ def make_problem(
     data += noise_frac * sig_rms * (rng.standard_normal(data.shape) + 1j * rng.standard_normal(data.shape)) / np.sqrt(2.0)
     flags = rng.random((nbls, nfreqs)) < flag_frac
     wgts = (~flags).astype(np.float64)
-    wgts /= wgts.sum()
+    # global normalisation; with a shard the other ranks' baselines are flagged at the same rate in expectation
+    wgts /= wgts.sum() * (nbls_slice / nbls)
     rms = np.sqrt(np.mean(np.abs(data[~flags]) ** 2))
     data = data / rms
     prob = FitProblem(

@@ -184,3 +184,19 @@ def test_errors_are_reported():
     bad.bl_ant1[0] = 99
     with pytest.raises((AssertionError, _lib.CalamityHipError)):
         s.set_problem(bad)
+
+
+def test_single_rank_communicator_exercises_the_rccl_path():
+    """A 1-rank RCCL communicator: the per-step all-reduce is issued (identity) and results are unchanged."""
+    from calamity_amd.solver import comm_unique_id
+
+    p, start = make_case(seed=13, with_sky=True)
+    s0 = make_solver(p, start, np.float64, reg=True)
+    s1 = make_solver(p, start, np.float64, reg=True)
+    s1.comm_init(comm_unique_id(), 0, 1)
+    for s in (s0, s1):
+        s.set_optimizer("Adam", learning_rate=1e-2)
+    l0, _, _ = s0.run(5, record=True)
+    l1, _, _ = s1.run(5, record=True)
+    np.testing.assert_array_equal(l0, l1)
+    np.testing.assert_array_equal(s0.get_params()[0], s1.get_params()[0])
