@@ -210,6 +210,14 @@ def main():
         value = args.steps * ntimes / dt
         kern_ms = tim["total_ms"] / max(tim["launches"], 1)
         achieved = tim["algorithmic_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.config}_{'f32' if dtype == np.float32 else 'f64'}_{args.layout}.json")
+        if world == 1 and args.max_bls is None and args.reg == "none" and os.path.exists(pmc_path):
+            # HBM bytes per launch of the same kernel on the same workload, from separate rocprofv3 --pmc FETCH_SIZE /
+            # WRITE_SIZE passes (tools/pmc_summary.py; gfx950 corrections of MI355X_MICROARCH.md applied there)
+            for k, v in json.load(open(pmc_path))["kernels"].items():
+                if "fused_basis_kernel" in k and ", 1, false>" in k:
+                    traffic, traffic_src = v["hbm_bytes"], os.path.relpath(pmc_path, ROOT)
         out = {
             "metric": "Adam steps/sec (chi2 eval/sec in extra), HERA-350 1024ch DPSS; %HBM roofline",
             "value": value,
@@ -237,7 +245,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": tim["algorithmic_bytes_per_launch"],
             },
