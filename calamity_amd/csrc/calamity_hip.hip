@@ -16,6 +16,9 @@
 #include <vector>
 
 #include "fit_kernels.hpp"
+#include "mfma_kernels.hpp"
+#include <cstdlib>
+#include <type_traits>
 
 using namespace calk;
 
@@ -133,6 +136,11 @@ struct SolverT final : cal_solver {
   DevBuf scal;                                 // 4 doubles: loss, s_r, s_i
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
+  // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
+  DevBuf mf_akf, mf_afk, mf_panels, mf_bl_coff;
+  int mf_npanels = 0;
+  size_t mf_lds = 0;
+  bool mf_ok = false;
   DevState* h_state = nullptr;                 // pinned mirror
   // settings
   cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7};
@@ -213,6 +221,12 @@ struct SolverT final : cal_solver {
                     d->basis_nvec[u], (int)(kTileBytes / sizeof(T) / FbSet<T>::fb_min));
       fb_used_max = std::max(fb_used_max, fb_u[u]);
     }
+    // the dense path tiles channels in chunks of kChunk
+    bool want_mfma = std::is_same<T, float>::value && layout == CAL_LAYOUT_SHARED && !getenv("CALAMITY_HIP_NO_MFMA");
+    for (int g = 0; g < ngrps && want_mfma; ++g) want_mfma = (d->grp_bl_start[g + 1] - d->grp_bl_start[g]) == 1;
+    for (int u = 0; u < nbasis && want_mfma; ++u) want_mfma = d->basis_nrowblk[u] == 1 && d->basis_nvec[u] <= 32 * kMaxNT;
+    if ((long long)nbls * (nfreqs + kChunk) >= (1LL << 31)) want_mfma = false;  // the dense kernel uses 32-bit sample offsets
+    if (want_mfma) fb_used_max = std::max(fb_used_max, kChunk);
     fpad = (nfreqs + fb_used_max - 1) / fb_used_max * fb_used_max;
     lds_bytes = 0;
     for (int u = 0; u < nbasis; ++u) lds_bytes = std::max(lds_bytes, lds_for(fb_u[u]));
@@ -282,6 +296,57 @@ struct SolverT final : cal_solver {
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(stream));
       basis_bytes = (double)off / fpad * nfreqs * sizeof(T);
+    }
+    mf_ok = false;
+    if (want_mfma) {
+      if constexpr (std::is_same<T, float>::value) {
+        std::vector<long long> okf(nbasis + 1, 0), ofk(nbasis + 1, 0);
+        std::vector<int> nvp2(nbasis), nvp32(nbasis);
+        int nvp2_max = 0;
+        for (int u = 0; u < nbasis; ++u) {
+          nvp2[u] = (d->basis_nvec[u] + 15) / 16 * 16;
+          nvp32[u] = (d->basis_nvec[u] + 31) / 32 * 32;
+          nvp2_max = std::max(nvp2_max, nvp2[u]);
+          okf[u + 1] = okf[u] + (long long)fpad * nvp2[u];
+          ofk[u + 1] = ofk[u] + (long long)fpad * nvp32[u];
+        }
+        CAL_TRY(mf_akf.alloc((size_t)okf[nbasis] * sizeof(float), false));
+        CAL_TRY(mf_afk.alloc((size_t)ofk[nbasis] * sizeof(float), false));
+        for (int u = 0; u < nbasis; ++u)
+          hipLaunchKernelGGL(mfma_layout_kernel, dim3(grid_for((long long)fpad * (nvp2[u] + nvp32[u]))), dim3(256), 0, stream,
+                             raw.as<float>() + d->basis_offset[u], mf_akf.as<float>() + okf[u], mf_afk.as<float>() + ofk[u], nfreqs, fpad,
+                             d->basis_nvec[u], nvp2[u], nvp32[u]);
+        HIP_TRY(hipGetLastError());
+        // panels of kPanel baselines with the same basis, heaviest first
+        std::vector<std::vector<int>> by_u(nbasis);
+        for (int b = 0; b < nbls; ++b) by_u[d->grp_basis[grp_of_bl[b]]].push_back(b);
+        std::vector<int> uorder(nbasis);
+        std::iota(uorder.begin(), uorder.end(), 0);
+        std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
+        std::vector<PanelItem> h_panels;
+        for (int u : uorder) {
+          for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
+            PanelItem pi{};
+            for (int k = 0; k < kPanel; ++k) pi.bl[k] = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+            pi.a_kf = okf[u];
+            pi.a_fk = ofk[u];
+            pi.nvec = d->basis_nvec[u];
+            pi.nvp2 = nvp2[u];
+            pi.nvp32 = nvp32[u];
+            h_panels.push_back(pi);
+          }
+        }
+        mf_npanels = (int)h_panels.size();
+        CAL_TRY(mf_panels.alloc(h_panels.size() * sizeof(PanelItem), false));
+        HIP_TRY(hipMemcpyAsync(mf_panels.p, h_panels.data(), h_panels.size() * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
+        std::vector<int> h_bl_coff(nbls);
+        for (int b = 0; b < nbls; ++b) h_bl_coff[b] = h_grp_coff[grp_of_bl[b]];
+        CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
+        HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        mf_lds = mfma_lds_bytes(nvp2_max);
+        mf_ok = true;
+      }
     }
     raw.release();
     CAL_TRY(bl_tile.alloc(nbls * sizeof(long long), false));
@@ -407,7 +472,7 @@ struct SolverT final : cal_solver {
     CAL_TRY(gcp0.alloc(2 * (size_t)gcp_len * sizeof(T)));
     gcp1.release();
     gc1.release();
-    CAL_TRY(part.alloc((size_t)nitems * 4 * sizeof(double)));
+    CAL_TRY(part.alloc((size_t)std::max(nitems, mf_npanels) * 4 * sizeof(double)));
     model_buf.release();
     scratch.release();
     has_problem = true;
@@ -621,14 +686,43 @@ struct SolverT final : cal_solver {
       ++ev_used;
       HIP_TRY(hipEventRecord(e0, stream));
     }
-    if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
+    const bool use_mfma = mf_ok && !R;
+    if (use_mfma) {
+      if constexpr (std::is_same<T, float>::value) {
+        MfmaArgs m{};
+        m.a_kf = mf_akf.as<float>();
+        m.a_fk = mf_afk.as<float>();
+        m.panels = mf_panels.as<PanelItem>();
+        m.bl_ant = bl_ant.as<int2>();
+        m.bl_coff = mf_bl_coff.as<int>();
+        m.data_r = data_r.as<float>();
+        m.data_i = data_i.as<float>();
+        m.wgts = wgts.as<float>();
+        m.gains = gains.as<float2>();
+        m.c_r = coef.as<float>();
+        m.c_i = coef.as<float>() + ncoef;
+        m.q0 = q0.as<float2>();
+        m.gc_r = reinterpret_cast<float*>(grad_c0());
+        m.gc_i = reinterpret_cast<float*>(grad_c0()) + ncoef;
+        m.part = part.as<double>();
+        m.state = st;
+        m.fpad = fpad;
+        if (grads)
+          hipLaunchKernelGGL(fused_mfma_kernel<true>, dim3(mf_npanels), dim3(256), mf_lds, stream, m);
+        else
+          hipLaunchKernelGGL(fused_mfma_kernel<false>, dim3(mf_npanels), dim3(256), mf_lds, stream, m);
+      }
+    } else {
+      if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
+    }
+    const int n_parts = use_mfma ? mf_npanels : nitems;
     if (timing) HIP_TRY(hipEventRecord(e1, stream));
     const size_t gn = (size_t)nants * fpad;
     T2* r0 = comm.as<T2>();
     T2* r1 = r0 + gn;
     T2* r2 = r1 + gn;
     if (grads) {
-      if (!gc_direct) {
+      if (!gc_direct && !use_mfma) {
         hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
                            gcp0.as<T>() + gcp_len, gc0.as<T>(), gc0.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
                            grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
@@ -640,16 +734,16 @@ struct SolverT final : cal_solver {
       const int nb = (int)((gn + 255) / 256) + 1;
       if (R)
         hipLaunchKernelGGL((gain_grad_kernel<T, true>), dim3(nb), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
-                           ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), nitems,
+                           ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), n_parts,
                            scal.as<double>(), st);
       else
         hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(nb), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
-                           ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), nitems,
+                           ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), n_parts,
                            scal.as<double>(), st);
     } else {
       // loss only: just the partial-sum block of the gain kernel (nants = 0 -> no antenna work)
       hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
-                         ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, 0, fpad, part.as<double>(), nitems, scal.as<double>(), st);
+                         ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, 0, fpad, part.as<double>(), n_parts, scal.as<double>(), st);
     }
     if (nccl) {
       // the one exchange step of the sharded fit: sum gain-gradient parts and loss scalars over ranks
