@@ -137,10 +137,10 @@ struct SolverT final : cal_solver {
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
-  DevBuf mf_akf, mf_afk, mf_panels, mf_bl_coff;
+  DevBuf mf_akf, mf_afk, mf_akf4, mf_afk4, mf_panels, mf_bl_coff;
   int mf_npanels = 0;
-  size_t mf_lds = 0;
-  bool mf_ok = false;
+  size_t mf_lds = 0, mf_ws_lds = 0;
+  bool mf_ok = false, mf_ws = true;
   DevState* h_state = nullptr;                 // pinned mirror
   // settings
   cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7};
@@ -225,7 +225,7 @@ struct SolverT final : cal_solver {
     bool want_mfma = std::is_same<T, float>::value && layout == CAL_LAYOUT_SHARED && !getenv("CALAMITY_HIP_NO_MFMA");
     for (int g = 0; g < ngrps && want_mfma; ++g) want_mfma = (d->grp_bl_start[g + 1] - d->grp_bl_start[g]) == 1;
     for (int u = 0; u < nbasis && want_mfma; ++u) want_mfma = d->basis_nrowblk[u] == 1 && d->basis_nvec[u] <= 32 * kMaxNT;
-    if ((long long)nbls * (nfreqs + kChunk) >= (1LL << 31)) want_mfma = false;  // the dense kernel uses 32-bit sample offsets
+    if ((long long)(nbls + 1) * (nfreqs + kChunk) >= (1LL << 31)) want_mfma = false;  // the dense kernel uses 32-bit sample offsets
     if (want_mfma) fb_used_max = std::max(fb_used_max, kChunk);
     fpad = (nfreqs + fb_used_max - 1) / fb_used_max * fb_used_max;
     lds_bytes = 0;
@@ -300,16 +300,25 @@ struct SolverT final : cal_solver {
     mf_ok = false;
     if (want_mfma) {
       if constexpr (std::is_same<T, float>::value) {
-        std::vector<long long> okf(nbasis + 1, 0), ofk(nbasis + 1, 0);
+        std::vector<long long> okf(nbasis + 1, 0), ofk(nbasis + 1, 0), okf4(nbasis + 1, 0), ofk4(nbasis + 1, 0);
         std::vector<int> nvp2(nbasis), nvp32(nbasis);
-        int nvp2_max = 0;
+        int nvp2_max = 0, nvec_max = 0;
         for (int u = 0; u < nbasis; ++u) {
           nvp2[u] = (d->basis_nvec[u] + 15) / 16 * 16;
           nvp32[u] = (d->basis_nvec[u] + 31) / 32 * 32;
           nvp2_max = std::max(nvp2_max, nvp2[u]);
           okf[u + 1] = okf[u] + (long long)fpad * nvp2[u];
           ofk[u + 1] = ofk[u] + (long long)fpad * nvp32[u];
+          nvec_max = std::max(nvec_max, d->basis_nvec[u]);
+          okf4[u + 1] = okf4[u] + (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256;
+          ofk4[u + 1] = ofk4[u] + (long long)(fpad / 8) * (nvp32[u] / 32) * 256;
         }
+        CAL_TRY(mf_akf4.alloc((size_t)okf4[nbasis] * sizeof(float), false));
+        CAL_TRY(mf_afk4.alloc((size_t)ofk4[nbasis] * sizeof(float), false));
+        for (int u = 0; u < nbasis; ++u)
+          hipLaunchKernelGGL(mfma_pack_kernel, dim3(grid_for(okf4[u + 1] - okf4[u] + ofk4[u + 1] - ofk4[u])), dim3(256), 0, stream,
+                             raw.as<float>() + d->basis_offset[u], mf_akf4.as<float>() + okf4[u], mf_afk4.as<float>() + ofk4[u], nfreqs, fpad,
+                             d->basis_nvec[u], nvp32[u]);
         CAL_TRY(mf_akf.alloc((size_t)okf[nbasis] * sizeof(float), false));
         CAL_TRY(mf_afk.alloc((size_t)ofk[nbasis] * sizeof(float), false));
         for (int u = 0; u < nbasis; ++u)
@@ -323,18 +332,43 @@ struct SolverT final : cal_solver {
         std::vector<int> uorder(nbasis);
         std::iota(uorder.begin(), uorder.end(), 0);
         std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
-        std::vector<PanelItem> h_panels;
+        // Optional XCD-aware order (CALAMITY_HIP_XCD_LISTS=1): workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
+        // 4 MB L2), so all panels of one basis block go to ONE XCD (its operand copies, ~1 MB, then stay L2-resident
+        // there); blocks are spread over XCDs by greedy longest-processing-time balancing of the MFMA work.  The kernel
+        // maps block b to panel (b % 8) * per_xcd + b / 8; short lists are padded with empty panels (nvec = 0).
+        constexpr int kXcd = 8;
+        std::vector<std::vector<PanelItem>> xlist(kXcd);
+        std::vector<double> xwork(kXcd, 0.0);
+        const bool no_xcd = getenv("CALAMITY_HIP_XCD_LISTS") == nullptr;  // default: plain heaviest-first order over all XCDs (per-XCD lists measured 3 % slower: imbalance)
+        size_t rr = 0;
         for (int u : uorder) {
+          if (by_u[u].empty()) continue;
+          int x = (int)(std::min_element(xwork.begin(), xwork.end()) - xwork.begin());
+          const int npan = (int)((by_u[u].size() + kPanel - 1) / kPanel);
+          xwork[x] += (double)npan * (nvp2[u] + nvp32[u]);
           for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
             PanelItem pi{};
             for (int k = 0; k < kPanel; ++k) pi.bl[k] = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
             pi.a_kf = okf[u];
             pi.a_fk = ofk[u];
+            pi.a_kf4 = okf4[u];
+            pi.a_fk4 = ofk4[u];
             pi.nvec = d->basis_nvec[u];
             pi.nvp2 = nvp2[u];
             pi.nvp32 = nvp32[u];
-            h_panels.push_back(pi);
+            if (no_xcd) x = (int)(rr++ % kXcd);
+            xlist[x].push_back(pi);
           }
+        }
+        size_t per_xcd = 0;
+        for (auto& l : xlist) per_xcd = std::max(per_xcd, l.size());
+        PanelItem empty{};
+        for (int k = 0; k < kPanel; ++k) empty.bl[k] = -1;
+        std::vector<PanelItem> h_panels;
+        h_panels.reserve(per_xcd * kXcd);
+        for (auto& l : xlist) {
+          h_panels.insert(h_panels.end(), l.begin(), l.end());
+          h_panels.insert(h_panels.end(), per_xcd - l.size(), empty);
         }
         mf_npanels = (int)h_panels.size();
         CAL_TRY(mf_panels.alloc(h_panels.size() * sizeof(PanelItem), false));
@@ -345,6 +379,10 @@ struct SolverT final : cal_solver {
         HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         mf_lds = mfma_lds_bytes(nvp2_max);
+        mf_ws_lds = mfma_ws_lds_bytes(nvec_max);
+        mf_ws = !getenv("CALAMITY_HIP_MFMA_NO_WS");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_mfma_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_ws_lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_mfma_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_ws_lds));
         mf_ok = true;
       }
     }
@@ -452,7 +490,7 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipMemcpy(ant_ent.p, h_ent.data(), h_ent.size() * sizeof(int2), hipMemcpyHostToDevice));
 
     // ---- state arrays
-    const size_t rowbytes = (size_t)nbls * fpad * sizeof(T);
+    const size_t rowbytes = (size_t)(nbls + 1) * fpad * sizeof(T);  // + one all-zero spare row (padding slots of the dense path)
     CAL_TRY(data_r.alloc(rowbytes));
     CAL_TRY(data_i.alloc(rowbytes));
     CAL_TRY(wgts.alloc(rowbytes));
@@ -466,7 +504,7 @@ struct SolverT final : cal_solver {
     CAL_TRY(coef_m.alloc(cbytes));
     CAL_TRY(coef_v.alloc(cbytes));
     coef_snap.release();
-    CAL_TRY(q0.alloc((size_t)nbls * fpad * sizeof(T2)));
+    CAL_TRY(q0.alloc((size_t)(nbls + 1) * fpad * sizeof(T2)));
     q1.release();
     CAL_TRY(comm.alloc(3 * gbytes));
     CAL_TRY(gcp0.alloc(2 * (size_t)gcp_len * sizeof(T)));
@@ -692,6 +730,8 @@ struct SolverT final : cal_solver {
         MfmaArgs m{};
         m.a_kf = mf_akf.as<float>();
         m.a_fk = mf_afk.as<float>();
+        m.a_kf4 = mf_akf4.as<float>();
+        m.a_fk4 = mf_afk4.as<float>();
         m.panels = mf_panels.as<PanelItem>();
         m.bl_ant = bl_ant.as<int2>();
         m.bl_coff = mf_bl_coff.as<int>();
@@ -707,10 +747,17 @@ struct SolverT final : cal_solver {
         m.part = part.as<double>();
         m.state = st;
         m.fpad = fpad;
-        if (grads)
+        m.nbls = nbls;
+        if (mf_ws) {
+          if (grads)
+            hipLaunchKernelGGL(fused_mfma_ws_kernel<true>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
+          else
+            hipLaunchKernelGGL(fused_mfma_ws_kernel<false>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
+        } else if (grads) {
           hipLaunchKernelGGL(fused_mfma_kernel<true>, dim3(mf_npanels), dim3(256), mf_lds, stream, m);
-        else
+        } else {
           hipLaunchKernelGGL(fused_mfma_kernel<false>, dim3(mf_npanels), dim3(256), mf_lds, stream, m);
+        }
       }
     } else {
       if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
@@ -985,6 +1032,10 @@ struct SolverT final : cal_solver {
 
 // ================================================================================================================
 extern "C" {
+
+#ifdef CAL_WS_STAMP
+int cal_debug_read_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(calk::g_ws_stamps), sizeof(calk::g_ws_stamps)); }
+#endif
 
 const char* cal_last_error(void) { return g_err.c_str(); }
 const char* cal_version(void) { return "calamity_hip 0.1 (gfx950)"; }

@@ -39,11 +39,15 @@ struct PanelItem {
   long long a_fk;     // element offset of the block in the [F][nvp32] copy        (adjoint B operand)
   int nvec, nvp2, nvp32;
   int pad;
+  long long a_kf4;    // packed forward operand  [F/32][nvp8/8][64 lanes][4]: lane (col, half), u -> A[32 fb + col][8 g + 2 u + half]
+  long long a_fk4;    // packed adjoint operand  [F/8][nvp32/32][64 lanes][4]: lane (col, half), u -> A[8 cg + 2 u + half][32 t + col]
 };
 
 struct MfmaArgs {
   const float* a_kf;
   const float* a_fk;
+  const float* a_kf4;
+  const float* a_fk4;
   const PanelItem* panels;
   const int2* bl_ant;
   const int* bl_coff;          // coefficient offset of each baseline's group
@@ -59,6 +63,7 @@ struct MfmaArgs {
   double* part;                // [npanels][4]
   const DevState* state;
   int fpad;
+  int nbls;                    // row nbls of data_r / data_i / wgts / q0 is an all-zero spare row for padding slots
 };
 
 constexpr int kSC = 33;  // LDS row stride of the coefficient panel  [k][32 rows]
@@ -68,7 +73,13 @@ template <bool GRAD>
 __global__ __launch_bounds__(256) void fused_mfma_kernel(const MfmaArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (A.state->done | A.state->done_after) return;
-  const PanelItem& P = A.panels[blockIdx.x];
+  // XCD-aware block -> panel map (see the host): the 8 XCDs each walk their own contiguous list of panels
+  const int per_xcd = gridDim.x >> 3;
+  const PanelItem& P = A.panels[(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)];
+  if (P.nvec == 0) {  // padding panel of a short XCD list
+    if (threadIdx.x == 0) A.part[(size_t)blockIdx.x * 4] = A.part[(size_t)blockIdx.x * 4 + 1] = A.part[(size_t)blockIdx.x * 4 + 2] = 0.0;
+    return;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -355,11 +366,408 @@ __global__ __launch_bounds__(256) void fused_mfma_kernel(const MfmaArgs A) {
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Wave-specialised version (the one that ships).  A wave's vector-memory operations retire in issue order, so a wave
+// that mixes L2-served MFMA operand loads with HBM loads (data, weights) stalls its matrix pipe on the slow ones.
+// Here a 512-thread workgroup has 4 MATRIX waves (waves 0-3: forward GEMM, adjoint GEMM; they only ever load basis
+// operands, which live in L2) and 4 ELEMENT waves (waves 4-7, one per SIMD beside a matrix wave: HBM loads of data /
+// weights / gains one chunk ahead, residual, chi^2, gbar_v, gbar_G store).  They meet in LDS:
+//   tick k:  matrix waves   F(k): V chunk k -> s_v[k&1]          and  B(k-2): adjoint with s_g[(k-2)&1]
+//            element waves  E(k-1): s_v[(k-1)&1] -> s_g[(k-1)&1], then request chunk k's inputs
+//   one workgroup barrier per tick; VALU work of the element wave overlaps the MFMAs of the matrix wave on its SIMD.
+#ifndef CAL_WS_THREADS
+#define CAL_WS_THREADS 512
+#endif
+constexpr int kWsThreads = CAL_WS_THREADS;  // 256 = timing experiment without element waves (results are wrong)
+#ifdef CAL_WS_STAMP
+// diagnostic build only: per-wave cycle stamps of a few workgroups (never read by the kernels)
+__device__ long long g_ws_stamps[8][8][16][4];  // [block slot][wave][tick][stamp]
+#define WS_STAMP(blk, tick, idx)                                                                                        \
+  do {                                                                                                                  \
+    if ((blk) >= 0 && lane == 0 && (tick) < 16) g_ws_stamps[blk][wave][tick][idx] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define WS_STAMP(blk, tick, idx)
+#endif
+constexpr int kSW = 36;  // LDS row stride of the V / gbar chunk buffers [channel][32 rows]: 16-B aligned rows, and 36 f mod 64
+                         // walks the 16 bank quads, so ds_read/write_b128 by 16 consecutive channels are conflict-free
+
+template <bool GRAD>
+__global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArgs A) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (A.state->done | A.state->done_after) return;
+  // XCD-aware block -> panel map (see the host): the 8 XCDs each walk their own contiguous list of panels
+  const int per_xcd = gridDim.x >> 3;
+  const PanelItem& P = A.panels[(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)];
+  if (P.nvec == 0) {  // padding panel of a short XCD list
+    if (threadIdx.x == 0) A.part[(size_t)blockIdx.x * 4] = A.part[(size_t)blockIdx.x * 4 + 1] = A.part[(size_t)blockIdx.x * 4 + 2] = 0.0;
+    return;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  // wave-uniform quantities live in SGPRs: every operand address below is (scalar base) + (lane offset)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_matrix = wave < 4;
+  const int w4 = wave & 3;     // channel quarter of the chunk handled by this wave (both roles)
+  const int col = lane & 31;
+  const int half = lane >> 5;
+  const int nvec = P.nvec, nvp32 = P.nvp32;
+  const int NT = nvp32 / 32;
+  const int ngk = (nvec + 7) / 8;  // forward k-groups of 8 vectors (4 k-steps)
+
+  float* s_c = reinterpret_cast<float*>(smem_raw);          // [ngk][64 lanes][4] packed coefficient operand
+  float* s_v = s_c + (size_t)ngk * 256;                     // [2][kChunk][kSW]  model visibilities, rows = (slot, re|im)
+  float* s_g = s_v + 2 * (size_t)kChunk * kSW;              // [2][kChunk][kSW]  gbar_v
+  int* s_bl = reinterpret_cast<int*>(s_g + 2 * (size_t)kChunk * kSW);  // [16] baseline, [16] ant0, [16] ant1
+  double* s_red = reinterpret_cast<double*>(s_bl + 48);     // [4]
+
+  if (tid < kPanel) {
+    const int b = P.bl[tid];
+    s_bl[tid] = b >= 0 ? b : A.nbls;  // padding slots use the all-zero extra row (weight 0) of the sample arrays
+    const int2 ant = b >= 0 ? A.bl_ant[b] : make_int2(0, 0);
+    s_bl[16 + tid] = ant.x;
+    s_bl[32 + tid] = ant.y;
+  }
+  {
+    // coefficient panel in the packed A-operand layout: s_c[(g * 64 + lane) * 4 + u] = c_part[row = lane & 31][k = 8 g + 2 u + (lane >> 5)],
+    // rows 0-15 re, 16-31 im of the panel slots; zero beyond nvec and for padding slots
+    const int n = ngk * 256;
+    for (int i = tid; i < n; i += kWsThreads) {
+      const int u = i & 3, l = (i >> 2) & 63, g = i >> 8;
+      const int row = l & 31, k = 8 * g + 2 * u + (l >> 5);
+      const int b = P.bl[row & 15];
+      float v = 0.f;
+      if (b >= 0 && k < nvec) v = (row < 16 ? A.c_r : A.c_i)[A.bl_coff[b] + k];
+      s_c[i] = v;
+    }
+  }
+  __syncthreads();
+
+#ifdef CAL_MF_DEBUG_CHUNKS
+  const int nchunks = CAL_MF_DEBUG_CHUNKS;  // timing experiment only (results are wrong)
+#else
+  const int nchunks = A.fpad / kChunk;
+#endif
+  const int nticks = nchunks + (GRAD ? 2 : 1);
+#ifdef CAL_WS_STAMP
+  const int sblk = (blockIdx.x >= 2048 && blockIdx.x < 2056) ? (int)blockIdx.x - 2048 : -1;
+#endif
+
+  if (is_matrix) {
+    // ================================================= matrix waves ==============================================
+    __builtin_amdgcn_s_setprio(2);  // the matrix wave's issue slots come first on the SIMD it shares with an element wave
+    int t0, t1 = -1, kq = 0, nkq = 1;
+    if (NT == 1) { t0 = 0; kq = w4; nkq = 4; }
+    else if (NT == 2) { t0 = w4 & 1; kq = w4 >> 1; nkq = 2; }
+    else if (NT <= 4) { t0 = w4 < NT ? w4 : -1; }
+    else { t0 = w4; t1 = w4 + 4 < NT ? w4 + 4 : -1; }
+    f32x16 gacc0, gacc1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gacc0[j] = gacc1[j] = 0.f;
+    const f32x4* akf4 = reinterpret_cast<const f32x4*>(A.a_kf4 + P.a_kf4);   // scalar bases
+    const f32x4* afk4 = reinterpret_cast<const f32x4*>(A.a_fk4 + P.a_fk4);
+    const f32x4* sc4 = reinterpret_cast<const f32x4*>(s_c);
+    for (int k = 0; k < nticks; ++k) {
+      WS_STAMP(sblk, k, 0);
+      if (k < nchunks) {
+        // ---- F(k): rows = (slot, re|im), columns = this wave's 32 channels, K = vectors.  One global_load_dwordx4 (basis, L2)
+        // and one ds_read_b128 (coefficients) feed four MFMAs; two register sets of 4 k-groups ping-pong.
+        f32x16 acc, acc2;  // two accumulator chains
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = acc2[j] = 0.f;
+        const f32x4* tile = akf4 + ((size_t)(k * 4 + w4) * ngk) * 64;  // scalar; + 64 g (scalar) + lane
+        f32x4 xb[4], xa[4], yb[4], ya[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int g = u < ngk ? u : ngk - 1;
+          xb[u] = (tile + g * 64)[lane];
+          xa[u] = (sc4 + g * 64)[lane];
+        }
+        for (int g0 = 0; g0 < ngk; g0 += 8) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 4 + u < ngk ? g0 + 4 + u : ngk - 1;
+            yb[u] = (tile + g * 64)[lane];
+            ya[u] = (sc4 + g * 64)[lane];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (g0 + u < ngk) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][0], xb[u][0], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][1], xb[u][1], acc2, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][2], xb[u][2], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][3], xb[u][3], acc2, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 8 + u < ngk ? g0 + 8 + u : ngk - 1;
+            xb[u] = (tile + g * 64)[lane];
+            xa[u] = (sc4 + g * 64)[lane];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (g0 + 4 + u < ngk) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u][0], yb[u][0], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u][1], yb[u][1], acc2, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u][2], yb[u][2], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u][3], yb[u][3], acc2, 0, 0, 0);
+            }
+          }
+        }
+        // accumulator regs 4 q .. 4 q + 3 of this lane = rows 8 q + 4 half + 0..3 of column (channel) w4*32 + col
+        f32x4* vout = reinterpret_cast<f32x4*>(s_v + (size_t)(k & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + 4 * half);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t;
+          t[0] = acc[4 * q] + acc2[4 * q];
+          t[1] = acc[4 * q + 1] + acc2[4 * q + 1];
+          t[2] = acc[4 * q + 2] + acc2[4 * q + 2];
+          t[3] = acc[4 * q + 3] + acc2[4 * q + 3];
+          vout[2 * q] = t;  // + 8 rows
+        }
+      }
+      WS_STAMP(sblk, k, 1);
+      if (GRAD && k >= 2 && t0 >= 0) {
+        // ---- B(k-2): rows = (slot, re|im), columns = vectors of tile t, K = this wave's slice of the chunk's channels
+        const int ci = k - 2;
+        const int ng_per = (kChunk / 8) / nkq;  // channel groups (8 channels = 4 k-steps) of this wave: 16, 8 or 4
+        const int cg0 = kq * ng_per, cg1 = cg0 + ng_per;
+        const float* gp = s_g + (size_t)(ci & 1) * kChunk * kSW + half * kSW + col;       // + (8 cg + 2 v) kSW
+        const f32x4* bp0 = afk4 + ((size_t)(ci * (kChunk / 8)) * NT + t0) * 64;            // scalar; + cg NT 64 + lane
+        const f32x4* bp1 = afk4 + ((size_t)(ci * (kChunk / 8)) * NT + (t1 >= 0 ? t1 : t0)) * 64;
+        const size_t bstr = (size_t)NT * 64;
+        f32x4 xb0[2], xb1[2], yb0[2], yb1[2];
+        float xa[2][4], ya[2][4];
+        auto bload = [&](f32x4 (&b0)[2], f32x4 (&b1)[2], float (&a)[2][4], int cgb) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            b0[u] = (bp0 + (cgb + u) * bstr)[lane];
+            if (t1 >= 0) b1[u] = (bp1 + (cgb + u) * bstr)[lane];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a[u][v] = gp[(8 * (cgb + u) + 2 * v) * kSW];
+          }
+        };
+        auto bmma = [&](const f32x4 (&b0)[2], const f32x4 (&b1)[2], const float (&a)[2][4]) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (t1 >= 0) {
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][v], b0[u][v], gacc0, 0, 0, 0);
+                gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][v], b1[u][v], gacc1, 0, 0, 0);
+              }
+            } else {  // single tile: gacc1 is a second, independent chain of the same tile (summed at the end)
+              gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][0], b0[u][0], gacc0, 0, 0, 0);
+              gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][1], b0[u][1], gacc1, 0, 0, 0);
+              gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][2], b0[u][2], gacc0, 0, 0, 0);
+              gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][3], b0[u][3], gacc1, 0, 0, 0);
+            }
+          }
+        };
+        bload(xb0, xb1, xa, cg0);
+        for (int cg = cg0; cg < cg1; cg += 4) {
+          bload(yb0, yb1, ya, cg + 2);
+          bmma(xb0, xb1, xa);
+          bload(xb0, xb1, xa, cg + 4 < cg1 ? cg + 4 : cg);
+          bmma(yb0, yb1, ya);
+        }
+      }
+      WS_STAMP(sblk, k, 2);
+      __syncthreads();
+      WS_STAMP(sblk, k, 3);
+#ifdef CAL_WS_STAMP
+      if (sblk >= 0 && lane == 0 && (k == 0 || k == nticks - 1)) { g_ws_stamps[sblk][wave][k == 0 ? 14 : 15][0] = (long long)__builtin_amdgcn_s_memrealtime(); g_ws_stamps[sblk][wave][14][1] = nvec; g_ws_stamps[sblk][wave][14][2] = NT; g_ws_stamps[sblk][wave][14][3] = t0 * 100 + t1 * 10 + nkq; }
+#endif
+    }
+    if (!GRAD) return;
+    if (t1 < 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gacc0[j] += gacc1[j];
+    }
+    // ---- coefficient gradients: sum the K-slices of different matrix waves through LDS, then store
+    if (nkq > 1) {
+      float* s_x = s_v;  // [4 waves][16 regs][64 lanes] = 16 KB, inside the (now idle) s_v double buffer
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s_x[(w4 * 16 + j) * 64 + lane] = gacc0[j];
+    }
+    __syncthreads();  // pairs with the element waves' barrier after their tick loop
+    if (nkq > 1 && kq == 0) {
+      const float* s_x = s_v;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float v = gacc0[j];
+        for (int q = 1; q < nkq; ++q) v += s_x[((w4 + q * (NT == 1 ? 1 : 2)) * 16 + j) * 64 + lane];
+        gacc0[j] = v;
+      }
+    }
+    if (kq == 0 && t0 >= 0) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = tt == 0 ? t0 : t1;
+        if (t < 0) continue;
+        const int n = t * 32 + col;
+        if (n < nvec) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
+            const int b = P.bl[slot];
+            if (b >= 0) {
+              const int coff = A.bl_coff[b];
+              A.gc_r[coff + n] = tt == 0 ? gacc0[j] : gacc1[j];
+              A.gc_i[coff + n] = tt == 0 ? gacc0[j + 8] : gacc1[j + 8];
+            }
+          }
+        }
+      }
+    }
+  } else {
+    // ================================================= element waves =============================================
+    // lane = (channel w4*32 + col of the chunk, slot group half): slots half*8 .. half*8 + 7.  No branches: padding slots
+    // point at the all-zero extra row.  Sample offsets are unsigned 32-bit lane offsets from scalar bases.
+    struct ElemIn {
+      float dr[8], di[8], w[8];
+      float2 g0[8], g1[8];
+    };
+    ElemIn X, Y;
+    unsigned ob[8], og0[8], og1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int slot = half * 8 + j;
+      ob[j] = (unsigned)s_bl[slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col);
+      og0[j] = (unsigned)s_bl[16 + slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col);
+      og1[j] = (unsigned)s_bl[32 + slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col);
+    }
+    auto request = [&](int ci, ElemIn& E) {
+      const float* dr = A.data_r + ci * kChunk;  // scalar bases of this chunk
+      const float* di = A.data_i + ci * kChunk;
+      const float* wg = A.wgts + ci * kChunk;
+      const float2* gn = A.gains + ci * kChunk;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        E.dr[j] = dr[ob[j]];
+        E.di[j] = di[ob[j]];
+        E.w[j] = wg[ob[j]];
+        E.g0[j] = gn[og0[j]];
+        E.g1[j] = gn[og1[j]];
+      }
+    };
+    double loss_acc = 0.0;
+    auto process = [&](int ci, const ElemIn& E) {
+      const f32x4* vin = reinterpret_cast<const f32x4*>(s_v + (size_t)(ci & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + half * 8);
+      f32x4* gout = reinterpret_cast<f32x4*>(s_g + (size_t)(ci & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + half * 8);
+      float2* qo = A.q0 + ci * kChunk;
+      float lt = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 vr4 = vin[h], vi4 = vin[4 + h];  // rows half*8 + 4 h + 0..3 (re) and +16 (im)
+        f32x4 gr4, gi4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = 4 * h + u;
+          const float vr = vr4[u], vi = vi4[u];
+          const float d_r = E.dr[j], d_i = E.di[j], w = E.w[j];
+          const float2 g0 = E.g0[j], g1 = E.g1[j];
+          const float G_r = g0.x * g1.x + g0.y * g1.y;
+          const float G_i = g0.y * g1.x - g0.x * g1.y;
+          const float m_r = G_r * vr - G_i * vi;
+          const float m_i = G_i * vr + G_r * vi;
+          const float r_r = d_r - m_r, r_i = d_i - m_i;
+          lt += w * (r_r * r_r + r_i * r_i);
+          if (GRAD) {
+            const float e_r = -2.f * w * r_r, e_i = -2.f * w * r_i;
+            gr4[u] = G_r * e_r + G_i * e_i;
+            gi4[u] = G_r * e_i - G_i * e_r;
+            float2 q;
+            q.x = vr * e_r + vi * e_i;
+            q.y = vr * e_i - vi * e_r;
+            qo[ob[j]] = q;
+          }
+        }
+        if (GRAD) {
+          gout[h] = gr4;
+          gout[4 + h] = gi4;
+        }
+      }
+      loss_acc += (double)lt;
+    };
+    request(0, X);
+    if (nchunks > 1) request(1, Y);
+    __syncthreads();  // tick 0: nothing to consume yet
+    for (int k = 1; k < nticks; k += 2) {
+      WS_STAMP(sblk, k, 0);
+#ifndef CAL_WS_X_NOELEM
+      if (k <= nchunks) {
+        process(k - 1, X);
+        WS_STAMP(sblk, k, 1);
+        if (k + 1 < nchunks) request(k + 1, X);
+      }
+#endif
+      WS_STAMP(sblk, k, 2);
+      __syncthreads();
+      WS_STAMP(sblk, k, 3);
+      if (k + 1 < nticks) {
+#ifndef CAL_WS_X_NOELEM
+        WS_STAMP(sblk, k + 1, 0);
+        if (k + 1 <= nchunks) {
+          process(k, Y);
+          WS_STAMP(sblk, k + 1, 1);
+          if (k + 2 < nchunks) request(k + 2, Y);
+        }
+#endif
+        WS_STAMP(sblk, k + 1, 2);
+        __syncthreads();
+        WS_STAMP(sblk, k + 1, 3);
+      }
+    }
+    {
+      const double l = ldsum(loss_acc);
+      if (lane == 0) s_red[w4] = l;
+    }
+    __syncthreads();  // GRAD: pairs with the matrix waves' epilogue barrier; otherwise the matrix waves have exited and only
+                      // the element waves are counted (ended waves leave the barrier)
+    if (wave == 4 && lane == 0) {
+      A.part[(size_t)blockIdx.x * 4 + 0] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+      A.part[(size_t)blockIdx.x * 4 + 1] = 0.0;
+      A.part[(size_t)blockIdx.x * 4 + 2] = 0.0;
+    }
+  }
+}
+
+inline size_t mfma_ws_lds_bytes(int nvec_max) {
+  return ((size_t)((nvec_max + 7) / 8) * 256 + 4 * (size_t)kChunk * kSW) * sizeof(float) + 48 * sizeof(int) + 4 * sizeof(double) + 64;
+}
+
 inline size_t mfma_lds_bytes(int nvp2_max) {
   return ((size_t)nvp2_max * kSC + (size_t)kChunk * kSG) * sizeof(float) + 48 * sizeof(int) + 4 * sizeof(double) + 64;
 }
 
 // unique basis block (row-major [F][nvec]) -> the two operand layouts (zero padded)
+// packed MFMA-native operand layouts of the wave-specialised kernel (see PanelItem)
+__global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ a_kf4, float* __restrict__ a_fk4, int nfreqs, int fpad,
+                                 int nvec, int nvp32) {
+  const int ngk = (nvec + 7) / 8, NT = nvp32 / 32;
+  const long long n1 = (long long)(fpad / 32) * ngk * 256, n2 = (long long)(fpad / 8) * NT * 256;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * blockDim.x) {
+    if (i < n1) {
+      const int u = (int)(i & 3), l = (int)((i >> 2) & 63);
+      const long long r = i >> 8;
+      const int g = (int)(r % ngk), fb = (int)(r / ngk);
+      const int f = fb * 32 + (l & 31), k = 8 * g + 2 * u + (l >> 5);
+      a_kf4[i] = (f < nfreqs && k < nvec) ? src[(long long)f * nvec + k] : 0.f;
+    } else {
+      const long long q = i - n1;
+      const int u = (int)(q & 3), l = (int)((q >> 2) & 63);
+      const long long r = q >> 8;
+      const int t = (int)(r % NT), cg = (int)(r / NT);
+      const int f = 8 * cg + 2 * u + (l >> 5), n = 32 * t + (l & 31);
+      a_fk4[q] = (f < nfreqs && n < nvec) ? src[(long long)f * nvec + n] : 0.f;
+    }
+  }
+}
+
 __global__ void mfma_layout_kernel(const float* __restrict__ src, float* __restrict__ a_kf, float* __restrict__ a_fk, int nfreqs,
                                    int fpad, int nvec, int nvp2, int nvp32) {
   const long long n1 = (long long)fpad * nvp2, n2 = (long long)fpad * nvp32;
