@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 
 
 def parse():
@@ -37,6 +38,7 @@ def parse():
     ap.add_argument("--reg", default="none", choices=["none", "sum"])
     ap.add_argument("--max-bls", type=int, default=None, help="bounded sample of the baselines (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shared", action="store_true", help="skip the extra shared-layout (MFMA) measurement")
     ap.add_argument("--cpu-sample-bls", type=int, default=192)
     return ap.parse_args()
 
@@ -205,6 +207,39 @@ def main():
     sync()
     chi2_rate = nev * ntimes / (time.perf_counter() - t1)
 
+    # the SHARED layout of the same workload (baselines of one delay alias ONE basis block; fp32 MFMA GEMM path): measured
+    # in the same run and reported beside the headline, against its own bounds
+    shared = None
+    if world == 1 and args.layout == "stream" and not args.no_shared and dtype == np.float32 and args.reg == "none":
+        s2 = HipFitSolver(dtype=dtype, device=0)
+        s2.set_problem(prob, layout="shared")
+        s2.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        s2.set_optimizer(args.optimizer, learning_rate=1e-2)
+        s2.run(max(args.warmup, 1), record=False, tol=0.0)
+        s2.timing_enable(True)
+        s2.synchronize()
+        t2 = time.perf_counter()
+        s2.run(args.steps, record=True, tol=0.0)
+        s2.synchronize()
+        dt2 = time.perf_counter() - t2
+        tim2 = s2.timing_get()
+        k2 = tim2["total_ms"] / max(tim2["launches"], 1)
+        flops = 8.0 * prob.nfreqs * prob.ncoeffs  # forward A c and adjoint A^T gbar_v, complex x real
+        uniq_bytes = float(sum(b.size for b in prob.basis)) * np.dtype(dtype).itemsize
+        bytes_unique = tim2["algorithmic_bytes_per_launch"] - tim2["basis_bytes_per_launch"] + uniq_bytes
+        shared = {
+            "steps_per_s": args.steps / dt2,
+            "ms_per_step": dt2 / args.steps * 1e3,
+            "kernel": "fused_mfma_ws_kernel<GRAD> (v_mfma_f32_32x32x2_f32)",
+            "kernel_ms": k2,
+            "roofline_mfma": {"bound": "mfma", "achieved": flops / (k2 * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": flops / (k2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_launch": flops},
+            "roofline_hbm_unique_basis": {"bound": "hbm", "achieved": bytes_unique / (k2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": bytes_unique / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_unique},
+            "device_memory_GB": s2.memory_bytes() / 1e9,
+        }
+        s2.close()
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = args.steps * ntimes / dt
@@ -254,6 +289,7 @@ def main():
                 "chi2_evals_per_s": chi2_rate,
                 "setup_s": t_setup,
                 "device_memory_GB": solvers[0].memory_bytes() / 1e9 * len(solvers),
+                "shared_layout": shared,
             },
         }
         if not args.no_cpu_baseline:

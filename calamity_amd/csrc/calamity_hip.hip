@@ -778,7 +778,8 @@ struct SolverT final : cal_solver {
                              gcp1.as<T>() + gcp_len, gc1.as<T>(), gc1.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
                              grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
       }
-      const int nb = (int)((gn + 255) / 256) + 1;
+      const int cpl = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;
+      const int nb = nants * ((fpad + 64 * cpl - 1) / (64 * cpl)) + 1;
       if (R)
         hipLaunchKernelGGL((gain_grad_kernel<T, true>), dim3(nb), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                            ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), n_parts,

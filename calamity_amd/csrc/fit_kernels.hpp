@@ -415,7 +415,9 @@ __global__ void coeff_partial_reduce_kernel(const T* __restrict__ gcp_r, const T
 }
 
 // ---- per-antenna segmented reduction of gbar_G (gradient of the gain gathers) + loss partial sums.
-// thread = (antenna a, channel f); the antenna's baselines are a sorted CSR list: entry = bl * 2 + role.
+// block = (antenna a, 64 * CPL channels); the antenna's baselines are a sorted CSR list (entry = bl * 2 + role, other
+// antenna) split into 4 segments, one per wave; lane = CPL adjacent channels (16-byte loads of gbar_G and of the other
+// antenna's gains); the 4 partial sums are combined through LDS in fixed order (bitwise reproducible, no float atomics).
 // grad g_a[f] = sum_{role 0} Q[bl][f] g_other[f] + sum_{role 1} conj(Q[bl][f]) g_other[f]
 template <typename T, bool REG>
 __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restrict__ q0, const vec2_t<T>* __restrict__ q1,
@@ -425,10 +427,11 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
                                                          int fpad, const double* __restrict__ part, int nitems,
                                                          double* __restrict__ scal, const DevState* st) {
   using T2 = vec2_t<T>;
+  constexpr int CPL = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;  // channels per lane: 2 (fp32), 1 (fp64)
+  typedef T vec_t __attribute__((ext_vector_type(2 * CPL)));
   if (st->done | st->done_after) return;
-  const int fblocks = fpad / 64;  // fpad is a multiple of 64? no: handled by the guard below
-  (void)fblocks;
-  const int nb_main = (nants * fpad + 255) / 256;
+  const int cblocks = (fpad + 64 * CPL - 1) / (64 * CPL);
+  const int nb_main = nants * cblocks;
   if ((int)blockIdx.x >= nb_main) {
     // last block: deterministic sum of the per-item loss partials -> scal[0..2]
     __shared__ double sh[3][256];
@@ -457,37 +460,85 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
     }
     return;
   }
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= nants * fpad) return;
-  const int a = idx / fpad;
-  const int f = idx - a * fpad;
-  T2 s0, s1, s2;
-  s0.x = s0.y = s1.x = s1.y = s2.x = s2.y = 0;
+  __shared__ T s_part[3][3][64][2 * CPL];  // [segment 1..3][sum 0..2][lane][components]
+  const int a = blockIdx.x / cblocks;
+  const int cb = blockIdx.x - a * cblocks;
+  const int lane = threadIdx.x & 63;
+  const int seg = threadIdx.x >> 6;
+  const int f = (cb * 64 + lane) * CPL;
+  const bool ok = f < fpad;  // fpad is a multiple of CPL
+  T s0[2 * CPL], s1[2 * CPL], s2[2 * CPL];
+#pragma unroll
+  for (int c = 0; c < 2 * CPL; ++c) s0[c] = s1[c] = s2[c] = 0;
   const int e0 = ant_ptr[a], e1 = ant_ptr[a + 1];
-  for (int e = e0; e < e1; ++e) {
-    const int2 ent = ant_ent[e];  // (bl * 2 + role, other antenna)
-    const int bl = ent.x >> 1;
-    const int role = ent.x & 1;
-    const T2 q = q0[(long long)bl * fpad + f];
-    const T2 go = gains[(long long)ent.y * fpad + f];
-    const T qi = role ? -q.y : q.y;
-    s0.x += q.x * go.x - qi * go.y;
-    s0.y += q.x * go.y + qi * go.x;
-    if (REG) {
-      const T2 p = q1[(long long)bl * fpad + f];
-      if (role == 0) {
-        s1.x += p.x * go.x - p.y * go.y;
-        s1.y += p.x * go.y + p.y * go.x;
-      } else {
-        s2.x += p.x * go.x + p.y * go.y;
-        s2.y += p.x * go.y - p.y * go.x;
+  const int per = (e1 - e0 + 3) >> 2;
+  const int eb = e0 + seg * per, ee = min(e1, eb + per);
+  if (ok) {
+#pragma unroll 4
+    for (int e = eb; e < ee; ++e) {
+      const int2 ent = ant_ent[e];  // (bl * 2 + role, other antenna): wave-uniform
+      const int bl = ent.x >> 1;
+      const int role = ent.x & 1;
+      const vec_t q = *reinterpret_cast<const vec_t*>(q0 + (long long)bl * fpad + f);
+      const vec_t go = *reinterpret_cast<const vec_t*>(gains + (long long)ent.y * fpad + f);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const T qr = q[2 * c], qi = role ? -q[2 * c + 1] : q[2 * c + 1];
+        s0[2 * c] += qr * go[2 * c] - qi * go[2 * c + 1];
+        s0[2 * c + 1] += qr * go[2 * c + 1] + qi * go[2 * c];
+      }
+      if (REG) {
+        const vec_t p = *reinterpret_cast<const vec_t*>(q1 + (long long)bl * fpad + f);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const T pr = p[2 * c], pi = p[2 * c + 1];
+          if (role == 0) {
+            s1[2 * c] += pr * go[2 * c] - pi * go[2 * c + 1];
+            s1[2 * c + 1] += pr * go[2 * c + 1] + pi * go[2 * c];
+          } else {
+            s2[2 * c] += pr * go[2 * c] + pi * go[2 * c + 1];
+            s2[2 * c + 1] += pr * go[2 * c + 1] - pi * go[2 * c];
+          }
+        }
       }
     }
   }
-  r0[idx] = s0;
-  if (REG) {
-    r1[idx] = s1;
-    r2[idx] = s2;
+  if (seg > 0) {
+#pragma unroll
+    for (int c = 0; c < 2 * CPL; ++c) {
+      s_part[seg - 1][0][lane][c] = s0[c];
+      if (REG) {
+        s_part[seg - 1][1][lane][c] = s1[c];
+        s_part[seg - 1][2][lane][c] = s2[c];
+      }
+    }
+  }
+  __syncthreads();
+  if (seg == 0 && ok) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+      for (int c = 0; c < 2 * CPL; ++c) {
+        s0[c] += s_part[g][0][lane][c];
+        if (REG) {
+          s1[c] += s_part[g][1][lane][c];
+          s2[c] += s_part[g][2][lane][c];
+        }
+      }
+    }
+    vec_t o0, o1, o2;
+#pragma unroll
+    for (int c = 0; c < 2 * CPL; ++c) {
+      o0[c] = s0[c];
+      o1[c] = s1[c];
+      o2[c] = s2[c];
+    }
+    const long long idx = (long long)a * fpad + f;
+    *reinterpret_cast<vec_t*>(r0 + idx) = o0;
+    if (REG) {
+      *reinterpret_cast<vec_t*>(r1 + idx) = o1;
+      *reinterpret_cast<vec_t*>(r2 + idx) = o2;
+    }
   }
 }
 
