@@ -393,6 +393,23 @@ __device__ long long g_ws_stamps[8][8][16][4];  // [block slot][wave][tick][stam
 constexpr int kSW = 36;  // LDS row stride of the V / gbar chunk buffers [channel][32 rows]: 16-B aligned rows, and 36 f mod 64
                          // walks the 16 bank quads, so ds_read/write_b128 by 16 consecutive channels are conflict-free
 
+
+// ---- hand-scheduled operand stream of the matrix waves.
+// hipcc places the s_waitcnt for a load in front of its first use, and around loop back-edges it falls back to draining the
+// queue (vmcnt(0)) -- measured: every 4-MFMA group then exposes a full L2 round trip (~500-900 cycles) and the matrix pipe
+// idles half of the time.  The basis operands are therefore requested with inline-asm loads the compiler does not track, a
+// fixed number of groups ahead (ring of kRing register quads), and consumed behind explicit counted waits.
+constexpr int kRing = 6;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ring_load(f32x4_t& dst, const f32x4_t* sbase, unsigned voff_bytes) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+#define RING_WAIT()                                                  \
+  do {                                                               \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 1) : "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  } while (0)
+
 template <bool GRAD>
 __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArgs A) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -469,54 +486,48 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
     const f32x4* akf4 = reinterpret_cast<const f32x4*>(A.a_kf4 + P.a_kf4);   // scalar bases
     const f32x4* afk4 = reinterpret_cast<const f32x4*>(A.a_fk4 + P.a_fk4);
     const f32x4* sc4 = reinterpret_cast<const f32x4*>(s_c);
+    const unsigned voff = (unsigned)lane * 16u;
+    f32x4 R0, R1, R2, R3, R4, R5;  // the operand ring (kRing = 6 register quads)
     for (int k = 0; k < nticks; ++k) {
       WS_STAMP(sblk, k, 0);
       if (k < nchunks) {
-        // ---- F(k): rows = (slot, re|im), columns = this wave's 32 channels, K = vectors.  One global_load_dwordx4 (basis, L2)
-        // and one ds_read_b128 (coefficients) feed four MFMAs; two register sets of 4 k-groups ping-pong.
+        // ---- F(k): rows = (slot, re|im), columns = this wave's 32 channels, K = vectors: item = k-group g (4 MFMAs)
         f32x16 acc, acc2;  // two accumulator chains
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = acc2[j] = 0.f;
-        const f32x4* tile = akf4 + ((size_t)(k * 4 + w4) * ngk) * 64;  // scalar; + 64 g (scalar) + lane
-        f32x4 xb[4], xa[4], yb[4], ya[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int g = u < ngk ? u : ngk - 1;
-          xb[u] = (tile + g * 64)[lane];
-          xa[u] = (sc4 + g * 64)[lane];
+        const f32x4* tile = akf4 + ((size_t)(k * 4 + w4) * ngk) * 64;  // scalar base; item g at + 64 g
+        auto src = [&](int g) { return tile + (g < ngk ? g : ngk - 1) * 64; };
+        ring_load(R0, src(0), voff);
+        ring_load(R1, src(1), voff);
+        ring_load(R2, src(2), voff);
+        ring_load(R3, src(3), voff);
+        ring_load(R4, src(4), voff);
+        ring_load(R5, src(5), voff);
+        f32x4 a_cur = (sc4 + 0)[lane], a_nxt;
+#define F_STEP(RJ, J)                                                                            \
+  {                                                                                              \
+    const int g = g0 + (J);                                                                      \
+    a_nxt = (sc4 + (g + 1 < ngk ? g + 1 : ngk - 1) * 64)[lane];                                  \
+    RING_WAIT();                                                                                 \
+    if (g < ngk) {                                                                               \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], RJ[0], acc, 0, 0, 0);                 \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], RJ[1], acc2, 0, 0, 0);               \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], RJ[2], acc, 0, 0, 0);                 \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], RJ[3], acc2, 0, 0, 0);               \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    ring_load(RJ, src(g + kRing), voff);                                                         \
+    a_cur = a_nxt;                                                                               \
+  }
+        for (int g0 = 0; g0 < ngk; g0 += kRing) {
+          F_STEP(R0, 0)
+          F_STEP(R1, 1)
+          F_STEP(R2, 2)
+          F_STEP(R3, 3)
+          F_STEP(R4, 4)
+          F_STEP(R5, 5)
         }
-        for (int g0 = 0; g0 < ngk; g0 += 8) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int g = g0 + 4 + u < ngk ? g0 + 4 + u : ngk - 1;
-            yb[u] = (tile + g * 64)[lane];
-            ya[u] = (sc4 + g * 64)[lane];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (g0 + u < ngk) {
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][0], xb[u][0], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][1], xb[u][1], acc2, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][2], xb[u][2], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][3], xb[u][3], acc2, 0, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int g = g0 + 8 + u < ngk ? g0 + 8 + u : ngk - 1;
-            xb[u] = (tile + g * 64)[lane];
-            xa[u] = (sc4 + g * 64)[lane];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (g0 + 4 + u < ngk) {
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u][0], yb[u][0], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u][1], yb[u][1], acc2, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u][2], yb[u][2], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u][3], yb[u][3], acc2, 0, 0, 0);
-            }
-          }
-        }
+#undef F_STEP
         // accumulator regs 4 q .. 4 q + 3 of this lane = rows 8 q + 4 half + 0..3 of column (channel) w4*32 + col
         f32x4* vout = reinterpret_cast<f32x4*>(s_v + (size_t)(k & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + 4 * half);
 #pragma unroll
@@ -531,49 +542,60 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
       }
       WS_STAMP(sblk, k, 1);
       if (GRAD && k >= 2 && t0 >= 0) {
-        // ---- B(k-2): rows = (slot, re|im), columns = vectors of tile t, K = this wave's slice of the chunk's channels
+        // ---- B(k-2): rows = (slot, re|im), columns = vectors of tile t, K = this wave's slice of the chunk's channels.
+        // item i = (channel group cg0 + i / ntl, tile i % ntl), ntl = 1 or 2 vector tiles per wave; 4 MFMAs per item
         const int ci = k - 2;
         const int ng_per = (kChunk / 8) / nkq;  // channel groups (8 channels = 4 k-steps) of this wave: 16, 8 or 4
-        const int cg0 = kq * ng_per, cg1 = cg0 + ng_per;
+        const int cg0 = kq * ng_per;
+        const int two = t1 >= 0 ? 1 : 0;
+        const int nitem = ng_per << two;
         const float* gp = s_g + (size_t)(ci & 1) * kChunk * kSW + half * kSW + col;       // + (8 cg + 2 v) kSW
-        const f32x4* bp0 = afk4 + ((size_t)(ci * (kChunk / 8)) * NT + t0) * 64;            // scalar; + cg NT 64 + lane
-        const f32x4* bp1 = afk4 + ((size_t)(ci * (kChunk / 8)) * NT + (t1 >= 0 ? t1 : t0)) * 64;
-        const size_t bstr = (size_t)NT * 64;
-        f32x4 xb0[2], xb1[2], yb0[2], yb1[2];
-        float xa[2][4], ya[2][4];
-        auto bload = [&](f32x4 (&b0)[2], f32x4 (&b1)[2], float (&a)[2][4], int cgb) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            b0[u] = (bp0 + (cgb + u) * bstr)[lane];
-            if (t1 >= 0) b1[u] = (bp1 + (cgb + u) * bstr)[lane];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) a[u][v] = gp[(8 * (cgb + u) + 2 * v) * kSW];
-          }
+        const f32x4* bp = afk4 + ((size_t)(ci * (kChunk / 8)) * NT) * 64;                  // scalar; + (cg NT + t) 64
+        auto src = [&](int i) {
+          i = i < nitem ? i : nitem - 1;
+          const int cg = cg0 + (i >> two), t = (i & two) ? t1 : t0;
+          return bp + ((size_t)cg * NT + t) * 64;
         };
-        auto bmma = [&](const f32x4 (&b0)[2], const f32x4 (&b1)[2], const float (&a)[2][4]) {
+        auto lds_a = [&](int i, float (&a)[4]) {
+          i = i < nitem ? i : nitem - 1;
+          const int cg = cg0 + (i >> two);
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (t1 >= 0) {
-#pragma unroll
-              for (int v = 0; v < 4; ++v) {
-                gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][v], b0[u][v], gacc0, 0, 0, 0);
-                gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][v], b1[u][v], gacc1, 0, 0, 0);
-              }
-            } else {  // single tile: gacc1 is a second, independent chain of the same tile (summed at the end)
-              gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][0], b0[u][0], gacc0, 0, 0, 0);
-              gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][1], b0[u][1], gacc1, 0, 0, 0);
-              gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][2], b0[u][2], gacc0, 0, 0, 0);
-              gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][3], b0[u][3], gacc1, 0, 0, 0);
-            }
-          }
+          for (int v = 0; v < 4; ++v) a[v] = gp[(8 * cg + 2 * v) * kSW];
         };
-        bload(xb0, xb1, xa, cg0);
-        for (int cg = cg0; cg < cg1; cg += 4) {
-          bload(yb0, yb1, ya, cg + 2);
-          bmma(xb0, xb1, xa);
-          bload(xb0, xb1, xa, cg + 4 < cg1 ? cg + 4 : cg);
-          bmma(yb0, yb1, ya);
+        ring_load(R0, src(0), voff);
+        ring_load(R1, src(1), voff);
+        ring_load(R2, src(2), voff);
+        ring_load(R3, src(3), voff);
+        ring_load(R4, src(4), voff);
+        ring_load(R5, src(5), voff);
+        float a_cur[4], a_nxt[4];
+        lds_a(0, a_cur);
+        // even items accumulate into gacc0, odd items into gacc1: with two tiles that is tile t0 / t1, with one tile two
+        // independent chains of the same tile (kRing is even, so the parity of an item is the parity of its ring slot)
+#define B_STEP(RJ, J, GACC)                                                                      \
+  {                                                                                              \
+    const int it = i0 + (J);                                                                     \
+    lds_a(it + 1, a_nxt);                                                                        \
+    RING_WAIT();                                                                                 \
+    if (it < nitem) {                                                                            \
+      GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], RJ[0], GACC, 0, 0, 0);               \
+      GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], RJ[1], GACC, 0, 0, 0);               \
+      GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], RJ[2], GACC, 0, 0, 0);               \
+      GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], RJ[3], GACC, 0, 0, 0);               \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    ring_load(RJ, src(it + kRing), voff);                                                        \
+    a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; a_cur[2] = a_nxt[2]; a_cur[3] = a_nxt[3];          \
+  }
+        for (int i0 = 0; i0 < nitem; i0 += kRing) {
+          B_STEP(R0, 0, gacc0)
+          B_STEP(R1, 1, gacc1)
+          B_STEP(R2, 2, gacc0)
+          B_STEP(R3, 3, gacc1)
+          B_STEP(R4, 4, gacc0)
+          B_STEP(R5, 5, gacc1)
         }
+#undef B_STEP
       }
       WS_STAMP(sblk, k, 2);
       __syncthreads();
@@ -582,6 +604,7 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
       if (sblk >= 0 && lane == 0 && (k == 0 || k == nticks - 1)) { g_ws_stamps[sblk][wave][k == 0 ? 14 : 15][0] = (long long)__builtin_amdgcn_s_memrealtime(); g_ws_stamps[sblk][wave][14][1] = nvec; g_ws_stamps[sblk][wave][14][2] = NT; g_ws_stamps[sblk][wave][14][3] = t0 * 100 + t1 * 10 + nkq; }
 #endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the ring's trailing (discarded) requests
     if (!GRAD) return;
     if (t1 < 0) {
 #pragma unroll
