@@ -137,9 +137,9 @@ struct SolverT final : cal_solver {
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
-  DevBuf mf_akf, mf_afk, mf_akf4, mf_afk4, mf_panels, mf_bl_coff;
+  DevBuf mf_akf4, mf_afk4, mf_panels, mf_bl_coff;
   int mf_npanels = 0;
-  size_t mf_lds = 0, mf_ws_lds = 0;
+  size_t mf_ws_lds = 0;
   bool mf_ok = false, mf_ws = true;
   DevState* h_state = nullptr;                 // pinned mirror
   // settings
@@ -300,15 +300,12 @@ struct SolverT final : cal_solver {
     mf_ok = false;
     if (want_mfma) {
       if constexpr (std::is_same<T, float>::value) {
-        std::vector<long long> okf(nbasis + 1, 0), ofk(nbasis + 1, 0), okf4(nbasis + 1, 0), ofk4(nbasis + 1, 0);
+        std::vector<long long> okf4(nbasis + 1, 0), ofk4(nbasis + 1, 0);
         std::vector<int> nvp2(nbasis), nvp32(nbasis);
-        int nvp2_max = 0, nvec_max = 0;
+        int nvec_max = 0;
         for (int u = 0; u < nbasis; ++u) {
           nvp2[u] = (d->basis_nvec[u] + 15) / 16 * 16;
           nvp32[u] = (d->basis_nvec[u] + 31) / 32 * 32;
-          nvp2_max = std::max(nvp2_max, nvp2[u]);
-          okf[u + 1] = okf[u] + (long long)fpad * nvp2[u];
-          ofk[u + 1] = ofk[u] + (long long)fpad * nvp32[u];
           nvec_max = std::max(nvec_max, d->basis_nvec[u]);
           okf4[u + 1] = okf4[u] + (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256;
           ofk4[u + 1] = ofk4[u] + (long long)(fpad / 8) * (nvp32[u] / 32) * 256;
@@ -319,12 +316,6 @@ struct SolverT final : cal_solver {
           hipLaunchKernelGGL(mfma_pack_kernel, dim3(grid_for(okf4[u + 1] - okf4[u] + ofk4[u + 1] - ofk4[u])), dim3(256), 0, stream,
                              raw.as<float>() + d->basis_offset[u], mf_akf4.as<float>() + okf4[u], mf_afk4.as<float>() + ofk4[u], nfreqs, fpad,
                              d->basis_nvec[u], nvp32[u]);
-        CAL_TRY(mf_akf.alloc((size_t)okf[nbasis] * sizeof(float), false));
-        CAL_TRY(mf_afk.alloc((size_t)ofk[nbasis] * sizeof(float), false));
-        for (int u = 0; u < nbasis; ++u)
-          hipLaunchKernelGGL(mfma_layout_kernel, dim3(grid_for((long long)fpad * (nvp2[u] + nvp32[u]))), dim3(256), 0, stream,
-                             raw.as<float>() + d->basis_offset[u], mf_akf.as<float>() + okf[u], mf_afk.as<float>() + ofk[u], nfreqs, fpad,
-                             d->basis_nvec[u], nvp2[u], nvp32[u]);
         HIP_TRY(hipGetLastError());
         // panels of kPanel baselines with the same basis, heaviest first
         std::vector<std::vector<int>> by_u(nbasis);
@@ -349,8 +340,6 @@ struct SolverT final : cal_solver {
           for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
             PanelItem pi{};
             for (int k = 0; k < kPanel; ++k) pi.bl[k] = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
-            pi.a_kf = okf[u];
-            pi.a_fk = ofk[u];
             pi.a_kf4 = okf4[u];
             pi.a_fk4 = ofk4[u];
             pi.nvec = d->basis_nvec[u];
@@ -378,7 +367,6 @@ struct SolverT final : cal_solver {
         CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
         HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        mf_lds = mfma_lds_bytes(nvp2_max);
         mf_ws_lds = mfma_ws_lds_bytes(nvec_max);
         mf_ws = !getenv("CALAMITY_HIP_MFMA_NO_WS");
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_mfma_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_ws_lds));
@@ -724,12 +712,13 @@ struct SolverT final : cal_solver {
       ++ev_used;
       HIP_TRY(hipEventRecord(e0, stream));
     }
-    const bool use_mfma = mf_ok && !R;
+    // dense path; with the "sum" regulariser it runs twice: a loss-only pass yields S (hence alpha = 2 (S - P)), then the
+    // gradient pass applies e = -2 w r + alpha w directly -- no second adjoint set, no combine kernels
+    const bool use_mfma = mf_ok && mf_ws;
+    const bool two_pass = use_mfma && R && grads;
     if (use_mfma) {
       if constexpr (std::is_same<T, float>::value) {
         MfmaArgs m{};
-        m.a_kf = mf_akf.as<float>();
-        m.a_fk = mf_afk.as<float>();
         m.a_kf4 = mf_akf4.as<float>();
         m.a_fk4 = mf_afk4.as<float>();
         m.panels = mf_panels.as<PanelItem>();
@@ -748,20 +737,25 @@ struct SolverT final : cal_solver {
         m.state = st;
         m.fpad = fpad;
         m.nbls = nbls;
-        if (mf_ws) {
-          if (grads)
-            hipLaunchKernelGGL(fused_mfma_ws_kernel<true>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
-          else
-            hipLaunchKernelGGL(fused_mfma_ws_kernel<false>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
-        } else if (grads) {
-          hipLaunchKernelGGL(fused_mfma_kernel<true>, dim3(mf_npanels), dim3(256), mf_lds, stream, m);
-        } else {
-          hipLaunchKernelGGL(fused_mfma_kernel<false>, dim3(mf_npanels), dim3(256), mf_lds, stream, m);
+        m.use_alpha = 0;
+        if (two_pass) {
+          hipLaunchKernelGGL(fused_mfma_ws_kernel<false>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
+          hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
+                             ant_ptr.as<int>(), ant_ent.as<int2>(), comm.as<T2>(), comm.as<T2>(), comm.as<T2>(), 0, fpad, part.as<double>(),
+                             mf_npanels, scal.as<double>(), st);
+          if (nccl) NCCL_TRY(ncclAllReduce(scal.p, scal.p, 4, ncclDouble, ncclSum, nccl, stream));
+          hipLaunchKernelGGL(alpha_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>());
+          m.use_alpha = 1;
         }
+        if (grads)
+          hipLaunchKernelGGL(fused_mfma_ws_kernel<true>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
+        else
+          hipLaunchKernelGGL(fused_mfma_ws_kernel<false>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
       }
     } else {
       if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
     }
+    const bool Rk = R && !use_mfma;  // the general kernel's two-adjoint-set form of the regulariser
     const int n_parts = use_mfma ? mf_npanels : nitems;
     if (timing) HIP_TRY(hipEventRecord(e1, stream));
     const size_t gn = (size_t)nants * fpad;
@@ -773,14 +767,14 @@ struct SolverT final : cal_solver {
         hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
                            gcp0.as<T>() + gcp_len, gc0.as<T>(), gc0.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
                            grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
-        if (R)
+        if (Rk)
           hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp1.as<T>(),
                              gcp1.as<T>() + gcp_len, gc1.as<T>(), gc1.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
                              grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
       }
       const int cpl = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;
       const int nb = nants * ((fpad + 64 * cpl - 1) / (64 * cpl)) + 1;
-      if (R)
+      if (Rk)
         hipLaunchKernelGGL((gain_grad_kernel<T, true>), dim3(nb), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                            ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), n_parts,
                            scal.as<double>(), st);
@@ -798,13 +792,13 @@ struct SolverT final : cal_solver {
       // (issued for a 1-rank communicator too, so the path can be exercised on a single GPU)
       NCCL_TRY(ncclGroupStart());
       if (grads)
-        NCCL_TRY(ncclAllReduce(r0, r0, (R ? 3 : 1) * gn * 2, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, nccl, stream));
+        NCCL_TRY(ncclAllReduce(r0, r0, (Rk ? 3 : 1) * gn * 2, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, nccl, stream));
       NCCL_TRY(ncclAllReduce(scal.p, scal.p, 4, ncclDouble, ncclSum, nccl, stream));
       NCCL_TRY(ncclGroupEnd());
     }
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>(), losses.as<double>(), losses_cap,
                        apply_update ? 1 : 0);
-    if (grads && R) {
+    if (grads && Rk) {
       hipLaunchKernelGGL(combine_gain_kernel<T>, dim3((int)((gn + 255) / 256)), dim3(256), 0, stream, r0, r1, r2, (int)gn, st);
       hipLaunchKernelGGL(combine_coeff_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, grad_c0(), grad_c0() + ncoef,
                          grad_c1(), grad_c1() + ncoef, ncoef, st);

@@ -588,6 +588,14 @@ __global__ void finalize_kernel(DevState* st, const double* __restrict__ scal, d
   }
 }
 
+// ---- "sum" regulariser, two-pass form (dense path): alpha = 2 (S - P) from the reduced sums of a loss-only pass
+__global__ void alpha_kernel(DevState* st, const double* __restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->done | st->done_after) return;
+  st->alpha_r = 2.0 * (scal[1] - st->prior_r);
+  st->alpha_i = 2.0 * (scal[2] - st->prior_i);
+}
+
 // ---- "sum" regulariser: fold the alpha-weighted parts into the gradients once alpha is known
 template <typename T>
 __global__ void combine_gain_kernel(vec2_t<T>* __restrict__ r0, const vec2_t<T>* __restrict__ r1,

@@ -15,16 +15,6 @@
 #pragma once
 #include "fit_kernels.hpp"
 
-#ifndef CAL_MF_FWD_PP
-#define CAL_MF_FWD_PP 1
-#endif
-#ifndef CAL_MF_BWD_PP
-#define CAL_MF_BWD_PP 1
-#endif
-#ifndef CAL_MF_DEFER_Q
-#define CAL_MF_DEFER_Q 1
-#endif
-
 namespace calk {
 
 constexpr int kPanel = 16;        // baselines per panel
@@ -35,8 +25,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct PanelItem {
   int bl[kPanel];     // baseline ids (-1: padding slot)
-  long long a_kf;     // element offset of the block in the [F/32][nvp2][32] copy  (forward B operand)
-  long long a_fk;     // element offset of the block in the [F][nvp32] copy        (adjoint B operand)
   int nvec, nvp2, nvp32;
   int pad;
   long long a_kf4;    // packed forward operand  [F/32][nvp8/8][64 lanes][4]: lane (col, half), u -> A[32 fb + col][8 g + 2 u + half]
@@ -44,8 +32,6 @@ struct PanelItem {
 };
 
 struct MfmaArgs {
-  const float* a_kf;
-  const float* a_fk;
   const float* a_kf4;
   const float* a_fk4;
   const PanelItem* panels;
@@ -63,312 +49,12 @@ struct MfmaArgs {
   double* part;                // [npanels][4]
   const DevState* state;
   int fpad;
+  int use_alpha;               // "sum" regulariser, second pass: e = -2 w r + alpha w with alpha = 2 (S - P) read from state
   int nbls;                    // row nbls of data_r / data_i / wgts / q0 is an all-zero spare row for padding slots
 };
 
-constexpr int kSC = 33;  // LDS row stride of the coefficient panel  [k][32 rows]
-constexpr int kSG = 33;  // LDS row stride of the gbar chunk         [f][32 rows]
-
-template <bool GRAD>
-__global__ __launch_bounds__(256) void fused_mfma_kernel(const MfmaArgs A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (A.state->done | A.state->done_after) return;
-  // XCD-aware block -> panel map (see the host): the 8 XCDs each walk their own contiguous list of panels
-  const int per_xcd = gridDim.x >> 3;
-  const PanelItem& P = A.panels[(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)];
-  if (P.nvec == 0) {  // padding panel of a short XCD list
-    if (threadIdx.x == 0) A.part[(size_t)blockIdx.x * 4] = A.part[(size_t)blockIdx.x * 4 + 1] = A.part[(size_t)blockIdx.x * 4 + 2] = 0.0;
-    return;
-  }
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int col = lane & 31;   // MFMA column
-  const int half = lane >> 5;
-  const int nvec = P.nvec, nvp2 = P.nvp2, nvp32 = P.nvp32;  // nvp2: vectors padded to a multiple of 16 (forward K)
-  const int NT = nvp32 / 32;
-
-  float* s_c = reinterpret_cast<float*>(smem_raw);   // [nvp2][kSC]: rows 0-15 re, 16-31 im of the panel's coefficients
-  float* s_g = s_c + (size_t)nvp2 * kSC;             // [kChunk][kSG]: gbar_v chunk, same row convention
-  int* s_bl = reinterpret_cast<int*>(s_g + (size_t)kChunk * kSG);  // [16] baseline ids, [16] ant0, [16] ant1
-  double* s_red = reinterpret_cast<double*>(s_bl + 48);            // [4] loss partials
-
-  if (tid < kPanel) {
-    const int b = P.bl[tid];
-    s_bl[tid] = b;
-    const int2 ant = b >= 0 ? A.bl_ant[b] : make_int2(0, 0);
-    s_bl[16 + tid] = ant.x;
-    s_bl[32 + tid] = ant.y;
-  }
-  // coefficient panel: thread (slot = tid / 16, k = tid % 16 + 16 m); padding slots and k >= nvec are zero
-  {
-    const int slot = tid >> 4;
-    const int b = P.bl[slot];
-    const int coff = b >= 0 ? A.bl_coff[b] : 0;
-    for (int k = tid & 15; k < nvp2; k += 16) {
-      const bool ok = b >= 0 && k < nvec;
-      s_c[k * kSC + slot] = ok ? A.c_r[coff + k] : 0.f;
-      s_c[k * kSC + 16 + slot] = ok ? A.c_i[coff + k] : 0.f;
-    }
-  }
-  __syncthreads();
-
-  // adjoint role of this wave: tile(s) of 32 vectors and the slice of the chunk's K range it sums
-  int t0, t1 = -1, kq = 0, nkq = 1;
-  if (NT == 1) { t0 = 0; kq = wave; nkq = 4; }
-  else if (NT == 2) { t0 = wave & 1; kq = wave >> 1; nkq = 2; }
-  else if (NT <= 4) { t0 = wave < NT ? wave : -1; }
-  else { t0 = wave; t1 = wave + 4 < NT ? wave + 4 : -1; }
-  f32x16 gacc0, gacc1;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) gacc0[j] = gacc1[j] = 0.f;
-  double loss_acc = 0.0;
-
-  const float* akf = A.a_kf + P.a_kf;
-  const float* afk = A.a_fk + P.a_fk;
-  const int nchunks = A.fpad / kChunk;
-
-  // per-lane inputs of the element-wise stage for one chunk: 8 panel slots x (d_r, d_i, w, g0, g1), all requested at once;
-  // padding slots read baseline 0 and are masked by w = 0.
-  float e_dr[8], e_di[8], e_w[8];
-  float2 e_g0[8], e_g1[8];
-  int ob[8];  // element offset of (slot's baseline, this lane's channel of chunk 0); host guarantees nbls * fpad < 2^31
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int b = s_bl[(j & 3) + 8 * (j >> 2) + 4 * half];
-    ob[j] = (b >= 0 ? b : 0) * A.fpad + wave * 32 + col;
-  }
-  auto prefetch_elem = [&](int ci) {
-    const int f = ci * kChunk + wave * 32 + col;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
-      const int b = s_bl[slot];
-      const int o = ob[j] + ci * kChunk;
-      e_dr[j] = A.data_r[o];
-      e_di[j] = A.data_i[o];
-      const float w = A.wgts[o];
-      e_w[j] = b >= 0 ? w : 0.f;
-      e_g0[j] = A.gains[(long long)s_bl[16 + slot] * A.fpad + f];
-      e_g1[j] = A.gains[(long long)s_bl[32 + slot] * A.fpad + f];
-    }
-  };
-  float2 q[8];  // gbar_G of the previous chunk, stored one chunk late (see below)
-
-  for (int ci = 0; ci < nchunks; ++ci) {
-    // ---- forward: this wave's 32 channels; rows = (baseline, re|im); K = vectors.  Operands are fetched one batch of
-    // four k-steps ahead of the MFMAs that consume them.
-    f32x16 acc;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    {
-      const float* tile = akf + (size_t)(ci * 4 + wave) * nvp2 * 32 + lane;  // + 64 s per k-step
-      const float* cp = s_c + half * kSC + col;                               // + 2 kSC s per k-step
-      const int nks = nvp2 >> 1;  // multiple of 8: two register sets of four k-steps ping-pong, no copies between them
-#if CAL_MF_FWD_PP
-      float b0[4], a0[4], b1[4], a1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        b0[u] = tile[u * 64];
-        a0[u] = cp[u * 2 * kSC];
-      }
-      for (int s = 0; s < nks; s += 8) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          b1[u] = tile[(s + 4 + u) * 64];
-          a1[u] = cp[(s + 4 + u) * 2 * kSC];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
-        const int sn = s + 8 < nks ? s + 8 : s;  // the last prefetch re-reads a valid batch (discarded)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          b0[u] = tile[(sn + u) * 64];
-          a0[u] = cp[(sn + u) * 2 * kSC];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
-      }
-#else
-      for (int s = 0; s < nks; s += 4) {
-        float b[4], a[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          b[u] = tile[(s + u) * 64];
-          a[u] = cp[(s + u) * 2 * kSC];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
-      }
-#endif
-    }
-    // A wave's vector-memory operations retire in issue order, so slow HBM loads must never sit in front of the L2-served
-    // operand loads of an MFMA loop.  Hence: the previous chunk's gbar_G stores and this chunk's data / weights / gains loads
-    // are issued together HERE, after the forward loop; the stores' acknowledgement hides under the loads' latency and the
-    // other resident waves of the SIMD keep the matrix pipe busy meanwhile.
-    if (CAL_MF_DEFER_Q && GRAD && ci > 0) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
-        if (s_bl[slot] >= 0) A.q0[ob[j] + (ci - 1) * kChunk] = q[j];
-      }
-    }
-    prefetch_elem(ci);
-    // ---- element-wise in the accumulator layout: reg j <-> panel slot (j&3) + 8 (j>>2) + 4 half ; re = acc[j], im = acc[j+8]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
-      const float d_r = e_dr[j], d_i = e_di[j], w = e_w[j];
-      const float2 g0 = e_g0[j], g1 = e_g1[j];
-      const float vr = acc[j], vi = acc[j + 8];
-      const float G_r = g0.x * g1.x + g0.y * g1.y;
-      const float G_i = g0.y * g1.x - g0.x * g1.y;
-      const float m_r = G_r * vr - G_i * vi;
-      const float m_i = G_i * vr + G_r * vi;
-      const float r_r = d_r - m_r, r_i = d_i - m_i;
-      loss_acc += (double)(w * (r_r * r_r + r_i * r_i));
-      if (GRAD) {
-        const float e_r = -2.f * w * r_r, e_i = -2.f * w * r_i;
-        q[j].x = vr * e_r + vi * e_i;
-        q[j].y = vr * e_i - vi * e_r;
-        const int fl = wave * 32 + col;
-        s_g[fl * kSG + slot] = G_r * e_r + G_i * e_i;
-        s_g[fl * kSG + 16 + slot] = G_r * e_i - G_i * e_r;
-      }
-    }
-    if (!CAL_MF_DEFER_Q && GRAD) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
-        if (s_bl[slot] >= 0) A.q0[ob[j] + ci * kChunk] = q[j];
-      }
-    }
-    if (GRAD) {
-      __syncthreads();
-      // ---- adjoint: rows = (baseline, re|im), columns = vectors of tile t, K = this wave's slice of the chunk's channels
-      const int ks_per = (kChunk / 2) / nkq;  // k-steps (2 channels each) of this wave; multiple of 4
-      const int ks0 = kq * ks_per;
-      if (t0 >= 0) {
-        const float* gp = s_g + half * kSG + col;                                                       // + 2 kSG s
-        const float* bp0 = afk + (size_t)(ci * kChunk + half) * nvp32 + t0 * 32 + col;                   // + 2 nvp32 s
-        const float* bp1 = afk + (size_t)(ci * kChunk + half) * nvp32 + (t1 >= 0 ? t1 : t0) * 32 + col;
-        const size_t bstr = 2 * (size_t)nvp32;
-#if CAL_MF_BWD_PP
-        // two register sets of four k-steps ping-pong (ks_per is a multiple of 8)
-        float xa[4], xb0[4], xb1[4], ya[4], yb0[4], yb1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          xa[u] = gp[(ks0 + u) * 2 * kSG];
-          xb0[u] = bp0[(ks0 + u) * bstr];
-          xb1[u] = bp1[(ks0 + u) * bstr];
-        }
-        const int ks1 = ks0 + ks_per;
-        for (int s = ks0; s < ks1; s += 8) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            ya[u] = gp[(s + 4 + u) * 2 * kSG];
-            yb0[u] = bp0[(s + 4 + u) * bstr];
-            yb1[u] = bp1[(s + 4 + u) * bstr];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u], xb0[u], gacc0, 0, 0, 0);
-            if (t1 >= 0) gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u], xb1[u], gacc1, 0, 0, 0);
-          }
-          const int sn = s + 8 < ks1 ? s + 8 : s;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            xa[u] = gp[(sn + u) * 2 * kSG];
-            xb0[u] = bp0[(sn + u) * bstr];
-            xb1[u] = bp1[(sn + u) * bstr];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], yb0[u], gacc0, 0, 0, 0);
-            if (t1 >= 0) gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[u], yb1[u], gacc1, 0, 0, 0);
-          }
-        }
-#else
-        for (int s = ks0; s < ks0 + ks_per; s += 4) {
-          float a[4], b0[4], b1[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            a[u] = gp[(s + u) * 2 * kSG];
-            b0[u] = bp0[(s + u) * bstr];
-            if (t1 >= 0) b1[u] = bp1[(s + u) * bstr];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            gacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[u], gacc0, 0, 0, 0);
-            if (t1 >= 0) gacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b1[u], gacc1, 0, 0, 0);
-          }
-        }
-#endif
-      }
-      __syncthreads();  // gbar chunk consumed before the next chunk overwrites it
-    }
-  }
-
-  if (CAL_MF_DEFER_Q && GRAD) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
-      if (s_bl[slot] >= 0) A.q0[ob[j] + (nchunks - 1) * kChunk] = q[j];
-    }
-  }
-  // ---- loss partial of the panel
-  {
-    const double l = ldsum(loss_acc);
-    if (lane == 0) s_red[wave] = l;
-    __syncthreads();
-    if (tid == 0) {
-      A.part[(size_t)blockIdx.x * 4 + 0] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-      A.part[(size_t)blockIdx.x * 4 + 1] = 0.0;
-      A.part[(size_t)blockIdx.x * 4 + 2] = 0.0;
-    }
-  }
-  if (!GRAD) return;
-  // ---- coefficient gradients: sum the K-slices of different waves (through LDS, reusing the gbar region), then store
-  if (nkq > 1) {
-    float* s_x = s_g;  // [wave][16 regs][64 lanes]
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s_x[(wave * 16 + j) * 64 + lane] = gacc0[j];
-    __syncthreads();
-    if (kq == 0) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float v = gacc0[j];
-        for (int q = 1; q < nkq; ++q) v += s_x[((wave + q * (NT == 1 ? 1 : 2)) * 16 + j) * 64 + lane];
-        gacc0[j] = v;
-      }
-    }
-  }
-  if (kq == 0 && t0 >= 0) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = tt == 0 ? t0 : t1;
-      if (t < 0) continue;
-      const int n = t * 32 + col;
-      if (n < nvec) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
-          const int b = s_bl[slot];
-          if (b >= 0) {
-            const int coff = A.bl_coff[b];
-            A.gc_r[coff + n] = tt == 0 ? gacc0[j] : gacc1[j];
-            A.gc_i[coff + n] = tt == 0 ? gacc0[j + 8] : gacc1[j + 8];
-          }
-        }
-      }
-    }
-  }
-}
-
-
 // ----------------------------------------------------------------------------------------------------------------
-// Wave-specialised version (the one that ships).  A wave's vector-memory operations retire in issue order, so a wave
+// Wave specialisation.  A wave's vector-memory operations retire in issue order, so a wave
 // that mixes L2-served MFMA operand loads with HBM loads (data, weights) stalls its matrix pipe on the slow ones.
 // Here a 512-thread workgroup has 4 MATRIX waves (waves 0-3: forward GEMM, adjoint GEMM; they only ever load basis
 // operands, which live in L2) and 4 ELEMENT waves (waves 4-7, one per SIMD beside a matrix wave: HBM loads of data /
@@ -438,7 +124,7 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
   float* s_v = s_c + (size_t)ngk * 256;                     // [2][kChunk][kSW]  model visibilities, rows = (slot, re|im)
   float* s_g = s_v + 2 * (size_t)kChunk * kSW;              // [2][kChunk][kSW]  gbar_v
   int* s_bl = reinterpret_cast<int*>(s_g + 2 * (size_t)kChunk * kSW);  // [16] baseline, [16] ant0, [16] ant1
-  double* s_red = reinterpret_cast<double*>(s_bl + 48);     // [4]
+  double* s_red = reinterpret_cast<double*>(s_bl + 48);     // [12]: loss, S_r, S_i partials of the 4 element waves
 
   if (tid < kPanel) {
     const int b = P.bl[tid];
@@ -677,12 +363,13 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
         E.g1[j] = gn[og1[j]];
       }
     };
-    double loss_acc = 0.0;
+    double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
+    const float al_r = A.use_alpha ? (float)A.state->alpha_r : 0.f, al_i = A.use_alpha ? (float)A.state->alpha_i : 0.f;
     auto process = [&](int ci, const ElemIn& E) {
       const f32x4* vin = reinterpret_cast<const f32x4*>(s_v + (size_t)(ci & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + half * 8);
       f32x4* gout = reinterpret_cast<f32x4*>(s_g + (size_t)(ci & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + half * 8);
       float2* qo = A.q0 + ci * kChunk;
-      float lt = 0.f;
+      float lt = 0.f, st_r = 0.f, st_i = 0.f;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const f32x4 vr4 = vin[h], vi4 = vin[4 + h];  // rows half*8 + 4 h + 0..3 (re) and +16 (im)
@@ -699,8 +386,10 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
           const float m_i = G_i * vr + G_r * vi;
           const float r_r = d_r - m_r, r_i = d_i - m_i;
           lt += w * (r_r * r_r + r_i * r_i);
+          st_r += w * m_r;  // S = sum w m of the "sum" regulariser (calibration.py:1648-1649)
+          st_i += w * m_i;
           if (GRAD) {
-            const float e_r = -2.f * w * r_r, e_i = -2.f * w * r_i;
+            const float e_r = -2.f * w * r_r + al_r * w, e_i = -2.f * w * r_i + al_i * w;
             gr4[u] = G_r * e_r + G_i * e_i;
             gi4[u] = G_r * e_i - G_i * e_r;
             float2 q;
@@ -715,6 +404,8 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
         }
       }
       loss_acc += (double)lt;
+      sr_acc += (double)st_r;
+      si_acc += (double)st_i;
     };
     request(0, X);
     if (nchunks > 1) request(1, Y);
@@ -746,28 +437,27 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
       }
     }
     {
-      const double l = ldsum(loss_acc);
-      if (lane == 0) s_red[w4] = l;
+      const double l = ldsum(loss_acc), sr = ldsum(sr_acc), si = ldsum(si_acc);
+      if (lane == 0) {
+        s_red[w4] = l;
+        s_red[4 + w4] = sr;
+        s_red[8 + w4] = si;
+      }
     }
     __syncthreads();  // GRAD: pairs with the matrix waves' epilogue barrier; otherwise the matrix waves have exited and only
                       // the element waves are counted (ended waves leave the barrier)
     if (wave == 4 && lane == 0) {
       A.part[(size_t)blockIdx.x * 4 + 0] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-      A.part[(size_t)blockIdx.x * 4 + 1] = 0.0;
-      A.part[(size_t)blockIdx.x * 4 + 2] = 0.0;
+      A.part[(size_t)blockIdx.x * 4 + 1] = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+      A.part[(size_t)blockIdx.x * 4 + 2] = s_red[8] + s_red[9] + s_red[10] + s_red[11];
     }
   }
 }
 
 inline size_t mfma_ws_lds_bytes(int nvec_max) {
-  return ((size_t)((nvec_max + 7) / 8) * 256 + 4 * (size_t)kChunk * kSW) * sizeof(float) + 48 * sizeof(int) + 4 * sizeof(double) + 64;
+  return ((size_t)((nvec_max + 7) / 8) * 256 + 4 * (size_t)kChunk * kSW) * sizeof(float) + 48 * sizeof(int) + 12 * sizeof(double) + 64;
 }
 
-inline size_t mfma_lds_bytes(int nvp2_max) {
-  return ((size_t)nvp2_max * kSC + (size_t)kChunk * kSG) * sizeof(float) + 48 * sizeof(int) + 4 * sizeof(double) + 64;
-}
-
-// unique basis block (row-major [F][nvec]) -> the two operand layouts (zero padded)
 // packed MFMA-native operand layouts of the wave-specialised kernel (see PanelItem)
 __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ a_kf4, float* __restrict__ a_fk4, int nfreqs, int fpad,
                                  int nvec, int nvp32) {
@@ -787,26 +477,6 @@ __global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restric
       const int t = (int)(r % NT), cg = (int)(r / NT);
       const int f = 8 * cg + 2 * u + (l >> 5), n = 32 * t + (l & 31);
       a_fk4[q] = (f < nfreqs && n < nvec) ? src[(long long)f * nvec + n] : 0.f;
-    }
-  }
-}
-
-__global__ void mfma_layout_kernel(const float* __restrict__ src, float* __restrict__ a_kf, float* __restrict__ a_fk, int nfreqs,
-                                   int fpad, int nvec, int nvp2, int nvp32) {
-  const long long n1 = (long long)fpad * nvp2, n2 = (long long)fpad * nvp32;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * blockDim.x) {
-    if (i < n1) {
-      const int fl = (int)(i % 32);
-      const long long r = i / 32;
-      const int k = (int)(r % nvp2);
-      const int fb = (int)(r / nvp2);
-      const int f = fb * 32 + fl;
-      a_kf[i] = (f < nfreqs && k < nvec) ? src[(long long)f * nvec + k] : 0.f;
-    } else {
-      const long long q = i - n1;
-      const int n = (int)(q % nvp32);
-      const int f = (int)(q / nvp32);
-      a_fk[q] = (f < nfreqs && n < nvec) ? src[(long long)f * nvec + n] : 0.f;
     }
   }
 }

@@ -100,6 +100,27 @@ def test_short_trajectory(dtype, optimizer, reg):
     assert relnorm(c_i, problem.coeffs_from_chunks(p, out[3])) <= tol["traj"]
 
 
+@pytest.mark.parametrize("reg", [False, True])
+def test_short_trajectory_dense_path(reg):
+    """fp32 + SHARED layout + one baseline per group -> the MFMA path (two passes per step with the "sum" regulariser)."""
+    p, start = make_case(seed=6, nants=12, nfreqs=200, with_sky=reg, perturb=False)
+    ch, fg_r, fg_i = oracle_inputs(p, start)
+    out = R.fit_gains_and_foregrounds(
+        start["g_r"], start["g_i"], fg_r, fg_i, ch["data_r"], ch["data_i"], ch["wgts"], ch["fg_comps"], ch["corr_inds"],
+        maxsteps=30, optimizer="Adam", learning_rate=1e-2, sky_model_r=ch["sky_model_r"], sky_model_i=ch["sky_model_i"],
+        model_regularization="sum" if reg else None,
+    )
+    s = make_solver(p, start, np.float32, "shared", reg)
+    s.set_optimizer("Adam", learning_rate=1e-2)
+    s.run(1, record=False)
+    losses, stopped, nupd = s.run(30, record=True, tol=1e-14)
+    tol = TOL[np.float32]
+    np.testing.assert_allclose(losses, np.asarray(out[4]["loss"], dtype=np.float64), rtol=tol["traj"])
+    g_r, g_i, c_r, c_i = s.get_params()
+    assert relnorm(g_r.astype(np.float64) + 1j * g_i, out[0] + 1j * out[1]) <= tol["traj"]
+    assert relnorm(c_r, problem.coeffs_from_chunks(p, out[2])) <= tol["traj"]
+
+
 def test_loop_controls_tol_usemin_freeze():
     p, start = make_case(seed=7, perturb=False)
     ch, fg_r, fg_i = oracle_inputs(p, start)
