@@ -1,0 +1,130 @@
+"""Full-size GPU checks at the BASELINE.json configurations.
+
+The padded NumPy oracle is only affordable up to HERA-37 x 1024 channels; at HERA-350 the checks are size-independent
+properties: the two basis layouts and the two kernel families (general VALU kernel / MFMA kernel) must agree, the
+analytic gradient must match a central finite difference of the loss along a random direction, the foreground model
+is linear in the coefficients, and coefficients -> model -> least-squares initialisation is a round trip on an
+orthonormal basis (calibration.py:828-913 with no flags).
+"""
+import numpy as np
+import pytest
+
+from calamity_amd import problem, synthetic
+from oracle import ref_numpy as R
+
+pytestmark = pytest.mark.gpu
+
+
+def relnorm(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def solver_for(p, start, dtype, layout):
+    from calamity_amd.solver import HipFitSolver
+
+    s = HipFitSolver(dtype=dtype)
+    s.set_problem(p, layout=layout)
+    s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    return s
+
+
+def perturbed(p, start, seed):
+    rng = np.random.default_rng(seed)
+    out = dict(start)
+    out["g_r"] = 1.0 + 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+    out["g_i"] = 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+    return out
+
+
+def test_hera37_full_size_against_oracle():
+    """BASELINE config 1 (HERA-37 hex, 1024 channels, fp64): loss and every gradient against the padded oracle."""
+    p, truth, start = synthetic.make_config("hera37")
+    start = perturbed(p, start, 1)
+    ch = problem.chunks_from_problem(p)
+    fg_r = problem.coeffs_to_chunks(p, start["c_r"], np.float64)
+    fg_i = problem.coeffs_to_chunks(p, start["c_i"], np.float64)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    loss, gg_r, gg_i, gf_r, gf_i = R.loss_and_grads(start["g_r"], start["g_i"], fg_r, fg_i, ch["fg_comps"], ch["data_r"], ch["data_i"], ch["wgts"], a0, a1)
+    for layout in ("stream", "shared"):
+        s = solver_for(p, start, np.float64, layout)
+        l2, hg_r, hg_i, hc_r, hc_i = s.eval_grads()
+        assert abs(l2 - loss) <= 1e-10 * abs(loss)
+        assert relnorm(hg_r, gg_r) <= 1e-10 and relnorm(hg_i, gg_i) <= 1e-10
+        assert relnorm(hc_r, problem.coeffs_from_chunks(p, gf_r)) <= 1e-10
+        assert relnorm(hc_i, problem.coeffs_from_chunks(p, gf_i)) <= 1e-10
+        s.close()
+    # fp32, both kernel families, against the same oracle numbers
+    for layout in ("stream", "shared"):
+        s = solver_for(p, start, np.float32, layout)
+        l2, hg_r, hg_i, hc_r, hc_i = s.eval_grads()
+        assert abs(l2 - loss) <= 1e-5 * abs(loss)
+        assert relnorm(hg_r, gg_r) <= 1e-4 and relnorm(hc_r, problem.coeffs_from_chunks(p, gf_r)) <= 1e-4
+        s.close()
+
+
+@pytest.fixture(scope="module")
+def hera350():
+    p, truth, start = synthetic.make_config("hera350", with_sky=True)
+    return p, perturbed(p, start, 2)
+
+
+def test_hera350_kernel_families_and_layouts_agree(hera350):
+    """BASELINE config 2 at full size (61 075 baselines x 1024 channels): fp32 MFMA path (shared layout), fp32 streaming
+    kernel (per-baseline tiles) and the fp64 general kernel give the same loss and gradients."""
+    p, start = hera350
+    ref = solver_for(p, start, np.float64, "shared")
+    l64, g64_r, g64_i, c64_r, c64_i = ref.eval_grads()
+    ref.close()
+    for layout in ("shared", "stream"):
+        s = solver_for(p, start, np.float32, layout)
+        assert abs(s.eval_loss() - l64) <= 1e-5 * abs(l64)
+        l32, g_r, g_i, c_r, c_i = s.eval_grads()
+        assert abs(l32 - l64) <= 1e-5 * abs(l64)
+        assert relnorm(g_r, g64_r) <= 1e-4 and relnorm(g_i, g64_i) <= 1e-4
+        assert relnorm(c_r, c64_r) <= 1e-4 and relnorm(c_i, c64_i) <= 1e-4
+        s.close()
+
+
+def test_hera350_gradient_is_the_derivative_of_the_loss(hera350):
+    """Central finite difference of the fp64 loss along a random direction equals <grad, direction>, with and without the
+    "sum" regulariser."""
+    p, start = hera350
+    rng = np.random.default_rng(5)
+    d = dict(g_r=rng.standard_normal(start["g_r"].shape), g_i=rng.standard_normal(start["g_i"].shape),
+             c_r=rng.standard_normal(start["c_r"].shape), c_i=rng.standard_normal(start["c_i"].shape))
+    s = solver_for(p, start, np.float64, "shared")
+    for reg in (False, True):
+        if reg:
+            s.set_regularization("sum", float(np.sum(p.sky_r * p.wgts)) * 0.9, float(np.sum(p.sky_i * p.wgts)) * 1.1)
+        s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        _, g_r, g_i, c_r, c_i = s.eval_grads()
+        slope = np.sum(g_r * d["g_r"]) + np.sum(g_i * d["g_i"]) + np.sum(c_r * d["c_r"]) + np.sum(c_i * d["c_i"])
+        h = 1e-5
+        s.set_params(*[start[k] + h * d[k] for k in ("g_r", "g_i", "c_r", "c_i")])
+        lp = s.eval_loss()
+        s.set_params(*[start[k] - h * d[k] for k in ("g_r", "g_i", "c_r", "c_i")])
+        lm = s.eval_loss()
+        assert np.isclose((lp - lm) / (2 * h), slope, rtol=1e-6)
+    s.close()
+
+
+def test_hera350_model_linearity_and_init_round_trip(hera350):
+    p, start = hera350
+    rng = np.random.default_rng(7)
+    s = solver_for(p, start, np.float64, "shared")
+    c1 = (rng.standard_normal(p.ncoeffs), rng.standard_normal(p.ncoeffs))
+    c2 = (rng.standard_normal(p.ncoeffs), rng.standard_normal(p.ncoeffs))
+    s.set_params(c_r=c1[0], c_i=c1[1])
+    m1 = s.model()
+    s.set_params(c_r=c2[0], c_i=c2[1])
+    m2 = s.model()
+    s.set_params(c_r=2.0 * c1[0] - 3.0 * c2[0], c_i=2.0 * c1[1] - 3.0 * c2[1])
+    m3 = s.model()
+    assert relnorm(m3[0], 2.0 * m1[0] - 3.0 * m2[0]) <= 1e-12 and relnorm(m3[1], 2.0 * m1[1] - 3.0 * m2[1]) <= 1e-12
+    # coefficients -> A c -> A^T (A c) with unit weights returns the coefficients (orthonormal DPSS columns)
+    s.set_data(m1[0], m1[1], np.ones((p.nbls, p.nfreqs)))
+    s.init_coeffs(m1[0], m1[1])
+    _, _, c_r, c_i = s.get_params()
+    assert relnorm(c_r, c1[0]) <= 1e-9 and relnorm(c_i, c1[1]) <= 1e-9
+    s.close()
