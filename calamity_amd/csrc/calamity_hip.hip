@@ -230,6 +230,7 @@ struct SolverT final : cal_solver {
     fpad = (nfreqs + fb_used_max - 1) / fb_used_max * fb_used_max;
     lds_bytes = 0;
     for (int u = 0; u < nbasis; ++u) lds_bytes = std::max(lds_bytes, lds_for(fb_u[u]));
+    if (const char* x = getenv("CALAMITY_HIP_X_LDS")) lds_bytes += (size_t)atoi(x);  // occupancy experiments only
     for (int b = 0; b < d->nbls; ++b) {
       if (d->bl_ant0[b] < 0 || d->bl_ant0[b] >= nants || d->bl_ant1[b] < 0 || d->bl_ant1[b] >= nants)
         return fail(CAL_ERR_INVALID, "set_problem: baseline %d has an antenna index outside [0, %d)", b, nants);
@@ -562,7 +563,7 @@ struct SolverT final : cal_solver {
     prior_r = pr;
     prior_i = pi;
     if (reg == CAL_REG_SUM) {
-      if (!q1.p) CAL_TRY(q1.alloc((size_t)nbls * fpad * sizeof(T2)));
+      if (!q1.p) CAL_TRY(q1.alloc((size_t)(nbls + 1) * fpad * sizeof(T2)));
       if (!gcp1.p) CAL_TRY(gcp1.alloc(2 * (size_t)gcp_len * sizeof(T)));
       if (!gc_direct && !gc1.p) CAL_TRY(gc1.alloc(2 * (size_t)ncoef * sizeof(T)));
     }
@@ -683,13 +684,15 @@ struct SolverT final : cal_solver {
     a.model_i = nullptr;
     a.state = state.as<DevState>();
     a.fpad = fpad;
+    a.nbls = nbls;
     return a;
   }
+  static constexpr size_t kQRowMax = TileCfg<T, FbSet<T>::fb_max>::q_lds_bytes(false);  // widest gbar_G row (1 KB)
   template <int MODE> void launch_fused(const FusedArgs<T>& a, bool with_reg) {
     if (with_reg)
-      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems), dim3(kThreads), lds_bytes, stream, a);
+      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? 2 * kQRowMax : 0), stream, a);
     else
-      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems), dim3(kThreads), lds_bytes, stream, a);
+      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQRowMax : 0), stream, a);
   }
   T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
   T* grad_c1() { return gc_direct ? gcp1.as<T>() : gc1.as<T>(); }

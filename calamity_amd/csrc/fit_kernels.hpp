@@ -89,6 +89,7 @@ struct FusedArgs {
   T* model_r; T* model_i;    // MODE_MODEL output [nbls][fpad]
   const DevState* state;
   int fpad;
+  int nbls;                  // q0 / q1 have nbls + 1 rows; row nbls stays zero
 };
 
 enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_MODEL = 2, MODE_INIT = 3 };  // INIT: c = A^T (src * [w != 0]), calibration.py:875-902
@@ -108,6 +109,8 @@ struct TileCfg {
            + 4 * (size_t)FB * sizeof(T)           // gbar_v for e0 and w part
            + 64;
   }
+  // MODE_GRAD: one tile's gbar_G (and the regulariser's second set) staged for the all-thread store
+  static constexpr size_t q_lds_bytes(bool reg) { return (reg ? 2 : 1) * (size_t)FB * 2 * sizeof(T); }
 };
 
 template <typename T> __device__ __forceinline__ T ldsum(T v) {
@@ -137,11 +140,15 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
   T* s_ci = s_cr + C::MAXK;
   T* s_pv = s_ci + C::MAXK;                // [2][kThreads]
   T* s_gv = s_pv + 2 * kThreads;           // [4][FB]: gv0_r, gv0_i, gv1_r, gv1_i
+  T2* s_q = reinterpret_cast<T2*>(s_gv + 4 * FB);  // MODE_GRAD: [REG ? 2 : 1][FB] gbar_G of the current tile
 
-  for (int k = tid; k < nvec; k += kThreads) {
-    s_cr[k] = A.c_r[it.coff + k];
-    s_ci[k] = A.c_i[it.coff + k];
+  const int nfwd = (nvec + C::NKS - 1) / C::NKS * C::NKS;  // <= MAXK: MAXK is a multiple of NKS
+  for (int k = tid; k < nfwd; k += kThreads) {
+    s_cr[k] = k < nvec ? A.c_r[it.coff + k] : (T)0;
+    s_ci[k] = k < nvec ? A.c_i[it.coff + k] : (T)0;
   }
+  // rows [nvec, nfwd) of the LDS tile are read by the forward pass and never written by the parking stores
+  for (int e = nvec * RS + tid; e < nfwd * RS; e += kThreads) s_tile[e] = (T)0;
 
   // register staging of one tile: kMaxLoads x 16 B per thread
   typedef T stage_t __attribute__((ext_vector_type(16 / sizeof(T))));
@@ -149,13 +156,32 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
   T pd_r = 0, pd_i = 0, pw = 0;  // prefetched data / weights of the tile (threads < FB)
   T2 pg0, pg1;                   // prefetched gains of the two antennas
   pg0.x = pg0.y = pg1.x = pg1.y = 0;
-  int p_bl = 0;
 
+  // Per-baseline metadata (tile offset, antenna pair) of the tile that will be issued NEXT, fetched one tile ahead
+  // of its use: a wave's vector-memory operations retire in issue order (vmcnt), so the dependent chain
+  // bl -> bl_tile[bl] -> tile loads and bl_ant[bl] -> gains inside issue_tile would stall the wave twice per tile.
+  // The index goes through an empty asm so that the loaded values stay in vector registers until issue_tile reads
+  // them; left alone the compiler moves them to scalar registers right behind the load, which is a wait for every
+  // older load of the wave (the whole tile in flight).
+  long long m_tile = 0;
+  int2 m_ant = make_int2(0, 0);
+  auto load_meta = [&](int tau) {
+    int bl = it.bl0 + tau / ntpb;
+    asm volatile("" : "+v"(bl));
+    m_tile = A.bl_tile[bl];
+    m_ant = A.bl_ant[bl];
+  };
+  // Order inside one issue: metadata of the tile after, the tile, the per-channel operands.  Whatever is issued
+  // after the tile loads is what the wait in front of the LDS parking may leave in flight.
   auto issue_tile = [&](int tau) {
     const int blrel = tau / ntpb;
     const int fbk = tau - blrel * ntpb;
     const int bl = it.bl0 + blrel;
-    const T* src = A.tiles + A.bl_tile[bl] + (long long)fbk * tile_elems;
+    const long long t_off = ((long long)__builtin_amdgcn_readfirstlane((int)(m_tile >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)m_tile);
+    const T* src = A.tiles + t_off + (long long)fbk * tile_elems;
+    const int2 ant = make_int2(__builtin_amdgcn_readfirstlane(m_ant.x), __builtin_amdgcn_readfirstlane(m_ant.y));
+    if (tau + 1 < it.tile1) load_meta(tau + 1);
 #pragma unroll
     for (int l = 0; l < kMaxLoads; ++l) {
       const int e = (l * kThreads + tid) * VEC;
@@ -166,25 +192,33 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       pd_r = A.data_r[o];
       pd_i = A.data_i[o];
       pw = A.wgts[o];
-      const int2 ant = A.bl_ant[bl];
       pg0 = A.gains[(long long)ant.x * A.fpad + fbk * FB + tid];
       pg1 = A.gains[(long long)ant.y * A.fpad + fbk * FB + tid];
-      p_bl = bl;
     }
+  };
+  // gbar_G of a tile leaves as one 4-byte store per thread (all 256 threads, no branch), issued in the middle of the
+  // tile's work, i.e. AFTER the loads of the next tile.  A store is acknowledged later than the loads around it and
+  // vmcnt retires in issue order: a store issued in front of those loads held back the wait for them (0.4 ms of
+  // 4.9 ms on HERA-350); behind them, the counted wait lets it stay in flight for one more tile.  The store in the
+  // prologue (zeros into the spare zero row of q0) makes the first trip through the loop look like every other trip
+  // to the compiler's wait-count bookkeeping.
+  constexpr int kQRowBytes = FB * (int)sizeof(T2);
+  const int q_byte = (tid * 4) % kQRowBytes;  // rows shorter than 1 KB: threads beyond the row repeat earlier words
+  auto store_q = [&](vec2_t<T>* dst, const T2* srow, long long o) {
+    reinterpret_cast<unsigned*>(dst + o)[q_byte / 4] = reinterpret_cast<const unsigned*>(srow)[q_byte / 4];
   };
 
   T acc0_r[C::KCH], acc0_i[C::KCH], acc1_r[C::KCH], acc1_i[C::KCH];
 #pragma unroll
   for (int j = 0; j < C::KCH; ++j) acc0_r[j] = acc0_i[j] = acc1_r[j] = acc1_i[j] = 0;
   double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
-  // gbar_G of the previous tile, stored one tile late: CDNA4 retires loads and stores of a wave in issue order
-  // (vmcnt), so a store issued mid-tile would sit in front of the wait for the next tile's loads; issued just
-  // before those loads it completes under their latency instead
-  T2 q0_prev, q1_prev;
-  q0_prev.x = q0_prev.y = q1_prev.x = q1_prev.y = 0;
-  long long o_prev = -1;
 
+  load_meta(it.tile0);
   issue_tile(it.tile0);
+  if (MODE == MODE_GRAD) {
+    reinterpret_cast<unsigned*>(A.q0 + (long long)A.nbls * A.fpad)[q_byte / 4] = 0u;
+    if (REG) reinterpret_cast<unsigned*>(A.q1 + (long long)A.nbls * A.fpad)[q_byte / 4] = 0u;
+  }
   for (int tau = it.tile0; tau < it.tile1; ++tau) {
     // ---- park the staged tile in LDS
 #pragma unroll
@@ -198,13 +232,9 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     }
     const T d_r = pd_r, d_i = pd_i, w = pw;
     const T2 g0 = pg0, g1 = pg1;
-    const int bl = p_bl;
+    const int bl = it.bl0 + tau / ntpb;
     const int fbk = tau % ntpb;
     __syncthreads();
-    if (MODE == MODE_GRAD && tid < FB && o_prev >= 0) {
-      A.q0[o_prev] = q0_prev;
-      if (REG) A.q1[o_prev] = q1_prev;
-    }
     if (tau + 1 < it.tile1) issue_tile(tau + 1);
 
     // ---- forward: v[f] = sum_k A[k][f] c[k]; thread = (channel f, k-slice ks)
@@ -213,12 +243,16 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       const int f = tid % FB;
       const int ks = tid / FB;
       T vr = 0, vi = 0;
-      const T* col = s_tile + f;
+      const T* col = s_tile + ks * RS + f;
+      const T* pcr = s_cr + ks;
+      const T* pci = s_ci + ks;
+      // the same trip count in every thread (rows and coefficients of [nvec, nfwd) are zero), so that the compiler can
+      // batch the LDS reads of several vectors in front of one wait
 #pragma unroll 4
-      for (int k = ks; k < nvec; k += C::NKS) {
-        const T a = col[k * RS];
-        vr += a * s_cr[k];
-        vi += a * s_ci[k];
+      for (int i = 0; i < nfwd; i += C::NKS) {
+        const T a = col[i * RS];
+        vr += a * pcr[i];
+        vi += a * pci[i];
       }
       s_pv[tid] = vr;
       s_pv[kThreads + tid] = vi;
@@ -264,20 +298,26 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
           T2 q;
           q.x = vr * e_r + vi * e_i;
           q.y = vr * e_i - vi * e_r;
-          q0_prev = q;
-          o_prev = o;
+          s_q[tid] = q;
           if (REG) {
             // the part of e that multiplies alpha: w (real)
             s_gv[2 * FB + tid] = G_r * w;
             s_gv[3 * FB + tid] = -G_i * w;
-            q1_prev.x = vr * w;
-            q1_prev.y = -vi * w;
+            T2 qw;
+            qw.x = vr * w;
+            qw.y = -vi * w;
+            s_q[FB + tid] = qw;
           }
         }
       }
     }
     if (BWD) {
       __syncthreads();
+      if (MODE == MODE_GRAD) {
+        const long long o = (long long)bl * A.fpad + fbk * FB;
+        store_q(A.q0, s_q, o);
+        if (REG) store_q(A.q1, s_q + FB, o);
+      }
       // ---- adjoint: gc[k] += sum_f A[k][f] gbar_v[f]; wave = channel quarter, lane = vector (64 per chunk)
 #ifndef CAL_X_NOBWD
       const int f_lo = wave * C::CW;
@@ -313,10 +353,6 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     __syncthreads();  // tile and gbar_v fully consumed before the next tile overwrites them
   }
 
-  if (MODE == MODE_GRAD && tid < FB && o_prev >= 0) {
-    A.q0[o_prev] = q0_prev;
-    if (REG) A.q1[o_prev] = q1_prev;
-  }
   // ---- item epilogue: loss partials (double), coefficient-gradient partials
   if (MODE == MODE_LOSS || MODE == MODE_GRAD) {
     double* s_red = reinterpret_cast<double*>(s_pv);  // reuse: 3 x kWaves doubles
