@@ -136,16 +136,18 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
   const int tile_elems = nvec * FB;
 
   T* s_tile = reinterpret_cast<T*>(smem);
-  T* s_cr = s_tile + (size_t)C::MAXK * RS;
-  T* s_ci = s_cr + C::MAXK;
-  T* s_pv = s_ci + C::MAXK;                // [2][kThreads]
-  T* s_gv = s_pv + 2 * kThreads;           // [4][FB]: gv0_r, gv0_i, gv1_r, gv1_i
-  T2* s_q = reinterpret_cast<T2*>(s_gv + 4 * FB);  // MODE_GRAD: [REG ? 2 : 1][FB] gbar_G of the current tile
+  // complex values are kept as (re, im) pairs in LDS so that one read feeds a packed fp32 FMA directly
+  T2* s_c = reinterpret_cast<T2*>(s_tile + (size_t)C::MAXK * RS);  // [MAXK] coefficients of the group
+  T* s_pv = reinterpret_cast<T*>(s_c + C::MAXK);                    // [2][kThreads] forward partials
+  T2* s_gv = reinterpret_cast<T2*>(s_pv + 2 * kThreads);            // [2][FB]: gbar_v of e0, of the w part
+  T2* s_q = s_gv + 2 * FB;  // MODE_GRAD: [REG ? 2 : 1][FB] gbar_G of the current tile
 
   const int nfwd = (nvec + C::NKS - 1) / C::NKS * C::NKS;  // <= MAXK: MAXK is a multiple of NKS
   for (int k = tid; k < nfwd; k += kThreads) {
-    s_cr[k] = k < nvec ? A.c_r[it.coff + k] : (T)0;
-    s_ci[k] = k < nvec ? A.c_i[it.coff + k] : (T)0;
+    T2 c;
+    c.x = k < nvec ? A.c_r[it.coff + k] : (T)0;
+    c.y = k < nvec ? A.c_i[it.coff + k] : (T)0;
+    s_c[k] = c;
   }
   // rows [nvec, nfwd) of the LDS tile are read by the forward pass and never written by the parking stores
   for (int e = nvec * RS + tid; e < nfwd * RS; e += kThreads) s_tile[e] = (T)0;
@@ -244,15 +246,15 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       const int ks = tid / FB;
       T vr = 0, vi = 0;
       const T* col = s_tile + ks * RS + f;
-      const T* pcr = s_cr + ks;
-      const T* pci = s_ci + ks;
+      const T2* pc = s_c + ks;
       // the same trip count in every thread (rows and coefficients of [nvec, nfwd) are zero), so that the compiler can
       // batch the LDS reads of several vectors in front of one wait
 #pragma unroll 4
       for (int i = 0; i < nfwd; i += C::NKS) {
         const T a = col[i * RS];
-        vr += a * pcr[i];
-        vi += a * pci[i];
+        const T2 c = pc[i];
+        vr += a * c.x;
+        vi += a * c.y;
       }
       s_pv[tid] = vr;
       s_pv[kThreads + tid] = vi;
@@ -273,8 +275,10 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       } else if (MODE == MODE_INIT) {
         // binary weights of calibration.py:875-877: ~np.isclose(w, 0.0) (atol 1e-8)
         const T msk = (fabs(w) <= (T)1e-8) ? (T)0 : (T)1;
-        s_gv[tid] = d_r * msk;
-        s_gv[FB + tid] = d_i * msk;
+        T2 gv;
+        gv.x = d_r * msk;
+        gv.y = d_i * msk;
+        s_gv[tid] = gv;
       } else {
         // G = g0 conj(g1)   (calibration.py:1598-1601: grgr + gigi, gigr - grgi)
         const T G_r = g0.x * g1.x + g0.y * g1.y;
@@ -292,8 +296,10 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
           const T e_r = (T)-2 * w * r_r;
           const T e_i = (T)-2 * w * r_i;
           // gbar_v = conj(G) e
-          s_gv[tid] = G_r * e_r + G_i * e_i;
-          s_gv[FB + tid] = G_r * e_i - G_i * e_r;
+          T2 gv;
+          gv.x = G_r * e_r + G_i * e_i;
+          gv.y = G_r * e_i - G_i * e_r;
+          s_gv[tid] = gv;
           // gbar_G = conj(v) e
           T2 q;
           q.x = vr * e_r + vi * e_i;
@@ -301,8 +307,10 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
           s_q[tid] = q;
           if (REG) {
             // the part of e that multiplies alpha: w (real)
-            s_gv[2 * FB + tid] = G_r * w;
-            s_gv[3 * FB + tid] = -G_i * w;
+            T2 gw;
+            gw.x = G_r * w;
+            gw.y = -G_i * w;
+            s_gv[FB + tid] = gw;
             T2 qw;
             qw.x = vr * w;
             qw.y = -vi * w;
@@ -332,11 +340,13 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
             const stage_t a = *reinterpret_cast<const stage_t*>(row + f);
 #pragma unroll
             for (int u = 0; u < VEC; ++u) {
-              a0r += a[u] * s_gv[f_lo + f + u];
-              a0i += a[u] * s_gv[FB + f_lo + f + u];
+              const T2 g0v = s_gv[f_lo + f + u];
+              a0r += a[u] * g0v.x;
+              a0i += a[u] * g0v.y;
               if (REG) {
-                a1r += a[u] * s_gv[2 * FB + f_lo + f + u];
-                a1i += a[u] * s_gv[3 * FB + f_lo + f + u];
+                const T2 g1v = s_gv[FB + f_lo + f + u];
+                a1r += a[u] * g1v.x;
+                a1i += a[u] * g1v.y;
               }
             }
           }
