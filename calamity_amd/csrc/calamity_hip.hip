@@ -687,12 +687,14 @@ struct SolverT final : cal_solver {
     a.nbls = nbls;
     return a;
   }
-  static constexpr size_t kQRowMax = TileCfg<T, FbSet<T>::fb_max>::q_lds_bytes(false);  // widest gbar_G row (1 KB)
+  // LDS buffer of gbar_G rows (MODE_GRAD); the narrowest tiles have the longest offset table
+  static constexpr size_t kQLdsMax1 = TileCfg<T, FbSet<T>::fb_min>::q_lds_bytes(false);
+  static constexpr size_t kQLdsMax2 = TileCfg<T, FbSet<T>::fb_min>::q_lds_bytes(true);
   template <int MODE> void launch_fused(const FusedArgs<T>& a, bool with_reg) {
     if (with_reg)
-      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? 2 * kQRowMax : 0), stream, a);
+      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax2 : 0), stream, a);
     else
-      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQRowMax : 0), stream, a);
+      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
   }
   T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
   T* grad_c1() { return gc_direct ? gcp1.as<T>() : gc1.as<T>(); }

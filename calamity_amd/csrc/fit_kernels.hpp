@@ -96,21 +96,17 @@ enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_MODEL = 2, MODE_INIT = 3 };  // INIT: 
 
 template <typename T, int FB>
 struct TileCfg {
-  static constexpr int VEC = 16 / (int)sizeof(T);
-  static constexpr int MAXK = kTileBytes / (int)sizeof(T) / FB;
-  static constexpr int RS = FB + VEC;            // padded LDS row stride (elements)
-  static constexpr int NKS = kThreads / FB;      // k-slices of the forward pass
-  static constexpr int CW = FB / kWaves;         // channels per wave in the adjoint pass
-  static constexpr int KCH = (MAXK + 63) / 64;   // vector chunks per lane in the adjoint pass
+  static constexpr int VEC = 16 / (int)sizeof(T);      // reals per 16-byte load
+  static constexpr int MAXK = kTileBytes / (int)sizeof(T) / FB;  // basis vectors (rows) a tile can hold
+  static constexpr int LPR = FB / VEC;                 // lanes that hold one row of the tile
+  static constexpr int NS = kThreads / LPR;            // rows covered by one 256-thread load = MAXK / kMaxLoads
+  static constexpr int QT = 1024 / FB;                 // tiles of gbar_G the LDS buffer holds (1024 channels)
   static constexpr size_t lds_bytes() {
-    return (size_t)MAXK * RS * sizeof(T)          // tile
-           + 2 * (size_t)MAXK * sizeof(T)         // c_r, c_i
-           + 2 * (size_t)kThreads * sizeof(T)     // forward partials (re, im)
-           + 4 * (size_t)FB * sizeof(T)           // gbar_v for e0 and w part
+    return (2 * (size_t)kWaves * FB + 2 * (size_t)FB + MAXK) * 2 * sizeof(T)  // forward partials (two parities), gbar_v, c
            + 64;
   }
-  // MODE_GRAD: one tile's gbar_G (and the regulariser's second set) staged for the all-thread store
-  static constexpr size_t q_lds_bytes(bool reg) { return (reg ? 2 : 1) * (size_t)FB * 2 * sizeof(T); }
+  // MODE_GRAD only: gbar_G rows (and the regulariser's second set) waiting for the flush, and their row offsets
+  static constexpr size_t q_lds_bytes(bool reg) { return (reg ? 2 : 1) * (size_t)1024 * 2 * sizeof(T) + QT * sizeof(long long); }
 };
 
 template <typename T> __device__ __forceinline__ T ldsum(T v) {
@@ -120,51 +116,90 @@ template <typename T> __device__ __forceinline__ T ldsum(T v) {
   return v;
 }
 
-// One item: stream its tiles once, forward + adjoint from LDS.
+// One item: stream its tiles once; forward and adjoint run out of the registers the tile was loaded into.
+//
+// A tile is [nvec][FB] reals, row-major.  The 16-byte load l of thread tid covers row k = l * NS + tid / LPR, channels
+// f0 = (tid % LPR) * VEC ... f0 + VEC - 1, so every thread owns the same kMaxLoads rows and VEC channels in every tile
+// of the item.  That makes both products register-resident:
+//   forward  v[f]  = sum_k A[k][f] c[k]      : per thread a partial over its rows (coefficients of those rows stay
+//                                              in registers for the whole item), summed over the threads that share
+//                                              the channels: shuffles inside the wave, 4 x FB pairs through LDS
+//   adjoint  gc[k] = sum_f A[k][f] gbar_v[f] : per thread a partial over its channels, ACCUMULATED over all tiles of
+//                                              the item in registers and summed over the LPR lanes of a row once,
+//                                              at the end of the item
+// LDS carries only per-channel vectors (about 17 KB of traffic per 28 KB tile); the tile itself never enters it.
 template <typename T, int FB, int MODE, bool REG>
 __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item it, unsigned char* smem, int item_idx) {
   using C = TileCfg<T, FB>;
   using T2 = vec2_t<T>;
   constexpr int VEC = C::VEC;
-  constexpr int RS = C::RS;
+  constexpr int LPR = C::LPR;
+  constexpr int NS = C::NS;
+  constexpr int L = kMaxLoads;
+  constexpr bool FWD = (MODE != MODE_INIT);
   constexpr bool BWD = (MODE == MODE_GRAD || MODE == MODE_INIT);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int fq = tid % LPR;
+  const int ks = tid / LPR;
+  const int f0 = fq * VEC;
   const int nvec = it.nvec;
   const int ntpb = A.fpad / FB;
   const int tile_elems = nvec * FB;
 
-  T* s_tile = reinterpret_cast<T*>(smem);
-  // complex values are kept as (re, im) pairs in LDS so that one read feeds a packed fp32 FMA directly
-  T2* s_c = reinterpret_cast<T2*>(s_tile + (size_t)C::MAXK * RS);  // [MAXK] coefficients of the group
-  T* s_pv = reinterpret_cast<T*>(s_c + C::MAXK);                    // [2][kThreads] forward partials
-  T2* s_gv = reinterpret_cast<T2*>(s_pv + 2 * kThreads);            // [2][FB]: gbar_v of e0, of the w part
-  T2* s_q = s_gv + 2 * FB;  // MODE_GRAD: [REG ? 2 : 1][FB] gbar_G of the current tile
+  T2* s_pv = reinterpret_cast<T2*>(smem);   // [2][kWaves][FB] forward partials of the four waves, by tile parity
+  T2* s_gv = s_pv + 2 * kWaves * FB;        // [2][FB]: gbar_v of e0, of the w part (regulariser)
+  T2* s_c = s_gv + 2 * FB;                  // [MAXK] coefficients of the group
+  T2* s_q = s_c + C::MAXK;                  // MODE_GRAD: [REG ? 2 : 1][QT][FB] gbar_G rows waiting for the flush
+  long long* s_qo = reinterpret_cast<long long*>(s_q + (REG ? 2 : 1) * C::QT * FB);  // [QT] their offsets in q0 / q1
 
-  const int nfwd = (nvec + C::NKS - 1) / C::NKS * C::NKS;  // <= MAXK: MAXK is a multiple of NKS
-  for (int k = tid; k < nfwd; k += kThreads) {
-    T2 c;
-    c.x = k < nvec ? A.c_r[it.coff + k] : (T)0;
-    c.y = k < nvec ? A.c_i[it.coff + k] : (T)0;
-    s_c[k] = c;
-  }
-  // rows [nvec, nfwd) of the LDS tile are read by the forward pass and never written by the parking stores
-  for (int e = nvec * RS + tid; e < nfwd * RS; e += kThreads) s_tile[e] = (T)0;
-
-  // register staging of one tile: kMaxLoads x 16 B per thread
   typedef T stage_t __attribute__((ext_vector_type(16 / sizeof(T))));
-  stage_t stage[kMaxLoads];
-  T pd_r = 0, pd_i = 0, pw = 0;  // prefetched data / weights of the tile (threads < FB)
-  T2 pg0, pg1;                   // prefetched gains of the two antennas
-  pg0.x = pg0.y = pg1.x = pg1.y = 0;
 
-  // Per-baseline metadata (tile offset, antenna pair) of the tile that will be issued NEXT, fetched one tile ahead
-  // of its use: a wave's vector-memory operations retire in issue order (vmcnt), so the dependent chain
-  // bl -> bl_tile[bl] -> tile loads and bl_ant[bl] -> gains inside issue_tile would stall the wave twice per tile.
-  // The index goes through an empty asm so that the loaded values stay in vector registers until issue_tile reads
-  // them; left alone the compiler moves them to scalar registers right behind the load, which is a wait for every
-  // older load of the wave (the whole tile in flight).
+  // coefficients of the group, (re, im) pairs, zero beyond nvec (those rows are not loaded either).  They are read
+  // back per tile rather than held in 2 x kMaxLoads registers: registers decide how many workgroups share a CU
+  if (FWD) {
+    for (int k = tid; k < C::MAXK; k += kThreads) {
+      T2 c;
+      c.x = k < nvec ? A.c_r[it.coff + k] : (T)0;
+      c.y = k < nvec ? A.c_i[it.coff + k] : (T)0;
+      s_c[k] = c;
+    }
+    __syncthreads();
+  }
+  T2 acc0[L], acc1[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) acc0[l].x = acc0[l].y = acc1[l].x = acc1[l].y = 0;
+  double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
+
+  // gbar_G leaves through LDS, 1024 channels at a time: CDNA4 retires a wave's loads and stores in issue order
+  // (vmcnt) and a store is acknowledged later than the loads around it, so a store per tile in front of the next
+  // tile's loads delays them (measured: 0.4 ms of 4.9 ms on HERA-350).  The flush of a single-baseline item has no
+  // load behind it.
+  int q_count = 0;
+  auto flush_q = [&]() {
+    constexpr int kSlotBytes = FB * (int)sizeof(T2);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#ifdef CAL_X_NOQ
+    q_count = 0;  // experiment: no gbar_G stores (results are wrong)
+#endif
+    for (int b = tid * 16; b < q_count * kSlotBytes; b += kThreads * 16) {
+      const int slot = b / kSlotBytes;
+      const int within = b - slot * kSlotBytes;
+      const long long o = s_qo[slot];
+      *reinterpret_cast<u4*>(reinterpret_cast<char*>(A.q0 + o) + within) =
+          *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(s_q) + b);
+      if (REG)
+        *reinterpret_cast<u4*>(reinterpret_cast<char*>(A.q1 + o) + within) =
+            *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(s_q + C::QT * FB) + b);
+    }
+    q_count = 0;
+  };
+
+  // Per-baseline metadata (tile offset, antenna pair) is fetched one tile ahead of its use, so that the chain
+  // bl -> bl_tile[bl] -> tile loads and bl_ant[bl] -> gains never waits inside a tile.  The index goes through an
+  // empty asm: left alone the compiler moves the loaded values to scalar registers right behind the load, which is a
+  // wait for every older load of the wave.
   long long m_tile = 0;
   int2 m_ant = make_int2(0, 0);
   auto load_meta = [&](int tau) {
@@ -173,105 +208,89 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     m_tile = A.bl_tile[bl];
     m_ant = A.bl_ant[bl];
   };
-  // Order inside one issue: metadata of the tile after, the tile, the per-channel operands.  Whatever is issued
-  // after the tile loads is what the wait in front of the LDS parking may leave in flight.
-  auto issue_tile = [&](int tau) {
+  load_meta(it.tile0);
+
+  for (int tau = it.tile0; tau < it.tile1; ++tau) {
     const int blrel = tau / ntpb;
     const int fbk = tau - blrel * ntpb;
     const int bl = it.bl0 + blrel;
+    const long long o_row = (long long)bl * A.fpad + fbk * FB;  // this tile's channels in the [nbls][fpad] arrays
+    if (MODE == MODE_GRAD && q_count == C::QT) flush_q();       // s_q was last written before the previous barrier
+
     const long long t_off = ((long long)__builtin_amdgcn_readfirstlane((int)(m_tile >> 32)) << 32) |
                             (unsigned)__builtin_amdgcn_readfirstlane((int)m_tile);
-    const T* src = A.tiles + t_off + (long long)fbk * tile_elems;
     const int2 ant = make_int2(__builtin_amdgcn_readfirstlane(m_ant.x), __builtin_amdgcn_readfirstlane(m_ant.y));
     if (tau + 1 < it.tile1) load_meta(tau + 1);
-#pragma unroll
-    for (int l = 0; l < kMaxLoads; ++l) {
-      const int e = (l * kThreads + tid) * VEC;
-      if (e < tile_elems) stage[l] = *reinterpret_cast<const stage_t*>(src + e);
-    }
+
+    // ---- issue everything the tile needs: per-channel operands first (threads < FB), then the tile
+    T d_r = 0, d_i = 0, w = 0;
+    T2 g0, g1;
+    g0.x = g0.y = g1.x = g1.y = 0;
     if (tid < FB) {
-      const long long o = (long long)bl * A.fpad + fbk * FB + tid;
-      pd_r = A.data_r[o];
-      pd_i = A.data_i[o];
-      pw = A.wgts[o];
-      pg0 = A.gains[(long long)ant.x * A.fpad + fbk * FB + tid];
-      pg1 = A.gains[(long long)ant.y * A.fpad + fbk * FB + tid];
-    }
-  };
-  // gbar_G of a tile leaves as one 4-byte store per thread (all 256 threads, no branch), issued in the middle of the
-  // tile's work, i.e. AFTER the loads of the next tile.  A store is acknowledged later than the loads around it and
-  // vmcnt retires in issue order: a store issued in front of those loads held back the wait for them (0.4 ms of
-  // 4.9 ms on HERA-350); behind them, the counted wait lets it stay in flight for one more tile.  The store in the
-  // prologue (zeros into the spare zero row of q0) makes the first trip through the loop look like every other trip
-  // to the compiler's wait-count bookkeeping.
-  constexpr int kQRowBytes = FB * (int)sizeof(T2);
-  const int q_byte = (tid * 4) % kQRowBytes;  // rows shorter than 1 KB: threads beyond the row repeat earlier words
-  auto store_q = [&](vec2_t<T>* dst, const T2* srow, long long o) {
-    reinterpret_cast<unsigned*>(dst + o)[q_byte / 4] = reinterpret_cast<const unsigned*>(srow)[q_byte / 4];
-  };
-
-  T acc0_r[C::KCH], acc0_i[C::KCH], acc1_r[C::KCH], acc1_i[C::KCH];
-#pragma unroll
-  for (int j = 0; j < C::KCH; ++j) acc0_r[j] = acc0_i[j] = acc1_r[j] = acc1_i[j] = 0;
-  double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
-
-  load_meta(it.tile0);
-  issue_tile(it.tile0);
-  if (MODE == MODE_GRAD) {
-    reinterpret_cast<unsigned*>(A.q0 + (long long)A.nbls * A.fpad)[q_byte / 4] = 0u;
-    if (REG) reinterpret_cast<unsigned*>(A.q1 + (long long)A.nbls * A.fpad)[q_byte / 4] = 0u;
-  }
-  for (int tau = it.tile0; tau < it.tile1; ++tau) {
-    // ---- park the staged tile in LDS
-#pragma unroll
-    for (int l = 0; l < kMaxLoads; ++l) {
-      const int e = (l * kThreads + tid) * VEC;
-      if (e < tile_elems) {
-        const int k = e / FB;
-        const int f = e - k * FB;
-        *reinterpret_cast<stage_t*>(s_tile + k * RS + f) = stage[l];
+      if (MODE != MODE_MODEL) {
+        d_r = A.data_r[o_row + tid];
+        d_i = A.data_i[o_row + tid];
+        w = A.wgts[o_row + tid];
+      }
+      if (MODE == MODE_LOSS || MODE == MODE_GRAD) {
+        g0 = A.gains[(long long)ant.x * A.fpad + fbk * FB + tid];
+        g1 = A.gains[(long long)ant.y * A.fpad + fbk * FB + tid];
       }
     }
-    const T d_r = pd_r, d_i = pd_i, w = pw;
-    const T2 g0 = pg0, g1 = pg1;
-    const int bl = it.bl0 + tau / ntpb;
-    const int fbk = tau % ntpb;
-    __syncthreads();
-    if (tau + 1 < it.tile1) issue_tile(tau + 1);
+    // Every load is unconditional and unmasked: a lane-masked load next to a zero fill of the other lanes makes the
+    // compiler wait for each load before it touches the register again, seven round trips per tile.  Rows past nvec
+    // re-read the last row of the tile (cache hits); their coefficients are zero and their adjoint sums are never
+    // written.
+    const T* src = A.tiles + t_off + (long long)fbk * tile_elems;
+    stage_t stage[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) stage[l] = *reinterpret_cast<const stage_t*>(src + (min(l * NS + ks, nvec - 1) * FB + f0));
 
-    // ---- forward: v[f] = sum_k A[k][f] c[k]; thread = (channel f, k-slice ks)
-#ifndef CAL_X_NOFWD
-    if (MODE != MODE_INIT) {
-      const int f = tid % FB;
-      const int ks = tid / FB;
-      T vr = 0, vi = 0;
-      const T* col = s_tile + ks * RS + f;
-      const T2* pc = s_c + ks;
-      // the same trip count in every thread (rows and coefficients of [nvec, nfwd) are zero), so that the compiler can
-      // batch the LDS reads of several vectors in front of one wait
-#pragma unroll 4
-      for (int i = 0; i < nfwd; i += C::NKS) {
-        const T a = col[i * RS];
-        const T2 c = pc[i];
-        vr += a * c.x;
-        vi += a * c.y;
+    // ---- forward
+    T2* pv_par = s_pv + (tau & 1) * kWaves * FB;
+    if (FWD) {
+      T2 pv[VEC];
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) pv[u].x = pv[u].y = 0;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const T2 c = s_c[l * NS + ks];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+          pv[u].x += stage[l][u] * c.x;
+          pv[u].y += stage[l][u] * c.y;
+        }
       }
-      s_pv[tid] = vr;
-      s_pv[kThreads + tid] = vi;
+      // rows held by the other lanes of this wave
+#pragma unroll
+      for (int sft = LPR; sft < 64; sft <<= 1) {
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+          pv[u].x += __shfl_xor(pv[u].x, sft, 64);
+          pv[u].y += __shfl_xor(pv[u].y, sft, 64);
+        }
+      }
+      if (lane < LPR) {
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) pv_par[wave * FB + f0 + u] = pv[u];
+      }
     }
-#endif
     __syncthreads();
+
+    // ---- per-channel stage: thread = channel
     if (tid < FB) {
       T vr = 0, vi = 0;
+      if (FWD) {
 #pragma unroll
-      for (int s = 0; s < C::NKS; ++s) {
-        vr += s_pv[s * FB + tid];
-        vi += s_pv[kThreads + s * FB + tid];
+        for (int wv = 0; wv < kWaves; ++wv) {
+          const T2 p = pv_par[wv * FB + tid];
+          vr += p.x;
+          vi += p.y;
+        }
       }
-      const long long o = (long long)bl * A.fpad + fbk * FB + tid;
       if (MODE == MODE_MODEL) {
-        A.model_r[o] = vr;
-        A.model_i[o] = vi;
+        A.model_r[o_row + tid] = vr;
+        A.model_i[o_row + tid] = vi;
       } else if (MODE == MODE_INIT) {
         // binary weights of calibration.py:875-877: ~np.isclose(w, 0.0) (atol 1e-8)
         const T msk = (fabs(w) <= (T)1e-8) ? (T)0 : (T)1;
@@ -304,7 +323,8 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
           T2 q;
           q.x = vr * e_r + vi * e_i;
           q.y = vr * e_i - vi * e_r;
-          s_q[tid] = q;
+          s_q[q_count * FB + tid] = q;
+          if (tid == 0) s_qo[q_count] = o_row;
           if (REG) {
             // the part of e that multiplies alpha: w (real)
             T2 gw;
@@ -314,57 +334,45 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
             T2 qw;
             qw.x = vr * w;
             qw.y = -vi * w;
-            s_q[FB + tid] = qw;
+            s_q[(C::QT + q_count) * FB + tid] = qw;
           }
         }
       }
     }
     if (BWD) {
       __syncthreads();
-      if (MODE == MODE_GRAD) {
-        const long long o = (long long)bl * A.fpad + fbk * FB;
-        store_q(A.q0, s_q, o);
-        if (REG) store_q(A.q1, s_q + FB, o);
+      // ---- adjoint: this thread's channels of gbar_v against its rows of the tile
+      T2 gv0[VEC], gv1[VEC];
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) {
+        gv0[u] = s_gv[f0 + u];
+        if (REG) gv1[u] = s_gv[FB + f0 + u];
       }
-      // ---- adjoint: gc[k] += sum_f A[k][f] gbar_v[f]; wave = channel quarter, lane = vector (64 per chunk)
-#ifndef CAL_X_NOBWD
-      const int f_lo = wave * C::CW;
 #pragma unroll
-      for (int j = 0; j < C::KCH; ++j) {
-        const int k = j * 64 + lane;
-        if (k < nvec) {
-          const T* row = s_tile + k * RS + f_lo;
-          T a0r = 0, a0i = 0, a1r = 0, a1i = 0;
+      for (int l = 0; l < L; ++l) {
 #pragma unroll
-          for (int f = 0; f < C::CW; f += VEC) {
-            const stage_t a = *reinterpret_cast<const stage_t*>(row + f);
-#pragma unroll
-            for (int u = 0; u < VEC; ++u) {
-              const T2 g0v = s_gv[f_lo + f + u];
-              a0r += a[u] * g0v.x;
-              a0i += a[u] * g0v.y;
-              if (REG) {
-                const T2 g1v = s_gv[FB + f_lo + f + u];
-                a1r += a[u] * g1v.x;
-                a1i += a[u] * g1v.y;
-              }
-            }
-          }
-          acc0_r[j] += a0r;
-          acc0_i[j] += a0i;
+        for (int u = 0; u < VEC; ++u) {
+          acc0[l].x += stage[l][u] * gv0[u].x;
+          acc0[l].y += stage[l][u] * gv0[u].y;
           if (REG) {
-            acc1_r[j] += a1r;
-            acc1_i[j] += a1i;
+            acc1[l].x += stage[l][u] * gv1[u].x;
+            acc1[l].y += stage[l][u] * gv1[u].y;
           }
         }
       }
-#endif
+      if (MODE == MODE_GRAD) ++q_count;
     }
-    __syncthreads();  // tile and gbar_v fully consumed before the next tile overwrites them
+    // no barrier here: the next tile writes the other parity of s_pv, and s_gv / s_q are rewritten only behind the
+    // next tile's first barrier, which no wave reaches before it has finished this tile
   }
 
+  if (MODE == MODE_GRAD) {
+    __syncthreads();
+    flush_q();
+  }
   // ---- item epilogue: loss partials (double), coefficient-gradient partials
   if (MODE == MODE_LOSS || MODE == MODE_GRAD) {
+    __syncthreads();
     double* s_red = reinterpret_cast<double*>(s_pv);  // reuse: 3 x kWaves doubles
     const double l = ldsum(loss_acc);
     const double sr = REG ? ldsum(sr_acc) : 0.0;
@@ -386,39 +394,29 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       A.part[(size_t)item_idx * 4 + 1] = b;
       A.part[(size_t)item_idx * 4 + 2] = c;
     }
-    __syncthreads();
   }
   if (BWD) {
-    // cross-wave sum of the four channel quarters through LDS (tile region is free now); one round per
-    // adjoint set so the scratch [kWaves][2][MAXK] always fits inside the tile region
-    T* s_x = s_tile;
+    // sum over the LPR lanes that hold the same rows (they are consecutive lanes of one wave); lane fq == 0 writes
 #pragma unroll
-    for (int round = 0; round < (REG ? 2 : 1); ++round) {
+    for (int l = 0; l < L; ++l) {
 #pragma unroll
-      for (int j = 0; j < C::KCH; ++j) {
-        const int k = j * 64 + lane;
-        if (k < nvec) {
-          s_x[(wave * 2 + 0) * C::MAXK + k] = round ? acc1_r[j] : acc0_r[j];
-          s_x[(wave * 2 + 1) * C::MAXK + k] = round ? acc1_i[j] : acc0_i[j];
+      for (int sft = 1; sft < LPR; sft <<= 1) {
+        acc0[l].x += __shfl_xor(acc0[l].x, sft, 64);
+        acc0[l].y += __shfl_xor(acc0[l].y, sft, 64);
+        if (REG) {
+          acc1[l].x += __shfl_xor(acc1[l].x, sft, 64);
+          acc1[l].y += __shfl_xor(acc1[l].y, sft, 64);
         }
       }
-      __syncthreads();
-      for (int k = tid; k < nvec; k += kThreads) {
-        T a = 0, b = 0;
-#pragma unroll
-        for (int wv = 0; wv < kWaves; ++wv) {
-          a += s_x[(wv * 2 + 0) * C::MAXK + k];
-          b += s_x[(wv * 2 + 1) * C::MAXK + k];
-        }
-        if (round == 0) {
-          A.gcp0_r[it.goff + k] = a;
-          A.gcp0_i[it.goff + k] = b;
-        } else {
-          A.gcp1_r[it.goff + k] = a;
-          A.gcp1_i[it.goff + k] = b;
+      const int k = l * NS + ks;
+      if (fq == 0 && k < nvec) {
+        A.gcp0_r[it.goff + k] = acc0[l].x;
+        A.gcp0_i[it.goff + k] = acc0[l].y;
+        if (REG) {
+          A.gcp1_r[it.goff + k] = acc1[l].x;
+          A.gcp1_i[it.goff + k] = acc1[l].y;
         }
       }
-      __syncthreads();
     }
   }
 }
@@ -427,8 +425,12 @@ template <typename T> struct FbSet;
 template <> struct FbSet<float> { static constexpr int fb_max = 128; static constexpr int fb_min = 16; };
 template <> struct FbSet<double> { static constexpr int fb_max = 64; static constexpr int fb_min = 8; };
 
+#ifndef CAL_WAVES_EU
+#define CAL_WAVES_EU 4
+#endif
 template <typename T, int MODE, bool REG>
-__global__ __launch_bounds__(kThreads) void fused_basis_kernel(const FusedArgs<T> A) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && !REG) ? CAL_WAVES_EU : 1)))
+void fused_basis_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (A.state->done | A.state->done_after) return;
   const Item it = A.items[blockIdx.x];
