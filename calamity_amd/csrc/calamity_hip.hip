@@ -685,6 +685,7 @@ struct SolverT final : cal_solver {
     a.state = state.as<DevState>();
     a.fpad = fpad;
     a.nbls = nbls;
+    a.stream_once = (layout == CAL_LAYOUT_STREAM && !getenv("CALAMITY_HIP_NO_NT")) ? 1 : 0;
     return a;
   }
   // LDS buffer of gbar_G rows (MODE_GRAD); the narrowest tiles have the longest offset table

@@ -90,6 +90,7 @@ struct FusedArgs {
   const DevState* state;
   int fpad;
   int nbls;                  // q0 / q1 have nbls + 1 rows; row nbls stays zero
+  int stream_once;           // CAL_LAYOUT_STREAM: every tile is read once per pass
 };
 
 enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_MODEL = 2, MODE_INIT = 3 };  // INIT: c = A^T (src * [w != 0]), calibration.py:875-902
@@ -243,8 +244,16 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     // written.
     const T* src = A.tiles + t_off + (long long)fbk * tile_elems;
     stage_t stage[L];
+    if (A.stream_once) {
+      // per-baseline tiles are read exactly once per pass: non-temporal loads keep them from displacing the gains and
+      // the other re-used arrays in L2 / Infinity Cache (measured: LOSS pass 4.09 -> 3.8 ms on HERA-350)
 #pragma unroll
-    for (int l = 0; l < L; ++l) stage[l] = *reinterpret_cast<const stage_t*>(src + (min(l * NS + ks, nvec - 1) * FB + f0));
+      for (int l = 0; l < L; ++l)
+        stage[l] = __builtin_nontemporal_load(reinterpret_cast<const stage_t*>(src + (min(l * NS + ks, nvec - 1) * FB + f0)));
+    } else {
+#pragma unroll
+      for (int l = 0; l < L; ++l) stage[l] = *reinterpret_cast<const stage_t*>(src + (min(l * NS + ks, nvec - 1) * FB + f0));
+    }
 
     // ---- forward
     T2* pv_par = s_pv + (tau & 1) * kWaves * FB;

@@ -128,3 +128,35 @@ def test_hera350_model_linearity_and_init_round_trip(hera350):
     _, _, c_r, c_i = s.get_params()
     assert relnorm(c_r, c1[0]) <= 1e-9 and relnorm(c_i, c1[1]) <= 1e-9
     s.close()
+
+
+def test_hera350_against_the_c_oracle(hera350):
+    """BASELINE config 2 at full size against the C / OpenMP restatement (oracle/ref_c.c), which is independent of the HIP
+    code and of the NumPy restatement it was checked against (tests/test_oracle_c.py): loss and every gradient in fp64,
+    with and without the "sum" regulariser, then a short fp32 Adam trajectory on the streaming layout."""
+    from oracle.ref_c import CRef
+
+    p, start = hera350
+    c = CRef(p, np.float64, nthreads=16)
+    s = solver_for(p, start, np.float64, "stream")
+    for reg in (False, True):
+        if reg:
+            pr, pi = float(np.sum(p.sky_r * p.wgts)) * 0.9, float(np.sum(p.sky_i * p.wgts)) * 1.1
+            c.set_regularization("sum", pr, pi)
+            s.set_regularization("sum", pr, pi)
+        loss, og_r, og_i, oc_r, oc_i = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        l2, hg_r, hg_i, hc_r, hc_i = s.eval_grads()
+        assert abs(l2 - loss) <= 1e-10 * abs(loss)
+        assert relnorm(hg_r, og_r) <= 1e-10 and relnorm(hg_i, og_i) <= 1e-10
+        assert relnorm(hc_r, oc_r) <= 1e-10 and relnorm(hc_i, oc_i) <= 1e-10
+    s.close()
+    # fp32 streaming kernel, 5 Adam updates, against the fp64 C trajectory
+    c.set_regularization(None)
+    og_r, og_i, oc_r, oc_i, olosses, _ = c.fit(start["g_r"], start["g_i"], start["c_r"], start["c_i"], 5, optimizer="Adam", learning_rate=1e-2)
+    s = solver_for(p, start, np.float32, "stream")
+    s.set_optimizer("Adam", learning_rate=1e-2)
+    losses, stopped, nupd = s.run(5, record=True, tol=0.0)
+    g_r, g_i, c_r, c_i = s.get_params()
+    assert np.allclose(losses, olosses, rtol=1e-4)
+    assert relnorm(g_r, og_r) <= 1e-3 and relnorm(c_r, oc_r) <= 1e-3 and relnorm(c_i, oc_i) <= 1e-3
+    s.close()

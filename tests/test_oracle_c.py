@@ -1,0 +1,82 @@
+"""The C / OpenMP restatement (oracle/ref_c.c) against the NumPy restatement (oracle/ref_numpy.py): two independently
+written CPU versions of calibration.py:1587-1656 + :663-668 must agree on loss, every gradient and on Adam / Adamax
+trajectories, with and without the "sum" regulariser, with a redundant (multi-baseline) group, for any thread count."""
+import numpy as np
+import pytest
+
+from calamity_amd import problem, synthetic
+from oracle import ref_numpy as R
+from oracle.ref_c import CRef
+
+
+def _setup(seed, with_sky, redundant):
+    p, truth, start = synthetic.make_problem(8, 32, f0=150e6, df=200e3, seed=seed, with_sky=with_sky)
+    if redundant:
+        p, start = synthetic.add_redundant_group(p, start, np.random.default_rng(seed))
+    rng = np.random.default_rng(seed + 7)
+    start = dict(start)
+    start["g_r"] = 1.0 + 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+    start["g_i"] = 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+    return p, start
+
+
+def _numpy_side(p, start, reg):
+    ch = problem.chunks_from_problem(p)
+    fg_r = problem.coeffs_to_chunks(p, start["c_r"], np.float64)
+    fg_i = problem.coeffs_to_chunks(p, start["c_i"], np.float64)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    priors = R.prior_sums(ch["sky_model_r"], ch["sky_model_i"], ch["wgts"]) if reg else None
+    return ch, fg_r, fg_i, a0, a1, priors
+
+
+@pytest.mark.parametrize("reg", [False, True])
+@pytest.mark.parametrize("redundant", [False, True])
+@pytest.mark.parametrize("nthreads", [1, 3])
+def test_loss_and_gradients(reg, redundant, nthreads):
+    p, start = _setup(11, reg, redundant)
+    ch, fg_r, fg_i, a0, a1, priors = _numpy_side(p, start, reg)
+    loss, gg_r, gg_i, gf_r, gf_i = R.loss_and_grads(start["g_r"], start["g_i"], fg_r, fg_i, ch["fg_comps"], ch["data_r"],
+                                                    ch["data_i"], ch["wgts"], a0, a1, *(priors if reg else ()))
+    c = CRef(p, np.float64, nthreads=nthreads)
+    if reg:
+        c.set_regularization("sum", *priors)
+    l2, cg_r, cg_i, cc_r, cc_i = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    assert abs(l2 - loss) <= 1e-12 * abs(loss)
+    assert c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"], grads=False) == pytest.approx(loss, rel=1e-12)
+    for a, b in ((cg_r, gg_r), (cg_i, gg_i), (cc_r, problem.coeffs_from_chunks(p, gf_r)), (cc_i, problem.coeffs_from_chunks(p, gf_i))):
+        assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("optimizer", ["Adam", "Adamax"])
+@pytest.mark.parametrize("reg", [False, True])
+def test_trajectory(optimizer, reg):
+    p, start = _setup(5, reg, True)
+    ch, fg_r, fg_i, a0, a1, priors = _numpy_side(p, start, reg)
+    nsteps = 12
+    # the NumPy loop: graph-build step unrecorded, so its recorded loss k is the loss before update k + 1
+    g_r, g_i, f_r, f_i, hist = R.fit_gains_and_foregrounds(
+        start["g_r"], start["g_i"], fg_r, fg_i, ch["data_r"], ch["data_i"], ch["wgts"], ch["fg_comps"], ch["corr_inds"],
+        maxsteps=nsteps - 1, tol=0.0, optimizer=optimizer, dtype=np.float64, learning_rate=1e-2,
+        sky_model_r=ch["sky_model_r"] if reg else None, sky_model_i=ch["sky_model_i"] if reg else None,
+        model_regularization="sum" if reg else None)
+    c = CRef(p, np.float64, nthreads=2)
+    if reg:
+        c.set_regularization("sum", *priors)
+    cg_r, cg_i, cc_r, cc_i, losses, _ = c.fit(start["g_r"], start["g_i"], start["c_r"], start["c_i"], nsteps,
+                                              optimizer=optimizer, learning_rate=1e-2)
+    assert np.allclose(losses[1:], hist["loss"], rtol=1e-10, atol=0)
+    assert np.linalg.norm(cg_r - g_r) <= 1e-10 * np.linalg.norm(g_r)
+    assert np.linalg.norm(cg_i - g_i) <= 1e-10 * np.linalg.norm(g_i) + 1e-14
+    assert np.linalg.norm(cc_r - problem.coeffs_from_chunks(p, f_r)) <= 1e-10 * np.linalg.norm(cc_r)
+    assert np.linalg.norm(cc_i - problem.coeffs_from_chunks(p, f_i)) <= 1e-10 * np.linalg.norm(cc_i)
+
+
+def test_fp32_build_close_to_fp64():
+    p, start = _setup(2, False, False)
+    c64 = CRef(p, np.float64)
+    c32 = CRef(p, np.float32)
+    l64, *g64 = c64.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    l32, *g32 = c32.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    assert abs(l32 - l64) <= 1e-5 * abs(l64)
+    for a, b in zip(g32, g64):
+        assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
