@@ -648,3 +648,51 @@ def calibrate_and_model_dpss(
         notebook_progressbar=notebook_progressbar, **fitting_kwargs,
     )
     return model, resid, gains, fitted_info
+
+
+def calibrate_and_model_mixed(
+    uvdata,
+    horizon=1.0,
+    min_dly=0.0,
+    offset=0.0,
+    ant_dly=0.0,
+    include_autos=False,
+    verbose=False,
+    red_tol=1.0,
+    red_tol_freq=0.5,
+    n_angle_bins=200,
+    notebook_progressbar=False,
+    use_redundancy=False,
+    use_tensorflow_to_derive_modeling_comps=False,
+    eigenval_cutoff=1e-10,
+    dtype_matinv=np.float64,
+    require_exact_angle_match=True,
+    angle_match_tol=1e-3,
+    grp_size_threshold=5,
+    model_comps_dict=None,
+    save_dict_to=None,
+    **fitting_kwargs,
+):
+    """Gains + foregrounds with DPSS vectors for baselines without frequency redundancy and joint covariance
+    eigenvectors for groups of baselines whose uv tracks overlap -- calibration.py:1353-1500 (same signature and
+    returns).  ``use_tensorflow_to_derive_modeling_comps`` is accepted for compatibility; the eigenproblems run on the
+    host either way."""
+    fitting_grps, blvecs, _, _ = modeling.get_uv_overlapping_grps_conjugated(
+        uvdata, red_tol=red_tol, include_autos=include_autos, red_tol_freq=red_tol_freq, n_angle_bins=n_angle_bins,
+        notebook_progressbar=notebook_progressbar, require_exact_angle_match=require_exact_angle_match,
+        angle_match_tol=angle_match_tol,
+    )
+    if model_comps_dict is None:
+        freqs = uvdata.freq_array[0] if np.ndim(uvdata.freq_array) == 2 else uvdata.freq_array
+        model_comps_dict = modeling.yield_mixed_comps(
+            fitting_grps, blvecs, freqs, eigenval_cutoff=eigenval_cutoff, ant_dly=ant_dly, horizon=horizon, offset=offset,
+            min_dly=min_dly, verbose=verbose, dtype=dtype_matinv, notebook_progressbar=notebook_progressbar,
+            grp_size_threshold=grp_size_threshold,
+        )
+    if save_dict_to is not None:
+        np.save(save_dict_to, model_comps_dict)
+    (model, resid, gains, fitted_info) = calibrate_and_model_tensor(
+        uvdata=uvdata, fg_model_comps_dict=model_comps_dict, include_autos=include_autos, verbose=verbose,
+        notebook_progressbar=notebook_progressbar, use_redundancy=use_redundancy, **fitting_kwargs,
+    )
+    return model, resid, gains, fitted_info

@@ -10,6 +10,7 @@ import datetime
 import numpy as np
 from scipy.signal import windows
 
+from . import simple_cov
 from .utils import PBARS, echo
 
 
@@ -133,4 +134,154 @@ def yield_pbl_dpss_model_comps(
             operator_cache=operator_cache,
             eigenval_cutoff=eigenval_cutoff,
         )
+    return modeling_vectors
+
+
+def _freqs_of(uvdata):
+    return uvdata.freq_array[0] if np.ndim(uvdata.freq_array) == 2 else uvdata.freq_array
+
+
+def get_uv_overlapping_grps_conjugated(
+    uvdata,
+    red_tol=1.0,
+    include_autos=False,
+    red_tol_freq=0.5,
+    n_angle_bins=200,
+    notebook_progressbar=False,
+    require_exact_angle_match=True,
+    angle_match_tol=1e-3,
+):
+    """Fitting groups of redundant groups whose uv tracks touch somewhere in the band -- modeling.py:84-252.
+
+    Two redundant groups are *connected* when they fall in the same angular bin (and, by default, at the same angle to
+    within ``angle_match_tol``), their ``|b| nu / c`` ranges overlap, and some pair of channels brings them within
+    ``red_tol_freq`` wavelengths of each other in the uv plane (or of the conjugate point, in which case the second
+    group is re-oriented).  Groups are then labelled greedily in order of (angle, length): an unlabelled group founds a
+    fitting group and pulls in its unlabelled connections, a labelled one pulls its unlabelled connections into its
+    parent.  Same return tuple as the reference: (fitting_grps, fitting_vec_centers, connections, grp_labels).
+
+    Data structures (sets of tuples, insertion in bin / group order) are kept as in the reference so that ties are broken
+    the same way.  The reference's re-orientation branch leaves the un-flipped key behind in its bookkeeping and would
+    raise KeyError in the labelling loop; here the flipped key replaces it.
+    """
+    _, red_grps, vec_bin_centers, _ = get_redundant_grps_data(
+        uvdata, include_autos=include_autos, tol=red_tol, remove_redundancy=False
+    )
+    red_grps = [list(g) for g in red_grps]
+    vec_bin_centers = [np.asarray(v, dtype=np.float64) for v in vec_bin_centers]
+    freqs = np.asarray(_freqs_of(uvdata), dtype=np.float64)
+    fmin, fmax = freqs.min(), freqs.max()
+    dangle = np.pi / n_angle_bins
+
+    def angle(vbc):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.arctan(vbc[1] / vbc[0])
+
+    bins = {i: [] for i in range(n_angle_bins)}
+    for n, vbc in enumerate(vec_bin_centers):
+        if np.abs(vbc[0]) > 0.0:
+            b = int(np.min([np.round((angle(vbc) + np.pi / 2) / dangle), n_angle_bins - 2]))
+        else:
+            b = n_angle_bins - 1
+        bins[b].append(n)
+
+    def closest_approach(p0, p1):
+        # smallest uv distance between any channel of track 0 and any channel of track 1 (wavelengths)
+        u0, v0 = p0[0] * freqs / 3e8, p0[1] * freqs / 3e8
+        u1, v1 = p1[0] * freqs / 3e8, p1[1] * freqs / 3e8
+        best = np.inf
+        for lo in range(0, len(freqs), 256):
+            d = np.sqrt(np.abs(u0[None, :] - u1[lo : lo + 256, None]) ** 2.0 + (v0[None, :] - v1[lo : lo + 256, None]) ** 2.0)
+            best = min(best, d.min())
+        return best
+
+    vbc_hash, connections = {}, {}
+    for b in PBARS[notebook_progressbar](range(n_angle_bins), disable=True):
+        nums = bins[b]
+        for i, n0 in enumerate(nums):
+            key0 = tuple(red_grps[n0])
+            if key0 not in connections:
+                connections[key0] = set({})
+                vbc_hash[key0] = vec_bin_centers[n0]
+            vbc0 = vec_bin_centers[n0]
+            for n1 in nums[i + 1 :]:
+                vbc1 = vec_bin_centers[n1]
+                lo0, lo1 = fmin * np.linalg.norm(vbc0) / 3e8, fmin * np.linalg.norm(vbc1) / 3e8
+                hi0, hi1 = fmax * np.linalg.norm(vbc0) / 3e8, fmax * np.linalg.norm(vbc1) / 3e8
+                if not ((lo0 > lo1 and lo0 < hi1) or (lo1 > lo0 and lo1 < hi0)):
+                    continue
+                if require_exact_angle_match and not np.abs(angle(vbc0) - angle(vbc1)) <= angle_match_tol:
+                    continue
+                if closest_approach(vbc0, vbc1) <= red_tol_freq:
+                    pass
+                elif closest_approach(vbc0, -vbc1) <= red_tol_freq:
+                    red_grps[n1] = [ap[::-1] for ap in red_grps[n1]]
+                    vec_bin_centers[n1] = vbc1 = -vbc1
+                else:
+                    continue
+                key1 = tuple(red_grps[n1])
+                connections[key0].add(key1)
+                if key1 not in connections:
+                    connections[key1] = set({})
+                    vbc_hash[key1] = vbc1
+                connections[key1].add(key0)
+
+    keys = list(vbc_hash)
+    lengths = [np.linalg.norm(vbc_hash[k]) for k in keys]
+    angles = [np.arccos(vbc_hash[k][0] / ln) for k, ln in zip(keys, lengths)]
+    order = [keys[n] for n in sorted(range(len(keys)), key=lambda n: (angles[n], lengths[n]))]
+    fitting_grps, grp_labels = {}, {}
+    for red_grp in order:
+        if red_grp not in grp_labels:
+            fitting_grps[red_grp] = [red_grp]
+            grp_labels[red_grp] = red_grp
+        parent = grp_labels[red_grp]
+        for connection in connections[red_grp]:
+            if connection not in grp_labels:
+                fitting_grps[parent].append(connection)
+                grp_labels[connection] = parent
+    fitting_grps = list(fitting_grps.values())
+    fitting_vec_centers = [[vbc_hash[red_grp] for red_grp in fit_grp] for fit_grp in fitting_grps]
+    return fitting_grps, fitting_vec_centers, connections, grp_labels
+
+
+def yield_mixed_comps(
+    fitting_grps,
+    fitting_blvecs,
+    freqs,
+    eigenval_cutoff=1e-10,
+    ant_dly=0.0,
+    horizon=1.0,
+    offset=0.0,
+    min_dly=0.0,
+    verbose=False,
+    dtype=np.float64,
+    notebook_progressbar=False,
+    use_tensorflow=False,
+    grp_size_threshold=5,
+):
+    """Modeling vectors for jointly fitted groups -- modeling.py:377-474.
+
+    Fitting groups of at most ``grp_size_threshold`` redundant groups are split into per-redundant-group DPSS bases
+    (keyed ``(red_grp,)``; note the reference passes ``ant_dly`` as the DPSS offset here, :447-455); larger ones get
+    the leading eigenvectors of the analytic covariance, ``(Nfreqs * len(fit_grp), Ncomponents)``, one ``Nfreqs`` row
+    block per redundant group.
+    """
+    operator_cache = {}
+    modeling_vectors = {}
+    for grpnum in PBARS[notebook_progressbar](range(len(fitting_grps)), disable=not verbose):
+        fit_grp = tuple(fitting_grps[grpnum])
+        blvecs = np.asarray(fitting_blvecs[grpnum], dtype=np.float64).reshape(-1, 3)
+        bllens = np.linalg.norm(blvecs, axis=1)
+        if len(fit_grp) <= grp_size_threshold:
+            for red_grp, bllen in zip(fit_grp, bllens):
+                modeling_vectors[(red_grp,)] = yield_dpss_model_comps_bl_grp(
+                    freqs=freqs, length=bllen, offset=ant_dly, horizon=horizon, min_dly=min_dly,
+                    operator_cache=operator_cache, eigenval_cutoff=eigenval_cutoff,
+                )
+        else:
+            modeling_vectors[fit_grp] = simple_cov.yield_simple_multi_baseline_model_comps(
+                blvecs=blvecs, ant_dly=ant_dly, offset=offset, min_dly=min_dly, horizon=horizon, dtype=dtype, freqs=freqs,
+                eigenval_cutoff=eigenval_cutoff, verbose=verbose,
+            )
     return modeling_vectors

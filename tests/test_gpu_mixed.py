@@ -1,0 +1,88 @@
+"""GPU tests of the mixed DPSS / joint-covariance entry point (calibration.py:1353-1500), modelled on the reference's
+test_calibration.py:772-812: fitting groups of several redundant groups share one coefficient vector and each baseline
+uses its own Nfreqs row block of the group's basis."""
+import numpy as np
+import pytest
+
+from calamity_amd import cal_utils, calibration, modeling
+from calamity_amd.uvcompat import SimpleUVData
+from oracle.ref_c import CRef
+
+pytestmark = pytest.mark.gpu
+
+
+def rms(x):
+    return np.sqrt(np.mean(np.abs(x) ** 2.0))
+
+
+def line_array(nfreqs=64, seed=0, eor_db=-60.0):
+    """East-west Golomb ruler (uv tracks of neighbouring lengths overlap) + flat-ish spectrum point sources."""
+    rng = np.random.default_rng(seed)
+    marks = np.array([0.0, 1.0, 4.0, 10.0, 12.0, 17.0]) * 2.0
+    antpos = np.stack([marks, np.zeros(6), np.zeros(6)], axis=1)
+    freqs = 100e6 + 20e6 / nfreqs * np.arange(nfreqs)
+    antpairs = [(i, j) for i in range(6) for j in range(i + 1, 6)]
+    uvd = SimpleUVData(antpos, antpairs, freqs, np.array([2458000.0]))
+    nsrc = 10
+    l = rng.uniform(-0.9, 0.9, size=nsrc)
+    flux = rng.uniform(0.5, 2.0, size=(nsrc, 1)) * (freqs[None, :] / freqs[0]) ** rng.uniform(-1.0, -0.5, size=(nsrc, 1))
+    for n in range(uvd.Nblts):
+        b = antpos[uvd.ant_2_array[n], 0] - antpos[uvd.ant_1_array[n], 0]
+        tau = l * b / 299792458.0
+        uvd.data_array[n, 0, :, 0] = np.sum(flux * np.exp(-2j * np.pi * tau[:, None] * freqs[None, :]), axis=0)
+    amp = rms(uvd.data_array) * 10.0 ** (eor_db / 20.0)
+    uvd.data_array = uvd.data_array + amp * (rng.standard_normal(uvd.data_array.shape) + 1j * rng.standard_normal(uvd.data_array.shape)) / np.sqrt(2)
+    return uvd
+
+
+def test_mixed_problem_parity_with_c_oracle():
+    """Loss and gradients of a problem whose fitting groups span several redundant groups (row blocks), fp64 and fp32,
+    both layouts, against the C restatement."""
+    from calamity_amd.solver import HipFitSolver
+
+    uvd = line_array()
+    freqs = uvd.freq_array[0] if np.ndim(uvd.freq_array) == 2 else uvd.freq_array
+    grps, centers, _, _ = modeling.get_uv_overlapping_grps_conjugated(uvd)
+    comps = modeling.yield_mixed_comps(grps, centers, freqs, ant_dly=2.0 / 0.3, grp_size_threshold=1)
+    assert max(len(k) for k in comps) == 8
+    gains = cal_utils.blank_uvcal_from_uvdata(uvd)
+    ants_map = {ant: i for i, ant in enumerate(gains.ant_array)}
+    p, corr_inds = calibration.tensorize_fg_model_comps_dict(comps, ants_map, nfreqs=uvd.Nfreqs, dtype=np.float64, grp_size_threshold=1)
+    d_r, d_i, w = calibration.tensorize_data(uvd, corr_inds, ants_map, polarization="xx", time=uvd.time_array[0], dtype=np.float64,
+                                             data_scale_factor=rms(uvd.data_array))
+    p.data_r, p.data_i, p.wgts = (calibration._flatten(x, p) for x in (d_r, d_i, w))
+    rng = np.random.default_rng(1)
+    g_r = 1.0 + 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+    g_i = 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+    c_r = rng.standard_normal(p.ncoeffs)
+    c_i = rng.standard_normal(p.ncoeffs)
+    ref = CRef(p, np.float64).loss_grads(g_r, g_i, c_r, c_i)
+    for dtype, tol_l, tol_g in ((np.float64, 1e-10, 1e-10), (np.float32, 1e-5, 1e-4)):
+        for layout in ("stream", "shared"):
+            s = HipFitSolver(dtype=dtype)
+            s.set_problem(p, layout=layout)
+            s.set_params(g_r, g_i, c_r, c_i)
+            out = s.eval_grads()
+            assert abs(out[0] - ref[0]) <= tol_l * abs(ref[0])
+            for a, b in zip(out[1:], ref[1:]):
+                assert np.linalg.norm(np.asarray(a, np.float64) - b) <= tol_g * np.linalg.norm(b)
+            s.close()
+
+
+@pytest.mark.parametrize("model_regularization", ["sum", "post_hoc"])
+def test_calibrate_and_model_mixed(model_regularization):
+    """test_calibration.py:772-812: gains start 1 % off, the foreground model is frozen at the least-squares projection
+    of the data on the mixed basis; afterwards rms(model) >= 100 rms(resid)."""
+    uvd = line_array()
+    g0 = cal_utils.blank_uvcal_from_uvdata(uvd)
+    rng = np.random.default_rng(3)
+    g0.gain_array = g0.gain_array + 1e-2 * (rng.standard_normal(g0.gain_array.shape) + 1j * rng.standard_normal(g0.gain_array.shape))
+    model, resid, gains, fit_history = calibration.calibrate_and_model_mixed(
+        min_dly=0.0, offset=0.0, ant_dly=2.0 / 0.3, red_tol_freq=0.5, uvdata=uvd, gains=g0, verbose=False, use_redundancy=False,
+        sky_model=None, freeze_model=True, maxsteps=3000, tol=1e-10, correct_resid=False, correct_model=False,
+        grp_size_threshold=1, model_regularization=model_regularization,
+    )
+    resid = cal_utils.apply_gains(resid, gains)
+    model = cal_utils.apply_gains(model, gains)
+    assert rms(model.data_array) >= 1e2 * rms(resid.data_array)
+    assert len(fit_history) >= 1
