@@ -14,6 +14,7 @@ gradient-descent fitter: ``calibrate_and_model_dpss`` (:1503-1584) -> ``calibrat
 
 There is no CPU fallback: without the HIP library / a GPU these functions raise.
 """
+import argparse
 import copy
 import datetime
 import json
@@ -21,7 +22,7 @@ import os
 
 import numpy as np
 
-from . import cal_utils, modeling
+from . import cal_utils, modeling, utils
 from .problem import FitProblem, coeffs_from_chunks, coeffs_to_chunks, problem_from_chunks
 from .solver import OPTIMIZERS, HipFitSolver
 from .utils import PBARS, echo
@@ -240,18 +241,29 @@ def _flatten(chunks, prob):
     return np.concatenate([np.asarray(c).reshape(-1, prob.nfreqs) for c in chunks])
 
 
+# device selection of the file driver (calibration.py:1741-1753): which GPU the solvers are created on, and a cap on
+# the device memory one fit may take
+_DEVICE = {"index": None, "memory_limit_gib": None}
+
+
 def get_solver(fg_model_comps, dtype=np.float32, layout=None, device=None):
     """The HipFitSolver that holds these components on the GPU (created once per component set and dtype)."""
     dtype = np.dtype(dtype)
     cache = fg_model_comps.__dict__.setdefault("_solvers", {})
     layout = layout or os.environ.get("CALAMITY_AMD_LAYOUT", "shared")
-    device = int(os.environ.get("CALAMITY_AMD_DEVICE", "0")) if device is None else device
+    if device is None:
+        device = _DEVICE["index"] if _DEVICE["index"] is not None else int(os.environ.get("CALAMITY_AMD_DEVICE", "0"))
     key = (dtype.str, layout, device)
     if key not in cache:
         shell = copy.copy(fg_model_comps)
         shell.data_r = shell.data_i = shell.wgts = None
         solver = HipFitSolver(dtype=dtype, device=device)
         solver.set_problem(shell, layout=layout)
+        limit = _DEVICE["memory_limit_gib"]
+        if limit is not None and solver.memory_bytes() > limit * 2.0**30:
+            used = solver.memory_bytes() / 2.0**30
+            solver.close()
+            raise MemoryError(f"the fit needs {used:.2f} GiB of device memory, gpu_memory_limit is {limit} GiB")
         cache[key] = solver
     return cache[key]
 
@@ -696,3 +708,194 @@ def calibrate_and_model_mixed(
         notebook_progressbar=notebook_progressbar, use_redundancy=use_redundancy, **fitting_kwargs,
     )
     return model, resid, gains, fitted_info
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# weights from autocorrelations, file / command-line driver: calibration.py:916-960, :1659-1942
+# ------------------------------------------------------------------------------------------------------------------
+def get_auto_weights(uvdata, delay_extent=25.0):
+    """Inverse-variance weights from DPSS-smoothed autocorrelations -- calibration.py:916-960.
+
+    Every autocorrelation spectrum is fitted (least squares on its unflagged channels) with the DPSS modes of a
+    zero-length baseline widened by ``delay_extent`` ns; the weight of baseline (i, j) is ``1 / (auto_i auto_j)`` on its
+    unflagged samples.  Returns a UVFlag-like object in flag mode whose ``weights_array`` holds the weights.
+    """
+    freqs = uvdata.freq_array[0] if np.ndim(uvdata.freq_array) == 2 else uvdata.freq_array
+    dpss_components = modeling.yield_dpss_model_comps_bl_grp(0.0, freqs, offset=delay_extent)
+    if type(uvdata).__module__.startswith("pyuvdata"):
+        from pyuvdata import UVFlag
+
+        data_weights = UVFlag(uvdata, mode="flag")
+    else:
+        from .uvcompat import SimpleUVFlag
+
+        data_weights = SimpleUVFlag(uvdata, mode="flag")
+    data_weights.weights_array = np.zeros(uvdata.data_array.shape)
+    auto_fit = {}
+    bls = uvdata.get_antpairpols()
+    for bl in bls:
+        if bl[0] == bl[1]:
+            rows = []
+            for ds, fs in zip(np.atleast_2d(uvdata.get_data(bl)), ~np.atleast_2d(uvdata.get_flags(bl))):
+                coeffs = np.linalg.lstsq(dpss_components[fs], ds[fs].real, rcond=None)[0]
+                rows.append(dpss_components @ coeffs)
+            auto_fit[bl] = np.atleast_2d(np.asarray(rows))
+    for bl in bls:
+        smooth_weights = 1.0 / (auto_fit[bl[0], bl[0], bl[-1]] * auto_fit[bl[1], bl[1], bl[-1]])
+        smooth_weights = smooth_weights * ~np.atleast_2d(uvdata.get_flags(bl))
+        dinds = data_weights.antpair2ind(*bl[:2])
+        polnum = np.where(data_weights.polarization_array == polstr2num(bl[-1], x_orientation=data_weights.x_orientation))[0][0]
+        data_weights.weights_array[dinds, 0, :, polnum] = smooth_weights
+    return data_weights
+
+
+def _read_uvdata(files):
+    from .uvcompat import read_container
+
+    if is_uvdata(files):
+        return files
+    files = [files] if isinstance(files, str) else list(files)
+    try:
+        from pyuvdata import UVData
+    except ImportError:
+        if len(files) != 1:
+            raise ImportError("reading several data files into one object needs pyuvdata")
+        return read_container(files[0])
+    uvd = UVData()
+    uvd.read(files)
+    return uvd
+
+
+def _read_uvcal(files):
+    from .uvcompat import read_container
+
+    if is_uvcal(files):
+        return files
+    files = [files] if isinstance(files, str) else list(files)
+    try:
+        from pyuvdata import UVCal
+    except ImportError:
+        if len(files) != 1:
+            raise ImportError("reading several gain files into one object needs pyuvdata")
+        return read_container(files[0])
+    uvc = UVCal()
+    uvc.read_calfits(files)
+    return uvc
+
+
+def read_calibrate_and_model_dpss(
+    input_data_files,
+    input_model_files=None,
+    input_gain_files=None,
+    resid_outfilename=None,
+    gain_outfilename=None,
+    model_outfilename=None,
+    fitted_info_outfilename=None,
+    x_orientation="east",
+    clobber=False,
+    bllen_min=0.0,
+    bllen_max=np.inf,
+    bl_ew_min=0.0,
+    ex_ants=None,
+    select_ants=None,
+    gpu_index=None,
+    gpu_memory_limit=None,
+    precision=32,
+    use_autocorrs_in_weights=False,
+    **calibration_kwargs,
+):
+    """File driver of the DPSS fit -- calibration.py:1659-1817 (same arguments, returns and output files).
+
+    Inputs are paths (read with pyuvdata when it is installed; without it, containers written by this package) or the
+    objects themselves.  ``gpu_index`` picks the MI355X the solvers are created on (default: device 0, all of them are
+    visible); ``gpu_memory_limit`` [GiB] makes a fit that needs more device memory raise ``MemoryError`` instead of
+    configuring an allocator pool.  As in the reference the baseline cuts are applied to the data only (:1767-1783
+    select on ``uvd`` twice and never on the model) and ``fitted_info_outfilename`` is accepted but nothing is written.
+    """
+    uvd = _read_uvdata(input_data_files)
+    weights = get_auto_weights(uvd) if use_autocorrs_in_weights else None
+    utils.select_baselines(uvd, bllen_min=bllen_min, bllen_max=bllen_max, bl_ew_min=bl_ew_min, ex_ants=ex_ants, select_ants=select_ants)
+    uvd_model = _read_uvdata(input_model_files) if input_model_files is not None else None
+    if uvd_model is not None:
+        utils.select_baselines(uvd, bllen_min=bllen_min, bllen_max=bllen_max, bl_ew_min=bl_ew_min)
+    uvc = _read_uvcal(input_gain_files) if input_gain_files is not None else None
+    dtype = {32: np.float32, 64: np.float64}[precision]
+    saved = dict(_DEVICE)
+    _DEVICE["index"] = gpu_index
+    _DEVICE["memory_limit_gib"] = gpu_memory_limit
+    try:
+        model_fit, resid_fit, gains_fit, fit_info = calibrate_and_model_dpss(
+            uvdata=uvd, sky_model=uvd_model, gains=uvc, dtype=dtype, weights=weights, **calibration_kwargs
+        )
+    finally:
+        _DEVICE.update(saved)
+    if resid_outfilename is not None:
+        resid_fit.write_uvh5(resid_outfilename, clobber=clobber)
+    if gain_outfilename is not None:
+        gains_fit.x_orientation = x_orientation
+        gains_fit.write_calfits(gain_outfilename, clobber=clobber)
+    if model_outfilename is not None:
+        model_fit.write_uvh5(model_outfilename, clobber=clobber)
+    fit_info["calibration_kwargs"] = calibration_kwargs
+    fit_info["calibration_kwargs"]["dtype"] = dtype
+    return model_fit, resid_fit, gains_fit, fit_info
+
+
+def input_output_parser():
+    """Input / output / selection / device arguments -- calibration.py:1820-1858."""
+    ap = argparse.ArgumentParser()
+    sp = ap.add_argument_group("Input and Output Arguments.")
+    sp.add_argument("--input_data_files", type=str, nargs="+", help="paths to data files to calibrate.", required=True)
+    sp.add_argument("--input_model_files", type=str, nargs="+", help="paths to model files to set overal amplitude and phase.")
+    sp.add_argument("--input_gain_files", type=str, nargs="+", help="paths to gains to use as a staring point.")
+    sp.add_argument("--resid_outfilename", type=str, default=None, help="postfix for resid output file.")
+    sp.add_argument("--model_outfilename", type=str, default=None, help="postfix for foreground model file.")
+    sp.add_argument("--gain_outfilename", type=str, default=None, help="path for writing fitted gains.")
+    # the reference's default is the string "False" (truthy), :1831
+    sp.add_argument("--clobber", action="store_true", default="False", help="Overwrite existing outputs.")
+    sp.add_argument("--x_orientation", default="east", type=str, help="x_orientation of feeds to set in output gains.")
+    sp.add_argument("--bllen_min", default=0.0, type=float, help="minimum baseline length to include in calibration and outputs.")
+    sp.add_argument("--bllen_max", default=np.inf, type=float, help="maximum baseline length to include in calbration and outputs.")
+    sp.add_argument("--bl_ew_min", default=0.0, type=float, help="minimum EW baseline component to include in calibration and outputs.")
+    sp.add_argument("--ex_ants", default=None, type=int, nargs="+", help="Antennas to exclude from calibration and modeling.")
+    sp.add_argument("--select_ants", default=None, type=int, nargs="+", help="Antennas to select exclusively for calibration and modeling.")
+    sp.add_argument("--gpu_index", default=None, type=int, help="Index of GPU to run on (if on a multi-GPU machine).")
+    sp.add_argument("--gpu_memory_limit", default=None, type=int, help="Limit GPU memory use to this many GBytes.")
+    sp.add_argument("--precision", default=32, type=int, help="Number of bits to keep track of.")
+    return ap
+
+
+def fitting_argparser():
+    """General fitting arguments -- calibration.py:1861-1930."""
+    ap = input_output_parser()
+    sp = ap.add_argument_group("General Fitting Arguments.")
+    sp.add_argument("--tol", type=float, default=1e-14, help="Stop gradient descent after cost function converges to within this value.")
+    sp.add_argument("--optimizer", type=str, default="Adamax", help="First order optimizer to use for gradient descent.")
+    sp.add_argument("--maxsteps", type=int, default=10000, help="Max number of steps to iterate during optimization.")
+    sp.add_argument("--verbose", default=False, action="store_true", help="lots of text ouputs.")
+    sp.add_argument("--use_min", default=False, action="store_true",
+                    help="Use params for mimimum cost function derived. Otherwise, use the params last visited by the descent. Avoids momentum overshoot.")
+    sp.add_argument("--use_redundancy", default=False, action="store_true", help="Model redundant visibilities with the same set of foreground parameters.")
+    sp.add_argument("--correct_model", default=True, action="store_true", help="Remove gain effects from foreground model.")
+    sp.add_argument("--correct_resid", default=False, action="store_true", help="Apply fitted gains to the fitted residuals.")
+    sp.add_argument("--graph_mode", default=False, action="store_true", help="Accepted for compatibility; there is no tracing compiler on this path.")
+    sp.add_argument("--init_guesses_from_previous_time_step", default=False, action="store_true",
+                    help="initialize gain and foreground guesses from previous time step when calibrating multiple times.")
+    sp.add_argument("--learning_rate", type=float, default=1e-2, help="gradient descent learning rate.")
+    sp.add_argument("--red_tol", type=float, default=1.0, help="Tolerance for determining redundancy between baselines [meters].")
+    sp.add_argument("--skip_threshold", type=float, default=0.5, help="Skip and flag time/polarization if more then this fractionf of data is flagged.")
+    sp.add_argument("--model_regularization", type=str, default="post_hoc")
+    sp.add_argument("--nsamples_in_weights", default=False, action="store_true", help="Weight contributions to MSE by nsamples.")
+    sp.add_argument("--use_model_snr_weights", default=False, action="store_true", help="If True, weight contributions to MSE as proportional to SNR.")
+    sp.add_argument("--use_autocorrs_in_weights", default=False, action="store_true", help="If True, use autocorrelations to derive relative SNR weights.")
+    return ap
+
+
+def dpss_fit_argparser():
+    """DPSS-specific arguments on top of the general ones -- calibration.py:1933-1942."""
+    ap = fitting_argparser()
+    sp = ap.add_argument_group("DPSS Specific Fitting Arguments.")
+    sp.add_argument("--horizon", default=1.0, type=float, help="Fraction of horizon delay to model with DPSS modes.")
+    sp.add_argument("--min_dly", default=0.0, type=float, help="Minimum delay [ns] to model with DPSS modes.")
+    sp.add_argument("--offset", default=0.0, type=float, help="Offset from horizon delay [ns] to model with DPSS modes.")
+    return ap

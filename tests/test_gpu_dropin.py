@@ -191,3 +191,51 @@ def test_calibrate_and_model_dpss_post_hoc_heavy_flags():
         correct_model=True, model_regularization="post_hoc",
     )
     assert np.all(np.isfinite(resid.data_array)) and np.all(np.isfinite(model.data_array)) and np.all(np.isfinite(gains.gain_array))
+
+
+def test_read_calibrate_and_model_dpss(tmp_path, monkeypatch):
+    """test_calibration.py:880-940: files in, files out, then the same through the argument parser with --precision 64
+    and autocorrelation weights; plus the device-memory cap."""
+    import os
+    import sys
+
+    uvd, sky, vecs = synthetic.make_uvdata(nants=5, nfreqs=48, ntimes=1, seed=4, redundant=True)
+    # the driver derives weights from autocorrelations: add flat autos to the data set
+    nants = uvd.antenna_positions.shape[0]
+    pairs = uvd.get_antpairs() + [(a, a) for a in range(nants)]
+    full = uvcompat.SimpleUVData(uvd.antenna_positions, pairs, uvd.freq_array[0], np.unique(uvd.time_array), x_orientation="east")
+    for ap in uvd.get_antpairs():
+        full.data_array[full.antpair2ind(ap)] = uvd.data_array[uvd.antpair2ind(ap)]
+    for a in range(nants):
+        full.data_array[full.antpair2ind((a, a))] = 50.0 + a
+    data_path, gain_path = str(tmp_path / "data.uvh5"), str(tmp_path / "gains_input.calfits")
+    full.write_uvh5(data_path)
+    g = cal_utils.blank_uvcal_from_uvdata(uvd)
+    g.x_orientation = "east"
+    g.write_calfits(gain_path)
+    outs = [str(tmp_path / n) for n in ("resid_fit.uvh5", "model_fit.uvh5", "gains_fit.calfits")]
+    model, resid, gains, info = calibration.read_calibrate_and_model_dpss(
+        input_data_files=data_path, input_model_files=data_path, input_gain_files=gain_path, resid_outfilename=outs[0],
+        model_outfilename=outs[1], gain_outfilename=outs[2], maxsteps=50,
+    )
+    assert info["calibration_kwargs"]["dtype"] == np.float32
+    # the strict east-west bound (|b_ew| > 0, utils.py:29) cuts the autos and any purely north-south baseline
+    pos = uvd.antenna_positions
+    assert set(model.get_antpairs()) == {ap for ap in uvd.get_antpairs() if abs(pos[ap[0], 0] - pos[ap[1], 0]) > 0}
+    for fn in outs:
+        assert os.path.exists(fn)
+        os.remove(fn)
+    monkeypatch.setattr(sys, "argv", [sys.argv[0], "--input_data_files", data_path, "--input_model_files", data_path,
+                                      "--input_gain_files", gain_path, "--resid_outfilename", outs[0], "--model_outfilename", outs[1],
+                                      "--gain_outfilename", outs[2], "--precision", "64", "--use_autocorrs_in_weights",
+                                      "--maxsteps", "50", "--gpu_index", "0"])
+    args = calibration.dpss_fit_argparser().parse_args()
+    _, _, gains2, info = calibration.read_calibrate_and_model_dpss(**vars(args))
+    assert info["calibration_kwargs"]["dtype"] == np.float64
+    assert gains2.x_orientation == "east" and np.all(np.isfinite(gains2.gain_array))
+    for fn in outs:
+        assert os.path.exists(fn)
+    back = uvcompat.read_container(outs[2])
+    assert np.array_equal(back.gain_array, gains2.gain_array)
+    with pytest.raises(MemoryError):
+        calibration.read_calibrate_and_model_dpss(input_data_files=data_path, maxsteps=5, gpu_memory_limit=1e-6)
