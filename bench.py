@@ -262,6 +262,32 @@ def main():
         }
         s2.close()
 
+    # measured streaming peaks of this box and, for orientation, the only configuration the
+    # reference publishes a rate for (tutorial notebook: 15 antennas, 105 baselines x 200 channels, Adamax, 61.77 steps/s
+    # on a P100) -- single-GPU runs only, after the solvers above have released their memory
+    peaks, tutorial = None, None
+    if rank == 0 and world == 1 and not args.no_shared:
+        for s_ in solvers:
+            s_.synchronize()
+        try:
+            rd, cp = _lib.stream_peak(0, 4 << 30, 5)
+            peaks = {"read_GBps": rd, "copy_GBps": cp, "how": "cal_device_stream_peak: 4 GiB, best of 5, 16-byte non-temporal loads / plain copy"}
+        except Exception as e:  # noqa: BLE001 -- a probe must not take the benchmark down
+            peaks = {"error": str(e)}
+        tp, _, tstart = synthetic.make_problem(15, 200, f0=100e6, df=100e3, seed=0)
+        ts = HipFitSolver(dtype=np.float32)
+        ts.set_problem(tp, layout="shared")
+        ts.set_params(tstart["g_r"], tstart["g_i"], tstart["c_r"], tstart["c_i"])
+        ts.set_optimizer("Adamax", learning_rate=1e-2)
+        ts.run(200, record=False)
+        ts.synchronize()
+        t0 = time.perf_counter()
+        ts.run(5000, record=True, tol=0.0)
+        ts.synchronize()
+        tutorial = {"steps_per_s": 5000 / (time.perf_counter() - t0), "config": f"{tp.nants} antennas, {tp.nbls} baselines x 200 channels, Adamax lr 1e-2, fp32",
+                    "reference_published_steps_per_s": 61.77, "reference_hardware": "Tesla P100, TensorFlow eager (examples/Calamity_Tutorial.ipynb:1178)"}
+        ts.close()
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = args.steps * ntimes / dt
@@ -306,12 +332,15 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": tim["algorithmic_bytes_per_launch"],
+                "peak_measured": peaks,
+                "frac_of_measured_read_peak": (achieved / peaks["read_GBps"]) if peaks and "read_GBps" in peaks else None,
             },
             "extra": {
                 "chi2_evals_per_s": chi2_rate,
                 "setup_s": t_setup,
                 "device_memory_GB": solvers[0].memory_bytes() / 1e9 * len(solvers),
                 "shared_layout": shared,
+                "tutorial_notebook_config": tutorial,
             },
         }
         if not args.no_cpu_baseline:

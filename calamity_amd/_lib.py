@@ -77,6 +77,7 @@ SYMBOLS = {
     "cal_version": (C.c_char_p, []),
     "cal_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "cal_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "cal_device_stream_peak": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cal_solver_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
     "cal_solver_destroy": (C.c_int, [_P]),
     "cal_solver_set_problem": (C.c_int, [_P, C.POINTER(ProblemDesc)]),
@@ -145,3 +146,10 @@ def device_info(device=0):
     cus = C.c_int32(0)
     check(load().cal_device_info(device, name, 256, C.byref(mem), C.byref(cus)))
     return dict(name=name.value.decode(), total_mem_bytes=mem.value, compute_units=cus.value)
+
+
+def stream_peak(device=0, nbytes=4 << 30, reps=5):
+    """Measured streaming peaks of the device in GB/s: (read-only sweep, copy)."""
+    rd, cp = C.c_double(0.0), C.c_double(0.0)
+    check(load().cal_device_stream_peak(device, nbytes, reps, C.byref(rd), C.byref(cp)))
+    return rd.value, cp.value

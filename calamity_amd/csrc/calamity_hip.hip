@@ -1057,6 +1057,50 @@ int cal_device_info(int device, char* name, size_t name_len, int64_t* total_mem_
   return CAL_OK;
 }
 
+int cal_device_stream_peak(int device, size_t bytes, int reps, double* read_gbps, double* copy_gbps) {
+  if (bytes < (64u << 20) || reps < 1) return fail(CAL_ERR_INVALID, "cal_device_stream_peak: need >= 64 MiB and >= 1 repetition");
+  HIP_TRY(hipSetDevice(device));
+  const size_t n = bytes / 16;  // float4 elements
+  void *src = nullptr, *dst = nullptr;
+  float* sink = nullptr;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipMalloc(&src, n * 16));
+  if (hipMalloc(&dst, n * 16) != hipSuccess) { (void)hipFree(src); return fail(CAL_ERR_HIP, "cal_device_stream_peak: out of device memory"); }
+  HIP_TRY(hipMalloc((void**)&sink, 1 << 20));
+  HIP_TRY(hipMemset(src, 0, n * 16));
+  HIP_TRY(hipMemset(dst, 0, n * 16));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, device));
+  const int grid = p.multiProcessorCount * 8;
+  double best_r = 0, best_c = 0;
+  for (int r = 0; r < reps + 1; ++r) {  // first launch of each kernel is a warm-up
+    float ms = 0;
+    HIP_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, 0, (const f4_t*)src, n, sink);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) best_r = std::max(best_r, (double)(n * 16) / (ms * 1e-3) / 1e9);
+    HIP_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, 0, (const f4_t*)src, (f4_t*)dst, n);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) best_c = std::max(best_c, (double)(2 * n * 16) / (ms * 1e-3) / 1e9);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  (void)hipFree(sink);
+  if (read_gbps) *read_gbps = best_r;
+  if (copy_gbps) *copy_gbps = best_c;
+  return CAL_OK;
+}
+
 int cal_solver_create(cal_solver** out, int device, int dtype) {
   if (!out) return fail(CAL_ERR_INVALID, "cal_solver_create: null");
   *out = nullptr;

@@ -110,6 +110,45 @@ struct TileCfg {
   static constexpr size_t q_lds_bytes(bool reg) { return (reg ? 2 : 1) * (size_t)1024 * 2 * sizeof(T) + QT * sizeof(long long); }
 };
 
+// acc (re, im) += a[u] * b (re, im) for the four reals a[0..3] of one 16-byte load: v_pk_fma_f32 broadcasts either half
+// of a 64-bit operand through op_sel, so no register shuffling is needed.  (hipcc matches only part of these broadcasts
+// and pads the rest with v_mov: 64 moves beside 62 packed FMAs per tile before this was written out.)
+typedef float pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pk_fma_lo(pair_t& acc, pair_t a, pair_t b) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pk_fma_hi(pair_t& acc, pair_t a, pair_t b) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+// acc[0..3] += a[0..3] (x) b : four (re, im) accumulators, one per real of the load
+__device__ __forceinline__ void fma_rows(float2* acc, const float __attribute__((ext_vector_type(4))) a, const float2 b) {
+  const pair_t a01 = {a[0], a[1]}, a23 = {a[2], a[3]}, bb = {b.x, b.y};
+  pair_t* p = reinterpret_cast<pair_t*>(acc);
+  pk_fma_lo(p[0], a01, bb);
+  pk_fma_hi(p[1], a01, bb);
+  pk_fma_lo(p[2], a23, bb);
+  pk_fma_hi(p[3], a23, bb);
+}
+// acc += sum_u a[u] * b[u] : one (re, im) accumulator
+__device__ __forceinline__ void fma_cols(float2& acc, const float __attribute__((ext_vector_type(4))) a, const float2* b) {
+  const pair_t a01 = {a[0], a[1]}, a23 = {a[2], a[3]};
+  pair_t& p = reinterpret_cast<pair_t&>(acc);
+  pk_fma_lo(p, a01, pair_t{b[0].x, b[0].y});
+  pk_fma_hi(p, a01, pair_t{b[1].x, b[1].y});
+  pk_fma_lo(p, a23, pair_t{b[2].x, b[2].y});
+  pk_fma_hi(p, a23, pair_t{b[3].x, b[3].y});
+}
+__device__ __forceinline__ void fma_rows(double2* acc, const double __attribute__((ext_vector_type(2))) a, const double2 b) {
+  acc[0].x += a[0] * b.x;
+  acc[0].y += a[0] * b.y;
+  acc[1].x += a[1] * b.x;
+  acc[1].y += a[1] * b.y;
+}
+__device__ __forceinline__ void fma_cols(double2& acc, const double __attribute__((ext_vector_type(2))) a, const double2* b) {
+  acc.x += a[0] * b[0].x + a[1] * b[1].x;
+  acc.y += a[0] * b[0].y + a[1] * b[1].y;
+}
+
 template <typename T> __device__ __forceinline__ T ldsum(T v) {
   // full-wave butterfly sum
 #pragma unroll
@@ -168,6 +207,10 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     }
     __syncthreads();
   }
+  // byte offset of this thread's part of load l inside a tile: the same in every tile of the item
+  unsigned voff[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) voff[l] = (unsigned)((min(l * NS + ks, nvec - 1) * FB + f0) * (int)sizeof(T));
   T2 acc0[L], acc1[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) acc0[l].x = acc0[l].y = acc1[l].x = acc1[l].y = 0;
@@ -227,32 +270,34 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     T d_r = 0, d_i = 0, w = 0;
     T2 g0, g1;
     g0.x = g0.y = g1.x = g1.y = 0;
-    if (tid < FB) {
+    // the per-channel stage (FB threads) moves to the next group of FB threads with every tile, so that over an item
+    // all four SIMDs of the CU carry the same share of it
+    const int ch = (tid + FB * (tau % (kThreads / FB))) % kThreads;  // this thread's channel in the per-channel stage
+    if (ch < FB) {
       if (MODE != MODE_MODEL) {
-        d_r = A.data_r[o_row + tid];
-        d_i = A.data_i[o_row + tid];
-        w = A.wgts[o_row + tid];
+        d_r = A.data_r[o_row + ch];
+        d_i = A.data_i[o_row + ch];
+        w = A.wgts[o_row + ch];
       }
       if (MODE == MODE_LOSS || MODE == MODE_GRAD) {
-        g0 = A.gains[(long long)ant.x * A.fpad + fbk * FB + tid];
-        g1 = A.gains[(long long)ant.y * A.fpad + fbk * FB + tid];
+        g0 = A.gains[(long long)ant.x * A.fpad + fbk * FB + ch];
+        g1 = A.gains[(long long)ant.y * A.fpad + fbk * FB + ch];
       }
     }
     // Every load is unconditional and unmasked: a lane-masked load next to a zero fill of the other lanes makes the
     // compiler wait for each load before it touches the register again, seven round trips per tile.  Rows past nvec
     // re-read the last row of the tile (cache hits); their coefficients are zero and their adjoint sums are never
     // written.
-    const T* src = A.tiles + t_off + (long long)fbk * tile_elems;
+    const char* src = reinterpret_cast<const char*>(A.tiles + t_off + (long long)fbk * tile_elems);  // uniform
     stage_t stage[L];
     if (A.stream_once) {
       // per-baseline tiles are read exactly once per pass: non-temporal loads keep them from displacing the gains and
       // the other re-used arrays in L2 / Infinity Cache (measured: LOSS pass 4.09 -> 3.8 ms on HERA-350)
 #pragma unroll
-      for (int l = 0; l < L; ++l)
-        stage[l] = __builtin_nontemporal_load(reinterpret_cast<const stage_t*>(src + (min(l * NS + ks, nvec - 1) * FB + f0)));
+      for (int l = 0; l < L; ++l) stage[l] = __builtin_nontemporal_load(reinterpret_cast<const stage_t*>(src + voff[l]));
     } else {
 #pragma unroll
-      for (int l = 0; l < L; ++l) stage[l] = *reinterpret_cast<const stage_t*>(src + (min(l * NS + ks, nvec - 1) * FB + f0));
+      for (int l = 0; l < L; ++l) stage[l] = *reinterpret_cast<const stage_t*>(src + voff[l]);
     }
 
     // ---- forward
@@ -263,12 +308,7 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       for (int u = 0; u < VEC; ++u) pv[u].x = pv[u].y = 0;
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        const T2 c = s_c[l * NS + ks];
-#pragma unroll
-        for (int u = 0; u < VEC; ++u) {
-          pv[u].x += stage[l][u] * c.x;
-          pv[u].y += stage[l][u] * c.y;
-        }
+        fma_rows(pv, stage[l], s_c[l * NS + ks]);
       }
       // rows held by the other lanes of this wave
 #pragma unroll
@@ -286,27 +326,27 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     }
     __syncthreads();
 
-    // ---- per-channel stage: thread = channel
-    if (tid < FB) {
+    // ---- per-channel stage: thread = channel ch
+    if (ch < FB) {
       T vr = 0, vi = 0;
       if (FWD) {
 #pragma unroll
         for (int wv = 0; wv < kWaves; ++wv) {
-          const T2 p = pv_par[wv * FB + tid];
+          const T2 p = pv_par[wv * FB + ch];
           vr += p.x;
           vi += p.y;
         }
       }
       if (MODE == MODE_MODEL) {
-        A.model_r[o_row + tid] = vr;
-        A.model_i[o_row + tid] = vi;
+        A.model_r[o_row + ch] = vr;
+        A.model_i[o_row + ch] = vi;
       } else if (MODE == MODE_INIT) {
         // binary weights of calibration.py:875-877: ~np.isclose(w, 0.0) (atol 1e-8)
         const T msk = (fabs(w) <= (T)1e-8) ? (T)0 : (T)1;
         T2 gv;
         gv.x = d_r * msk;
         gv.y = d_i * msk;
-        s_gv[tid] = gv;
+        s_gv[ch] = gv;
       } else {
         // G = g0 conj(g1)   (calibration.py:1598-1601: grgr + gigi, gigr - grgi)
         const T G_r = g0.x * g1.x + g0.y * g1.y;
@@ -327,23 +367,23 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
           T2 gv;
           gv.x = G_r * e_r + G_i * e_i;
           gv.y = G_r * e_i - G_i * e_r;
-          s_gv[tid] = gv;
+          s_gv[ch] = gv;
           // gbar_G = conj(v) e
           T2 q;
           q.x = vr * e_r + vi * e_i;
           q.y = vr * e_i - vi * e_r;
-          s_q[q_count * FB + tid] = q;
-          if (tid == 0) s_qo[q_count] = o_row;
+          s_q[q_count * FB + ch] = q;
+          if (ch == 0) s_qo[q_count] = o_row;
           if (REG) {
             // the part of e that multiplies alpha: w (real)
             T2 gw;
             gw.x = G_r * w;
             gw.y = -G_i * w;
-            s_gv[FB + tid] = gw;
+            s_gv[FB + ch] = gw;
             T2 qw;
             qw.x = vr * w;
             qw.y = -vi * w;
-            s_q[(C::QT + q_count) * FB + tid] = qw;
+            s_q[(C::QT + q_count) * FB + ch] = qw;
           }
         }
       }
@@ -359,15 +399,8 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       }
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-#pragma unroll
-        for (int u = 0; u < VEC; ++u) {
-          acc0[l].x += stage[l][u] * gv0[u].x;
-          acc0[l].y += stage[l][u] * gv0[u].y;
-          if (REG) {
-            acc1[l].x += stage[l][u] * gv1[u].x;
-            acc1[l].y += stage[l][u] * gv1[u].y;
-          }
-        }
+        fma_cols(acc0[l], stage[l], gv0);
+        if (REG) fma_cols(acc1[l], stage[l], gv1);
       }
       if (MODE == MODE_GRAD) ++q_count;
     }
@@ -428,6 +461,25 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       }
     }
   }
+}
+
+// ---- streaming-peak probes (cal_device_stream_peak): what the memory system delivers to the simplest possible kernel
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_read_kernel(const f4_t* __restrict__ src, size_t n, float* __restrict__ sink) {
+  f4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i + 3 * 256 < n; i += stride) {
+    const f4_t a = __builtin_nontemporal_load(src + i);
+    const f4_t b = __builtin_nontemporal_load(src + i + 256);
+    const f4_t c = __builtin_nontemporal_load(src + i + 512);
+    const f4_t d = __builtin_nontemporal_load(src + i + 768);
+    acc += a + b + c + d;
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[blockIdx.x] = acc.x;  // never true for finite data: keeps the loads
+}
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f4_t* __restrict__ src, f4_t* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
 template <typename T> struct FbSet;

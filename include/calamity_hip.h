@@ -108,6 +108,10 @@ const char* cal_last_error(void);
 const char* cal_version(void);
 int cal_device_count(int* count);
 int cal_device_info(int device, char* name, size_t name_len, int64_t* total_mem_bytes, int32_t* compute_units);
+/* Measured streaming peaks of the device (no reference counterpart; BASELINE.md section 3 asks for the roofline against a
+ * stream kernel measured on the box next to the nominal 8 TB/s): a read-only sweep (16-byte non-temporal loads, the
+ * access pattern of the fit's tile stream) and a copy, each over `bytes` of HBM, best of `reps` launches, in GB/s. */
+int cal_device_stream_peak(int device, size_t bytes, int reps, double* read_gbps, double* copy_gbps);
 
 /* tf.device / GPU selection of read_calibrate_and_model_dpss, calibration.py:1741-1753, :1796-1804 */
 int cal_solver_create(cal_solver** out, int device, int dtype);
