@@ -272,6 +272,7 @@ def main():
         try:
             rd, cp = _lib.stream_peak(0, 4 << 30, 5)
             peaks = {"read_GBps": rd, "copy_GBps": cp, "how": "cal_device_stream_peak: 4 GiB, best of 5, 16-byte non-temporal loads / plain copy"}
+            peaks["busy_shader_clock_MHz"] = _lib.busy_clock_mhz(0)
         except Exception as e:  # noqa: BLE001 -- a probe must not take the benchmark down
             peaks = {"error": str(e)}
         tp, _, tstart = synthetic.make_problem(15, 200, f0=100e6, df=100e3, seed=0)

@@ -78,6 +78,7 @@ SYMBOLS = {
     "cal_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "cal_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "cal_device_stream_peak": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "cal_device_busy_clock_mhz": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "cal_solver_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
     "cal_solver_destroy": (C.c_int, [_P]),
     "cal_solver_set_problem": (C.c_int, [_P, C.POINTER(ProblemDesc)]),
@@ -153,3 +154,10 @@ def stream_peak(device=0, nbytes=4 << 30, reps=5):
     rd, cp = C.c_double(0.0), C.c_double(0.0)
     check(load().cal_device_stream_peak(device, nbytes, reps, C.byref(rd), C.byref(cp)))
     return rd.value, cp.value
+
+
+def busy_clock_mhz(device=0):
+    """Shader clock (MHz) the device holds while all CUs run vector FMAs."""
+    mhz = C.c_double(0.0)
+    check(load().cal_device_busy_clock_mhz(device, C.byref(mhz)))
+    return mhz.value

@@ -1101,6 +1101,30 @@ int cal_device_stream_peak(int device, size_t bytes, int reps, double* read_gbps
   return CAL_OK;
 }
 
+int cal_device_busy_clock_mhz(int device, double* mhz) {
+  if (!mhz) return fail(CAL_ERR_INVALID, "cal_device_busy_clock_mhz: null");
+  HIP_TRY(hipSetDevice(device));
+  long long* out = nullptr;
+  float* sink = nullptr;
+  HIP_TRY(hipMalloc((void**)&out, 2 * sizeof(long long)));
+  HIP_TRY(hipMalloc((void**)&sink, 64));
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, device));
+  int wall_khz = 0;
+  HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device));
+  long long h[2] = {0, 0};
+  for (int rep = 0; rep < 3; ++rep) {  // the last repetition is measured at the clock the load has settled on
+    hipLaunchKernelGGL(busy_clock_kernel, dim3(p.multiProcessorCount * 8), dim3(256), 0, 0, out, 400000, sink);
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  HIP_TRY(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
+  (void)hipFree(out);
+  (void)hipFree(sink);
+  if (h[1] <= 0 || wall_khz <= 0) return fail(CAL_ERR_HIP, "cal_device_busy_clock_mhz: no wall-clock counter");
+  *mhz = (double)h[0] / ((double)h[1] / (wall_khz * 1e3)) / 1e6;
+  return CAL_OK;
+}
+
 int cal_solver_create(cal_solver** out, int device, int dtype) {
   if (!out) return fail(CAL_ERR_INVALID, "cal_solver_create: null");
   *out = nullptr;

@@ -112,6 +112,9 @@ int cal_device_info(int device, char* name, size_t name_len, int64_t* total_mem_
  * stream kernel measured on the box next to the nominal 8 TB/s): a read-only sweep (16-byte non-temporal loads, the
  * access pattern of the fit's tile stream) and a copy, each over `bytes` of HBM, best of `reps` launches, in GB/s. */
 int cal_device_stream_peak(int device, size_t bytes, int reps, double* read_gbps, double* copy_gbps);
+/* Shader clock the device sustains while every CU is busy with vector FMAs for a few milliseconds (MHz): boxes of the
+ * same model differ in the clock they hold under load, and compute-side kernel times scale with it. */
+int cal_device_busy_clock_mhz(int device, double* mhz);
 
 /* tf.device / GPU selection of read_calibrate_and_model_dpss, calibration.py:1741-1753, :1796-1804 */
 int cal_solver_create(cal_solver** out, int device, int dtype);

@@ -86,3 +86,57 @@ def test_calibrate_and_model_mixed(model_regularization):
     model = cal_utils.apply_gains(model, gains)
     assert rms(model.data_array) >= 1e2 * rms(resid.data_array)
     assert len(fit_history) >= 1
+
+
+def test_yield_fg_model_and_fg_coeffs_mixed():
+    """test_calibration.py:350-413 for joint groups: visibilities that lie in the span of the mixed basis come back from
+    least-squares coefficients -> model cube -> insertion."""
+    import copy
+
+    uvd = line_array()
+    freqs = uvd.freq_array[0] if np.ndim(uvd.freq_array) == 2 else uvd.freq_array
+    grps, centers, _, _ = modeling.get_uv_overlapping_grps_conjugated(uvd)
+    comps = modeling.yield_mixed_comps(grps, centers, freqs, ant_dly=2.0 / 0.3, grp_size_threshold=1)
+    gains = cal_utils.blank_uvcal_from_uvdata(uvd)
+    ants_map = {ant: i for i, ant in enumerate(gains.ant_array)}
+    rng = np.random.default_rng(9)
+    sky = copy.deepcopy(uvd)
+    for fit_grp, vecs in comps.items():
+        spec = vecs @ (rng.standard_normal(vecs.shape[1]) + 1j * rng.standard_normal(vecs.shape[1]))
+        for rnum, red_grp in enumerate(fit_grp):
+            for ap in red_grp:
+                sky.data_array[sky.antpair2ind(ap), 0, :, 0] = spec[rnum * sky.Nfreqs : (rnum + 1) * sky.Nfreqs]
+    p, corr_inds = calibration.tensorize_fg_model_comps_dict(comps, ants_map, nfreqs=sky.Nfreqs, dtype=np.float64, grp_size_threshold=1)
+    scale = rms(sky.data_array)
+    t0 = sky.time_array[0]
+    d_r, d_i, w = calibration.tensorize_data(sky, corr_inds, ants_map, polarization="xx", time=t0, dtype=np.float64, data_scale_factor=scale)
+    c_re = calibration.tensorize_fg_coeffs(d_r, w, p)
+    c_im = calibration.tensorize_fg_coeffs(d_i, w, p)
+    m_r = calibration.yield_fg_model_array(sky.Nants_data, sky.Nfreqs, p, c_re, corr_inds, dtype=np.float64)
+    m_i = calibration.yield_fg_model_array(sky.Nants_data, sky.Nfreqs, p, c_im, corr_inds, dtype=np.float64)
+    out = copy.deepcopy(sky)
+    out.data_array[:] = 0.0
+    red_grps = [rg for fit_grp in comps for rg in fit_grp]
+    calibration.insert_model_into_uvdata_tensor(out, t0, "xx", ants_map, red_grps, m_r, m_i, scale_factor=scale)
+    assert np.allclose(out.data_array, sky.data_array, atol=1e-8 * scale)
+
+
+def test_calibrate_and_model_mixed_redundant():
+    """test_calibration.py:826-877: a redundant (hex) array, inverse-variance-like weights, gains fitted against a frozen
+    model of the data itself; model and data are >= 100 x the residual."""
+    from calamity_amd import synthetic
+    from calamity_amd.uvcompat import SimpleUVFlag
+
+    uvd, sky, _ = synthetic.make_uvdata(nants=7, nfreqs=48, ntimes=1, seed=11, redundant=True, eor_db=-70.0)
+    weights = SimpleUVFlag(uvd, mode="flag")
+    rng = np.random.default_rng(0)
+    weights.weights_array = rng.uniform(0.5, 1.5, size=uvd.data_array.shape)
+    g0 = cal_utils.blank_uvcal_from_uvdata(uvd)
+    g0.gain_array = g0.gain_array + 1e-2 * (rng.standard_normal(g0.gain_array.shape) + 1j * rng.standard_normal(g0.gain_array.shape))
+    model, resid, gains, fit_history = calibration.calibrate_and_model_mixed(
+        min_dly=0.0, offset=0.0, ant_dly=2.0 / 0.3, red_tol_freq=0.5, uvdata=uvd, gains=g0, verbose=False, use_redundancy=False,
+        sky_model=None, freeze_model=True, maxsteps=3000, correct_resid=False, correct_model=False, weights=weights,
+    )
+    assert rms(model.data_array) >= 1e2 * rms(resid.data_array)
+    assert rms(uvd.data_array) >= 1e2 * rms(resid.data_array)
+    assert len(fit_history) == 1 and len(fit_history[0]) == 1
