@@ -1,0 +1,88 @@
+"""Shape coverage of the HIP kernels against the C restatement: every tile width (fp32 FB 128/64/32/16, fp64 FB 64/32/16/8
+follow from nvec), nvec on both sides of every boundary, a channel count that is not a multiple of the tile width,
+fitting groups of 1, 3 and 20 baselines (the latter flush the gbar_G buffer inside an item), one-baseline-per-group
+problems for the dense (MFMA) path, and items split over workgroups."""
+import numpy as np
+import pytest
+
+from calamity_amd.problem import FitProblem
+from oracle.ref_c import CRef
+
+pytestmark = pytest.mark.gpu
+
+
+def random_problem(nvecs, bls_per_grp, nants=9, nfreqs=200, seed=0, rowblocks=False):
+    rng = np.random.default_rng(seed)
+    basis, grp_basis, start, a0, a1, rb = [], [], [0], [], [], []
+    for n, (nvec, nb) in enumerate(zip(nvecs, bls_per_grp)):
+        nrb = min(nb, 3) if rowblocks else 1
+        basis.append(rng.standard_normal((nrb * nfreqs, nvec)) / np.sqrt(nfreqs))
+        grp_basis.append(n)
+        for b in range(nb):
+            i, j = rng.choice(nants, size=2, replace=False)
+            a0.append(i)
+            a1.append(j)
+            rb.append(b % nrb)
+        start.append(start[-1] + nb)
+    nbls = len(a0)
+    w = rng.uniform(0.0, 1.0, size=(nbls, nfreqs)) * (rng.random((nbls, nfreqs)) > 0.1)
+    p = FitProblem(nants=nants, nfreqs=nfreqs, basis=basis, grp_basis=np.asarray(grp_basis, np.int32), grp_bl_start=np.asarray(start, np.int32),
+                   bl_ant0=np.asarray(a0, np.int32), bl_ant1=np.asarray(a1, np.int32), bl_rowblk=np.asarray(rb, np.int32),
+                   data_r=rng.standard_normal((nbls, nfreqs)), data_i=rng.standard_normal((nbls, nfreqs)), wgts=w / w.sum())
+    p.sky_r, p.sky_i = rng.standard_normal((nbls, nfreqs)), rng.standard_normal((nbls, nfreqs))
+    start = dict(g_r=1.0 + 0.1 * rng.standard_normal((nants, nfreqs)), g_i=0.1 * rng.standard_normal((nants, nfreqs)),
+                 c_r=rng.standard_normal(p.ncoeffs), c_i=rng.standard_normal(p.ncoeffs))
+    return p, start
+
+
+def check(p, start, dtypes=(np.float64, np.float32), layouts=("stream", "shared"), regs=(False, True)):
+    from calamity_amd.solver import HipFitSolver
+
+    c = CRef(p, np.float64)
+    for reg in regs:
+        pr, pi = (float(np.sum(p.sky_r * p.wgts)), float(np.sum(p.sky_i * p.wgts))) if reg else (0.0, 0.0)
+        c.set_regularization("sum" if reg else None, pr, pi)
+        ref = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        for dtype in dtypes:
+            tol_l, tol_g = (1e-10, 1e-10) if dtype == np.float64 else (2e-5, 2e-4)
+            for layout in layouts:
+                s = HipFitSolver(dtype=dtype)
+                s.set_problem(p, layout=layout)
+                s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+                if reg:
+                    s.set_regularization("sum", pr, pi)
+                assert abs(s.eval_loss() - ref[0]) <= tol_l * abs(ref[0]), (dtype, layout, reg)
+                out = s.eval_grads()
+                assert abs(out[0] - ref[0]) <= tol_l * abs(ref[0]), (dtype, layout, reg)
+                for a, b in zip(out[1:], ref[1:]):
+                    assert np.linalg.norm(np.asarray(a, np.float64) - b) <= tol_g * np.linalg.norm(b), (dtype, layout, reg)
+                s.close()
+
+
+def test_every_tile_width_and_group_size():
+    nvecs = [1, 7, 56, 57, 112, 113, 224, 225, 300, 448, 30, 100]
+    bls = [1, 3, 20, 1, 3, 20, 2, 1, 3, 1, 20, 20]
+    p, start = random_problem(nvecs, bls, seed=1)
+    check(p, start)
+
+
+def test_row_blocks_inside_groups():
+    p, start = random_problem([5, 60, 130], [4, 7, 20], seed=2, rowblocks=True)
+    check(p, start)
+
+
+def test_dense_path_vector_counts():
+    """One baseline per group, nvec <= 256: fp32 + shared layout takes the MFMA kernel (nvec padded to 8 / 32 inside)."""
+    nvecs = [1, 7, 8, 9, 31, 32, 33, 64, 100, 129, 224, 255, 256] * 3
+    p, start = random_problem(nvecs, [1] * len(nvecs), nants=12, nfreqs=1024, seed=3)
+    # make same-shape groups share one basis block, as the operator cache does: panels of several baselines
+    first = {}
+    for g, n in enumerate(nvecs):
+        p.grp_basis[g] = first.setdefault(n, g)
+    check(p, start, dtypes=(np.float32,), layouts=("shared",))
+
+
+def test_many_channels_few_groups_split_items():
+    """Fewer groups than workgroup slots: items are split by tiles and their coefficient gradients summed afterwards."""
+    p, start = random_problem([20, 90, 250], [2, 5, 3], nants=6, nfreqs=4096, seed=4)
+    check(p, start, regs=(False,))
