@@ -223,6 +223,9 @@ struct SolverT final : cal_solver {
     }
     // the dense path tiles channels in chunks of kChunk
     bool want_mfma = std::is_same<T, float>::value && layout == CAL_LAYOUT_SHARED && !getenv("CALAMITY_HIP_NO_MFMA");
+    // a panel of 16 baselines occupies one CU for 60-70 us whatever the problem size; below ~2000 baselines the panels do
+    // not fill the chip and the general kernel (one workgroup per baseline) is 2-3x faster (HERA-37 fp32: 25 vs 71 us)
+    if (nbls < 2048 && !getenv("CALAMITY_HIP_FORCE_MFMA")) want_mfma = false;
     for (int g = 0; g < ngrps && want_mfma; ++g) want_mfma = (d->grp_bl_start[g + 1] - d->grp_bl_start[g]) == 1;
     for (int u = 0; u < nbasis && want_mfma; ++u) want_mfma = d->basis_nrowblk[u] == 1 && d->basis_nvec[u] <= 32 * kMaxNT;
     if ((long long)(nbls + 1) * (nfreqs + kChunk) >= (1LL << 31)) want_mfma = false;  // the dense kernel uses 32-bit sample offsets

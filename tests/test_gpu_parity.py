@@ -101,8 +101,10 @@ def test_short_trajectory(dtype, optimizer, reg):
 
 
 @pytest.mark.parametrize("reg", [False, True])
-def test_short_trajectory_dense_path(reg):
-    """fp32 + SHARED layout + one baseline per group -> the MFMA path (two passes per step with the "sum" regulariser)."""
+def test_short_trajectory_dense_path(reg, monkeypatch):
+    """fp32 + SHARED layout + one baseline per group -> the MFMA path (two passes per step with the "sum" regulariser).
+    Problems this small normally take the general kernel; the environment switch forces the dense one."""
+    monkeypatch.setenv("CALAMITY_HIP_FORCE_MFMA", "1")
     p, start = make_case(seed=6, nants=12, nfreqs=200, with_sky=reg, perturb=False)
     ch, fg_r, fg_i = oracle_inputs(p, start)
     out = R.fit_gains_and_foregrounds(

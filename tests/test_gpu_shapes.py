@@ -71,8 +71,10 @@ def test_row_blocks_inside_groups():
     check(p, start)
 
 
-def test_dense_path_vector_counts():
-    """One baseline per group, nvec <= 256: fp32 + shared layout takes the MFMA kernel (nvec padded to 8 / 32 inside)."""
+def test_dense_path_vector_counts(monkeypatch):
+    """One baseline per group, nvec <= 256: fp32 + shared layout takes the MFMA kernel (nvec padded to 8 / 32 inside);
+    forced here, problems below ~2000 baselines normally take the general kernel."""
+    monkeypatch.setenv("CALAMITY_HIP_FORCE_MFMA", "1")
     nvecs = [1, 7, 8, 9, 31, 32, 33, 64, 100, 129, 224, 255, 256] * 3
     p, start = random_problem(nvecs, [1] * len(nvecs), nants=12, nfreqs=1024, seed=3)
     # make same-shape groups share one basis block, as the operator cache does: panels of several baselines

@@ -1,9 +1,18 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash tools/prof_round.sh <tag>
+# rocprofv3 kernel trace + stats of the default bench, separate PMC passes (FETCH_SIZE, WRITE_SIZE) for the streaming and
+# the shared layout, and a plain bench run; everything under gpurun_out/<tag>/
 set -e
+tag=${1:-prof}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/prof_r1c gpurun_out/pmc_r1c
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r1c -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 > gpurun_out/prof_r1c/stdout.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_r1c -o fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-shared --no-cpu-baseline > gpurun_out/pmc_r1c/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_r1c -o write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-shared --no-cpu-baseline > gpurun_out/pmc_r1c/write.log 2>&1
-python3 bench.py --steps 20 --warmup 3 > gpurun_out/bench_r1c.log 2>&1
-tail -1 gpurun_out/bench_r1c.log
+out=gpurun_out/$tag
+mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/trace -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/trace_stdout.log 2>&1
+echo "trace done"
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc -o fetch --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc -o write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
+echo "write done"
+python3 bench.py --steps 20 --warmup 3 > $out/bench.log 2>&1
+tail -1 $out/bench.log | cut -c1-400
