@@ -190,7 +190,8 @@ struct SolverT final : cal_solver {
     if (fb == M) return TileCfg<T, M>::lds_bytes();
     if (fb == M / 2) return TileCfg<T, M / 2>::lds_bytes();
     if (fb == M / 4) return TileCfg<T, M / 4>::lds_bytes();
-    return TileCfg<T, M / 8>::lds_bytes();
+    if (fb == M / 8) return TileCfg<T, M / 8>::lds_bytes();
+    return TileCfg<T, M / 16>::lds_bytes();
   }
 
   // ------------------------------------------------------------------------------------------------------------

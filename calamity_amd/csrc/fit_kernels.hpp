@@ -231,8 +231,13 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       const int slot = b / kSlotBytes;
       const int within = b - slot * kSlotBytes;
       const long long o = s_qo[slot];
+#ifdef CAL_X_QNT
+      __builtin_nontemporal_store(*reinterpret_cast<const u4*>(reinterpret_cast<const char*>(s_q) + b),
+                                  reinterpret_cast<u4*>(reinterpret_cast<char*>(A.q0 + o) + within));
+#else
       *reinterpret_cast<u4*>(reinterpret_cast<char*>(A.q0 + o) + within) =
           *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(s_q) + b);
+#endif
       if (REG)
         *reinterpret_cast<u4*>(reinterpret_cast<char*>(A.q1 + o) + within) =
             *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(s_q + C::QT * FB) + b);
@@ -499,8 +504,8 @@ __global__ __launch_bounds__(256) void busy_clock_kernel(long long* out, int ite
 }
 
 template <typename T> struct FbSet;
-template <> struct FbSet<float> { static constexpr int fb_max = 128; static constexpr int fb_min = 16; };
-template <> struct FbSet<double> { static constexpr int fb_max = 64; static constexpr int fb_min = 8; };
+template <> struct FbSet<float> { static constexpr int fb_max = 128; static constexpr int fb_min = 8; };
+template <> struct FbSet<double> { static constexpr int fb_max = 64; static constexpr int fb_min = 4; };
 
 #ifndef CAL_WAVES_EU
 #define CAL_WAVES_EU 4
@@ -516,7 +521,8 @@ void fused_basis_kernel(const FusedArgs<T> A) {
   if (fb == FBM) process_item<T, FBM, MODE, REG>(A, it, smem, blockIdx.x);
   else if (fb == FBM / 2) process_item<T, FBM / 2, MODE, REG>(A, it, smem, blockIdx.x);
   else if (fb == FBM / 4) process_item<T, FBM / 4, MODE, REG>(A, it, smem, blockIdx.x);
-  else process_item<T, FBM / 8, MODE, REG>(A, it, smem, blockIdx.x);
+  else if (fb == FBM / 8) process_item<T, FBM / 8, MODE, REG>(A, it, smem, blockIdx.x);
+  else process_item<T, FBM / 16, MODE, REG>(A, it, smem, blockIdx.x);
 }
 
 // ---- sum the partial coefficient gradients of multi-item groups: gc[n] = sum_q gcp[goff_q + k]

@@ -1,4 +1,4 @@
-"""Shape coverage of the HIP kernels against the C restatement: every tile width (fp32 FB 128/64/32/16, fp64 FB 64/32/16/8
+"""Shape coverage of the HIP kernels against the C restatement: every tile width (fp32 FB 128/64/32/16/8, fp64 FB 64/32/16/8/4
 follow from nvec), nvec on both sides of every boundary, a channel count that is not a multiple of the tile width,
 fitting groups of 1, 3 and 20 baselines (the latter flush the gbar_G buffer inside an item), one-baseline-per-group
 problems for the dense (MFMA) path, and items split over workgroups."""
@@ -60,8 +60,8 @@ def check(p, start, dtypes=(np.float64, np.float32), layouts=("stream", "shared"
 
 
 def test_every_tile_width_and_group_size():
-    nvecs = [1, 7, 56, 57, 112, 113, 224, 225, 300, 448, 30, 100]
-    bls = [1, 3, 20, 1, 3, 20, 2, 1, 3, 1, 20, 20]
+    nvecs = [1, 7, 56, 57, 112, 113, 224, 225, 300, 448, 449, 896, 30, 100]
+    bls = [1, 3, 20, 1, 3, 20, 2, 1, 3, 1, 2, 1, 20, 20]
     p, start = random_problem(nvecs, bls, seed=1)
     check(p, start)
 
@@ -88,3 +88,15 @@ def test_many_channels_few_groups_split_items():
     """Fewer groups than workgroup slots: items are split by tiles and their coefficient gradients summed afterwards."""
     p, start = random_problem([20, 90, 250], [2, 5, 3], nants=6, nfreqs=4096, seed=4)
     check(p, start, regs=(False,))
+
+
+def test_more_vectors_than_a_tile_holds_is_reported():
+    from calamity_amd._lib import CalamityHipError
+    from calamity_amd.solver import HipFitSolver
+
+    p, start = random_problem([897], [1], seed=5)
+    s = HipFitSolver(dtype=np.float32)
+    with pytest.raises(CalamityHipError) as e:
+        s.set_problem(p, layout="stream")
+    assert e.value.code == -5 and "897" in str(e.value)
+    s.close()
