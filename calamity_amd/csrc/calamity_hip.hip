@@ -122,13 +122,15 @@ struct SolverT final : cal_solver {
   bool has_problem = false, has_data = false, has_gains = false, has_coef = false, has_opt = false;
   // problem
   int nants = 0, nfreqs = 0, fpad = 0, ngrps = 0, nbls = 0, ncoef = 0, nitems = 0, layout = 0;
+  int nitems_simple = 0;   // items [0, nitems_simple) are single-baseline groups (fused_basis_kernel), the rest multi-baseline (fused_group_kernel)
+  size_t lds_group_bytes = 0;
   bool gc_direct = true;
   size_t lds_bytes = 0;
   long long gcp_len = 0;
   std::vector<int> h_grp_coff;
   double basis_bytes = 0;
   // device buffers
-  DevBuf tiles, bl_tile, bl_ant, items, ant_ptr, ant_ent, coef_grp, grp_coff, grp_item_ptr, item_goff;
+  DevBuf tiles, bl_tile, bl_ant, runs, items, ant_ptr, ant_ent, coef_grp, grp_coff, grp_item_ptr, item_goff;
   DevBuf data_r, data_i, wgts;
   DevBuf gains, gains_m, gains_v, gains_snap;  // [nants][fpad] T2
   DevBuf coef, coef_m, coef_v, coef_snap;      // [2][ncoef] T (r plane then i plane)
@@ -184,6 +186,14 @@ struct SolverT final : cal_solver {
     for (int fb = std::min(cap, FbSet<T>::fb_max); fb >= FbSet<T>::fb_min; fb /= 2)
       if ((long long)nvec * fb * (long long)sizeof(T) <= kTileBytes) return fb;
     return -1;
+  }
+  static size_t group_lds_for(int fb) {
+    constexpr int M = FbSet<T>::fb_max;
+    if (fb == M) return group_lds_bytes<T, M>();
+    if (fb == M / 2) return group_lds_bytes<T, M / 2>();
+    if (fb == M / 4) return group_lds_bytes<T, M / 4>();
+    if (fb == M / 8) return group_lds_bytes<T, M / 8>();
+    return group_lds_bytes<T, M / 16>();
   }
   static size_t lds_for(int fb) {
     constexpr int M = FbSet<T>::fb_max;
@@ -283,13 +293,21 @@ struct SolverT final : cal_solver {
       utiles.p = nullptr; utiles.bytes = 0;
       basis_bytes = (double)uoff[nbasis] / fpad * nfreqs * sizeof(T);
     } else {
-      std::vector<CopyJob> jobs(nbls);
+      // every baseline owns its tiles, except that consecutive baselines of one group with the same row block (a
+      // redundant set: one forward product for all of them) share one copy
+      std::vector<CopyJob> jobs;
+      jobs.reserve(nbls);
       long long off = 0;
       for (int b = 0; b < nbls; ++b) {
         const int u = d->grp_basis[grp_of_bl[b]];
         const int rb = d->bl_rowblk ? d->bl_rowblk[b] : 0;
         const long long n = (long long)fpad * d->basis_nvec[u];
-        jobs[b] = CopyJob{uoff[u] + (long long)rb * n, off, n};
+        const bool alias = b > 0 && grp_of_bl[b - 1] == grp_of_bl[b] && (d->bl_rowblk ? d->bl_rowblk[b - 1] : 0) == rb;
+        if (alias) {
+          h_bl_tile[b] = h_bl_tile[b - 1];
+          continue;
+        }
+        jobs.push_back(CopyJob{uoff[u] + (long long)rb * n, off, n});
         h_bl_tile[b] = off;
         off += n;
       }
@@ -297,7 +315,7 @@ struct SolverT final : cal_solver {
       DevBuf djobs;
       CAL_TRY(djobs.alloc(jobs.size() * sizeof(CopyJob), false));
       HIP_TRY(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(CopyJob), hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(tile_copy_kernel<T>, dim3(nbls), dim3(256), 0, stream, utiles.as<T>(), tiles.as<T>(), djobs.as<CopyJob>());
+      hipLaunchKernelGGL(tile_copy_kernel<T>, dim3((unsigned)jobs.size()), dim3(256), 0, stream, utiles.as<T>(), tiles.as<T>(), djobs.as<CopyJob>());
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(stream));
       basis_bytes = (double)off / fpad * nfreqs * sizeof(T);
@@ -387,49 +405,109 @@ struct SolverT final : cal_solver {
     CAL_TRY(bl_ant.alloc(nbls * sizeof(int2), false));
     HIP_TRY(hipMemcpy(bl_ant.p, h_ant.data(), nbls * sizeof(int2), hipMemcpyHostToDevice));
 
+    // ---- runs of the multi-baseline groups: consecutive baselines with the same row block, cut to kRunMax
+    std::vector<int2> h_runs;
+    std::vector<int> h_grp_run0(ngrps + 1, 0);
+    int nsimple_grps = 0;
+    for (int g = 0; g < ngrps; ++g) {
+      const int s0 = d->grp_bl_start[g], s1 = d->grp_bl_start[g + 1];
+      h_grp_run0[g] = (int)h_runs.size();
+      if (s1 - s0 == 1) {
+        ++nsimple_grps;
+        continue;
+      }
+      int lo = s0;
+      for (int b = s0 + 1; b <= s1; ++b) {
+        const bool cut = b == s1 || (d->bl_rowblk && d->bl_rowblk[b] != d->bl_rowblk[lo]) || b - lo == kRunMax;
+        if (cut) {
+          h_runs.push_back(make_int2(lo, b));
+          lo = b;
+        }
+      }
+    }
+    h_grp_run0[ngrps] = (int)h_runs.size();
+    CAL_TRY(runs.alloc(std::max<size_t>(1, h_runs.size()) * sizeof(int2), false));
+    if (!h_runs.empty()) HIP_TRY(hipMemcpy(runs.p, h_runs.data(), h_runs.size() * sizeof(int2), hipMemcpyHostToDevice));
+
     // ---- work items: whole groups when that already fills the chip, otherwise split along tiles
     long long total_tiles = 0;
     for (int g = 0; g < ngrps; ++g)
-      total_tiles += (long long)(d->grp_bl_start[g + 1] - d->grp_bl_start[g]) * (fpad / fb_u[d->grp_basis[g]]);
+      if (d->grp_bl_start[g + 1] - d->grp_bl_start[g] == 1) total_tiles += fpad / fb_u[d->grp_basis[g]];
     // one item per group when the groups alone fill the chip (256 CUs x ~4 resident workgroups, several waves of them);
     // otherwise split groups along their tiles (partial coefficient gradients are summed by coeff_partial_reduce_kernel)
     const long long target_items = 8192;
-    const bool groups_fill_chip = ngrps >= 2048;
-    const long long tiles_per_item = groups_fill_chip ? std::max<long long>(64, 4 * total_tiles / ngrps)
+    const bool groups_fill_chip = nsimple_grps >= 2048;
+    const long long tiles_per_item = groups_fill_chip ? std::max<long long>(64, 4 * total_tiles / std::max(1, nsimple_grps))
                                                       : std::max<long long>(4, total_tiles / target_items);
     std::vector<Item> h_items;
     std::vector<int> h_grp_item_ptr(ngrps + 1, 0);
     gc_direct = true;
+    std::vector<long long> h_item_cost;
+    std::vector<char> h_item_multi;
+    lds_group_bytes = 0;
     for (int g = 0; g < ngrps; ++g) {
       const int u = d->grp_basis[g];
       const int ntpb = fpad / fb_u[u];
-      const long long nt = (long long)(d->grp_bl_start[g + 1] - d->grp_bl_start[g]) * ntpb;
-      const int nparts = (int)std::max<long long>(1, (nt + tiles_per_item - 1) / tiles_per_item);
-      if (nparts > 1) gc_direct = false;
       int fl = 0;
       while ((1 << fl) < fb_u[u]) ++fl;
-      for (int p = 0; p < nparts; ++p) {
-        Item it{};
-        it.bl0 = d->grp_bl_start[g];
-        it.tile0 = (int)(nt * p / nparts);
-        it.tile1 = (int)(nt * (p + 1) / nparts);
-        it.nvec = d->basis_nvec[u];
-        it.coff = h_grp_coff[g];
-        it.fb_log2 = fl;
-        it.pad = g;
-        h_items.push_back(it);
+      Item it{};
+      it.nvec = d->basis_nvec[u];
+      it.coff = h_grp_coff[g];
+      it.fb_log2 = fl;
+      it.pad = g;
+      if (d->grp_bl_start[g + 1] - d->grp_bl_start[g] == 1) {
+        const long long nt = ntpb;
+        const int nparts = (int)std::max<long long>(1, (nt + tiles_per_item - 1) / tiles_per_item);
+        if (nparts > 1) gc_direct = false;
+        for (int p = 0; p < nparts; ++p) {
+          it.bl0 = d->grp_bl_start[g];
+          it.tile0 = (int)(nt * p / nparts);
+          it.tile1 = (int)(nt * (p + 1) / nparts);
+          h_items.push_back(it);
+          h_item_cost.push_back((long long)(it.tile1 - it.tile0) * it.nvec * fb_u[u]);
+          h_item_multi.push_back(0);
+        }
+      } else {
+        // units = (run, channel block), run-major; a unit costs one tile (load, forward, adjoint: about 8 batches' worth)
+        // plus one batch of the per-channel stage per kThreads / FB baselines.  Items are cut at ~96 batch equivalents
+        // so that a big redundant set is spread over many workgroups (their partial coefficient gradients are summed).
+        lds_group_bytes = std::max(lds_group_bytes, group_lds_for(fb_u[u]));
+        const int bpt = kThreads / fb_u[u];
+        const int r0 = h_grp_run0[g], r1 = h_grp_run0[g + 1];
+        const long long budget = 96;
+        long long cost = 0;
+        int unit_lo = 0, nparts = 0;
+        const int nunits = (r1 - r0) * ntpb;
+        for (int uu = 0; uu < nunits; ++uu) {
+          const int2 rn = h_runs[r0 + uu / ntpb];
+          cost += 8 + (rn.y - rn.x + bpt - 1) / bpt;
+          if (cost >= budget || uu + 1 == nunits) {
+            it.bl0 = r0;
+            it.tile0 = unit_lo;
+            it.tile1 = uu + 1;
+            h_items.push_back(it);
+            h_item_cost.push_back(cost * 1024);  // same scale as nvec x FB of a full tile, roughly
+            h_item_multi.push_back(1);
+            unit_lo = uu + 1;
+            cost = 0;
+            ++nparts;
+          }
+        }
+        if (nparts > 1) gc_direct = false;
       }
       h_grp_item_ptr[g + 1] = (int)h_items.size();
     }
     nitems = (int)h_items.size();
-    // heaviest first: the hardware dispatches workgroups in index order, so the tail is made of the lightest items
+    // single-baseline items first, then the multi-baseline ones (two launches); inside each class heaviest first: the
+    // hardware dispatches workgroups in index order, so the tail is made of the lightest items
     std::vector<int> order(nitems);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      const long long wa = (long long)(h_items[a].tile1 - h_items[a].tile0) * h_items[a].nvec * (1 << h_items[a].fb_log2);
-      const long long wb = (long long)(h_items[b].tile1 - h_items[b].tile0) * h_items[b].nvec * (1 << h_items[b].fb_log2);
-      return wa > wb;
+      if (h_item_multi[a] != h_item_multi[b]) return h_item_multi[a] < h_item_multi[b];
+      return h_item_cost[a] > h_item_cost[b];
     });
+    nitems_simple = 0;
+    for (int q = 0; q < nitems; ++q) nitems_simple += h_item_multi[q] ? 0 : 1;
     std::vector<int> h_item_goff(nitems);
     gcp_len = 0;
     if (gc_direct) {
@@ -689,17 +767,30 @@ struct SolverT final : cal_solver {
     a.state = state.as<DevState>();
     a.fpad = fpad;
     a.nbls = nbls;
+    a.runs = runs.as<int2>();
+    a.item_base = 0;
     a.stream_once = (layout == CAL_LAYOUT_STREAM && !getenv("CALAMITY_HIP_NO_NT")) ? 1 : 0;
     return a;
   }
   // LDS buffer of gbar_G rows (MODE_GRAD); the narrowest tiles have the longest offset table
   static constexpr size_t kQLdsMax1 = TileCfg<T, FbSet<T>::fb_min>::q_lds_bytes(false);
   static constexpr size_t kQLdsMax2 = TileCfg<T, FbSet<T>::fb_min>::q_lds_bytes(true);
-  template <int MODE> void launch_fused(const FusedArgs<T>& a, bool with_reg) {
-    if (with_reg)
-      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax2 : 0), stream, a);
-    else
-      hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
+  template <int MODE> void launch_fused(const FusedArgs<T>& a0, bool with_reg) {
+    FusedArgs<T> a = a0;
+    if (nitems_simple > 0) {
+      a.item_base = 0;
+      if (with_reg)
+        hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems_simple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax2 : 0), stream, a);
+      else
+        hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems_simple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
+    }
+    if (nitems > nitems_simple) {
+      a.item_base = nitems_simple;
+      if (with_reg)
+        hipLaunchKernelGGL((fused_group_kernel<T, MODE, true>), dim3(nitems - nitems_simple), dim3(kThreads), lds_group_bytes, stream, a);
+      else
+        hipLaunchKernelGGL((fused_group_kernel<T, MODE, false>), dim3(nitems - nitems_simple), dim3(kThreads), lds_group_bytes, stream, a);
+    }
   }
   T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
   T* grad_c1() { return gc_direct ? gcp1.as<T>() : gc1.as<T>(); }

@@ -91,6 +91,8 @@ struct FusedArgs {
   int fpad;
   int nbls;                  // q0 / q1 have nbls + 1 rows; row nbls stays zero
   int stream_once;           // CAL_LAYOUT_STREAM: every tile is read once per pass
+  const int2* runs;          // group kernel: [nruns] (first baseline, one past the last) of baselines that share a row block
+  int item_base;             // index of this launch's first item in `items` / `part`
 };
 
 enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_MODEL = 2, MODE_INIT = 3 };  // INIT: c = A^T (src * [w != 0]), calibration.py:875-902
@@ -507,6 +509,283 @@ template <typename T> struct FbSet;
 template <> struct FbSet<float> { static constexpr int fb_max = 128; static constexpr int fb_min = 8; };
 template <> struct FbSet<double> { static constexpr int fb_max = 64; static constexpr int fb_min = 4; };
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fitting groups of several baselines (use_redundancy / joint groups, calibration.py:173-184).
+//
+// Baselines of a group share one coefficient vector; those that also share the row block of the basis (a *run*: a
+// redundant set) have the SAME forward product v = A c, and the adjoint is linear, A^T sum_b gbar_v_b.  So per
+// (run, channel block) the tile is loaded once, the forward runs once, the per-channel stage runs for every baseline
+// of the run (kThreads / FB baselines at a time, one thread per (baseline, channel)) and one adjoint takes the sum.
+// With 20x fewer basis products than baselines on a redundant HERA-350 the pass is bound by the per-sample arrays.
+// Work item = a range of (run, channel block) units of one group; runs are cut to at most kRunMax baselines by the host.
+constexpr int kRunMax = 64;
+
+template <typename T, int FB, int MODE, bool REG>
+__device__ __forceinline__ void process_group_item(const FusedArgs<T>& A, const Item it, unsigned char* smem, int item_idx) {
+  using C = TileCfg<T, FB>;
+  using T2 = vec2_t<T>;
+  constexpr int VEC = C::VEC;
+  constexpr int LPR = C::LPR;
+  constexpr int NS = C::NS;
+  constexpr int L = kMaxLoads;
+  constexpr int BPT = kThreads / FB;  // baselines handled side by side in the per-channel stage
+  constexpr bool FWD = (MODE != MODE_INIT);
+  constexpr bool BWD = (MODE == MODE_GRAD || MODE == MODE_INIT);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int fq = tid % LPR;
+  const int ks = tid / LPR;
+  const int f0 = fq * VEC;
+  const int sub = tid / FB;
+  const int ch = tid % FB;
+  const int nvec = it.nvec;
+  const int ntpb = A.fpad / FB;
+  const int tile_elems = nvec * FB;
+
+  T2* s_pv = reinterpret_cast<T2*>(smem);   // [2][kWaves][FB] forward partials, by unit parity
+  T2* s_gv = s_pv + 2 * kWaves * FB;        // [2][FB] gbar_v summed over the run (e0 part, w part)
+  T2* s_c = s_gv + 2 * FB;                  // [MAXK]
+  T2* s_gvp = s_c + C::MAXK;                // [2][BPT][FB] per-sub-row sums of gbar_v
+  int2* s_ant = reinterpret_cast<int2*>(s_gvp + 2 * kThreads);  // [kRunMax] antenna pairs of the current run
+
+  typedef T stage_t __attribute__((ext_vector_type(16 / sizeof(T))));
+  if (FWD) {
+    for (int k = tid; k < C::MAXK; k += kThreads) {
+      T2 c;
+      c.x = k < nvec ? A.c_r[it.coff + k] : (T)0;
+      c.y = k < nvec ? A.c_i[it.coff + k] : (T)0;
+      s_c[k] = c;
+    }
+    __syncthreads();
+  }
+  unsigned voff[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) voff[l] = (unsigned)((min(l * NS + ks, nvec - 1) * FB + f0) * (int)sizeof(T));
+  T2 acc0[L], acc1[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) acc0[l].x = acc0[l].y = acc1[l].x = acc1[l].y = 0;
+  double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
+
+  struct Operands { T d_r, d_i, w; T2 g0, g1; };
+  int cur_run = -1;
+  int2 run = make_int2(0, 0);
+  long long t_off = 0;
+  for (int u = it.tile0; u < it.tile1; ++u) {
+    const int r = u / ntpb;
+    const int fbk = u - r * ntpb;
+    if (r != cur_run) {
+      // new run: its baseline range, its tile offset, its antenna pairs (read by the per-channel stage from LDS, so the
+      // gains loads do not wait on an index load)
+      cur_run = r;
+      run = A.runs[it.bl0 + r];
+      run.x = __builtin_amdgcn_readfirstlane(run.x);
+      run.y = __builtin_amdgcn_readfirstlane(run.y);
+      const long long to = A.bl_tile[run.x];
+      t_off = ((long long)__builtin_amdgcn_readfirstlane((int)(to >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)to);
+      if (tid < run.y - run.x) s_ant[tid] = A.bl_ant[run.x + tid];
+    }
+    const int nb = run.y - run.x;
+    const char* src = reinterpret_cast<const char*>(A.tiles + t_off + (long long)fbk * tile_elems);
+    stage_t stage[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) stage[l] = *reinterpret_cast<const stage_t*>(src + voff[l]);
+
+    T2* pv_par = s_pv + (u & 1) * kWaves * FB;
+    if (FWD) {
+      T2 pv[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) pv[k].x = pv[k].y = 0;
+#pragma unroll
+      for (int l = 0; l < L; ++l) fma_rows(pv, stage[l], s_c[l * NS + ks]);
+#pragma unroll
+      for (int sft = LPR; sft < 64; sft <<= 1) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          pv[k].x += __shfl_xor(pv[k].x, sft, 64);
+          pv[k].y += __shfl_xor(pv[k].y, sft, 64);
+        }
+      }
+      if (lane < LPR) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) pv_par[wave * FB + f0 + k] = pv[k];
+      }
+    }
+    __syncthreads();  // forward partials and s_ant visible
+
+    // ---- per-channel stage: thread = (baseline sub-row, channel); the forward product is the same for every baseline
+    T vr = 0, vi = 0;
+    if (FWD) {
+#pragma unroll
+      for (int wv = 0; wv < kWaves; ++wv) {
+        const T2 p = pv_par[wv * FB + ch];
+        vr += p.x;
+        vi += p.y;
+      }
+    }
+    auto load_operands = [&](int b) {
+      Operands o;
+      const int bc = min(b, nb - 1);  // sub-rows past the run re-read its last baseline and are masked below
+      const long long row = (long long)(run.x + bc) * A.fpad + fbk * FB + ch;
+      o.d_r = o.d_i = o.w = 0;
+      o.g0.x = o.g0.y = o.g1.x = o.g1.y = 0;
+      if (MODE != MODE_MODEL) {
+        o.d_r = A.data_r[row];
+        o.d_i = A.data_i[row];
+        o.w = A.wgts[row];
+      }
+      if (MODE == MODE_LOSS || MODE == MODE_GRAD) {
+        const int2 ant = s_ant[bc];
+        o.g0 = A.gains[(long long)ant.x * A.fpad + fbk * FB + ch];
+        o.g1 = A.gains[(long long)ant.y * A.fpad + fbk * FB + ch];
+      }
+      return o;
+    };
+    T2 gvsum, gwsum;
+    gvsum.x = gvsum.y = gwsum.x = gwsum.y = 0;
+    Operands nxt = load_operands(sub);
+    for (int b0 = 0; b0 < nb; b0 += BPT) {
+      const Operands o = nxt;
+      if (b0 + BPT < nb) nxt = load_operands(b0 + BPT + sub);
+      const int b = b0 + sub;
+      const bool valid = b < nb;
+      const long long row = (long long)(run.x + min(b, nb - 1)) * A.fpad + fbk * FB + ch;
+      const T w = valid ? o.w : (T)0;
+      if (MODE == MODE_MODEL) {
+        if (valid) {
+          A.model_r[row] = vr;
+          A.model_i[row] = vi;
+        }
+      } else if (MODE == MODE_INIT) {
+        const T msk = (!valid || fabs(o.w) <= (T)1e-8) ? (T)0 : (T)1;
+        gvsum.x += o.d_r * msk;
+        gvsum.y += o.d_i * msk;
+      } else {
+        const T G_r = o.g0.x * o.g1.x + o.g0.y * o.g1.y;
+        const T G_i = o.g0.y * o.g1.x - o.g0.x * o.g1.y;
+        const T m_r = G_r * vr - G_i * vi;
+        const T m_i = G_i * vr + G_r * vi;
+        const T r_r = o.d_r - m_r;
+        const T r_i = o.d_i - m_i;
+        loss_acc += (double)(w * (r_r * r_r + r_i * r_i));
+        if (REG) {
+          sr_acc += (double)(w * m_r);
+          si_acc += (double)(w * m_i);
+        }
+        if (MODE == MODE_GRAD) {
+          const T e_r = (T)-2 * w * r_r;
+          const T e_i = (T)-2 * w * r_i;
+          gvsum.x += G_r * e_r + G_i * e_i;
+          gvsum.y += G_r * e_i - G_i * e_r;
+          T2 q;
+          q.x = vr * e_r + vi * e_i;
+          q.y = vr * e_i - vi * e_r;
+          if (valid) A.q0[row] = q;
+          if (REG) {
+            gwsum.x += G_r * w;
+            gwsum.y += -G_i * w;
+            T2 qw;
+            qw.x = vr * w;
+            qw.y = -vi * w;
+            if (valid) A.q1[row] = qw;
+          }
+        }
+      }
+    }
+    if (BWD) {
+      s_gvp[sub * FB + ch] = gvsum;
+      if (REG) s_gvp[kThreads + sub * FB + ch] = gwsum;
+      __syncthreads();
+      if (tid < FB) {
+        T2 a, b2;
+        a.x = a.y = b2.x = b2.y = 0;
+#pragma unroll
+        for (int sb = 0; sb < BPT; ++sb) {
+          const T2 p = s_gvp[sb * FB + tid];
+          a.x += p.x;
+          a.y += p.y;
+          if (REG) {
+            const T2 p2 = s_gvp[kThreads + sb * FB + tid];
+            b2.x += p2.x;
+            b2.y += p2.y;
+          }
+        }
+        s_gv[tid] = a;
+        if (REG) s_gv[FB + tid] = b2;
+      }
+      __syncthreads();
+      T2 gv0[VEC], gv1[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        gv0[k] = s_gv[f0 + k];
+        if (REG) gv1[k] = s_gv[FB + f0 + k];
+      }
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        fma_cols(acc0[l], stage[l], gv0);
+        if (REG) fma_cols(acc1[l], stage[l], gv1);
+      }
+    }
+    // the next unit's first barrier separates this unit's reads of s_ant / s_gv / s_gvp from their next writes, except
+    // for s_ant, which a new run rewrites before that barrier:
+    if (u + 1 < it.tile1 && (u + 1) / ntpb != r) __syncthreads();
+  }
+
+  // ---- item epilogue: loss partials (double), coefficient-gradient partials
+  if (MODE == MODE_LOSS || MODE == MODE_GRAD) {
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(s_pv);
+    const double l = ldsum(loss_acc);
+    const double sr = REG ? ldsum(sr_acc) : 0.0;
+    const double si = REG ? ldsum(si_acc) : 0.0;
+    if (lane == 0) {
+      s_red[wave] = l;
+      s_red[kWaves + wave] = sr;
+      s_red[2 * kWaves + wave] = si;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double a = 0, b = 0, c = 0;
+      for (int wv = 0; wv < kWaves; ++wv) {
+        a += s_red[wv];
+        b += s_red[kWaves + wv];
+        c += s_red[2 * kWaves + wv];
+      }
+      A.part[(size_t)item_idx * 4 + 0] = a;
+      A.part[(size_t)item_idx * 4 + 1] = b;
+      A.part[(size_t)item_idx * 4 + 2] = c;
+    }
+  }
+  if (BWD) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int sft = 1; sft < LPR; sft <<= 1) {
+        acc0[l].x += __shfl_xor(acc0[l].x, sft, 64);
+        acc0[l].y += __shfl_xor(acc0[l].y, sft, 64);
+        if (REG) {
+          acc1[l].x += __shfl_xor(acc1[l].x, sft, 64);
+          acc1[l].y += __shfl_xor(acc1[l].y, sft, 64);
+        }
+      }
+      const int k = l * NS + ks;
+      if (fq == 0 && k < nvec) {
+        A.gcp0_r[it.goff + k] = acc0[l].x;
+        A.gcp0_i[it.goff + k] = acc0[l].y;
+        if (REG) {
+          A.gcp1_r[it.goff + k] = acc1[l].x;
+          A.gcp1_i[it.goff + k] = acc1[l].y;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int FB>
+constexpr size_t group_lds_bytes() {
+  return (2 * (size_t)kWaves * FB + 2 * (size_t)FB + TileCfg<T, FB>::MAXK + 2 * (size_t)kThreads) * 2 * sizeof(T) + kRunMax * sizeof(int2) + 64;
+}
+
 #ifndef CAL_WAVES_EU
 #define CAL_WAVES_EU 4
 #endif
@@ -515,14 +794,30 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((sizeo
 void fused_basis_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (A.state->done | A.state->done_after) return;
-  const Item it = A.items[blockIdx.x];
+  const int idx = A.item_base + blockIdx.x;
+  const Item it = A.items[idx];
   constexpr int FBM = FbSet<T>::fb_max;
   const int fb = 1 << it.fb_log2;
-  if (fb == FBM) process_item<T, FBM, MODE, REG>(A, it, smem, blockIdx.x);
-  else if (fb == FBM / 2) process_item<T, FBM / 2, MODE, REG>(A, it, smem, blockIdx.x);
-  else if (fb == FBM / 4) process_item<T, FBM / 4, MODE, REG>(A, it, smem, blockIdx.x);
-  else if (fb == FBM / 8) process_item<T, FBM / 8, MODE, REG>(A, it, smem, blockIdx.x);
-  else process_item<T, FBM / 16, MODE, REG>(A, it, smem, blockIdx.x);
+  if (fb == FBM) process_item<T, FBM, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 2) process_item<T, FBM / 2, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 4) process_item<T, FBM / 4, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 8) process_item<T, FBM / 8, MODE, REG>(A, it, smem, idx);
+  else process_item<T, FBM / 16, MODE, REG>(A, it, smem, idx);
+}
+
+template <typename T, int MODE, bool REG>
+__global__ __launch_bounds__(kThreads) void fused_group_kernel(const FusedArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (A.state->done | A.state->done_after) return;
+  const int idx = A.item_base + blockIdx.x;
+  const Item it = A.items[idx];
+  constexpr int FBM = FbSet<T>::fb_max;
+  const int fb = 1 << it.fb_log2;
+  if (fb == FBM) process_group_item<T, FBM, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 2) process_group_item<T, FBM / 2, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 4) process_group_item<T, FBM / 4, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 8) process_group_item<T, FBM / 8, MODE, REG>(A, it, smem, idx);
+  else process_group_item<T, FBM / 16, MODE, REG>(A, it, smem, idx);
 }
 
 // ---- sum the partial coefficient gradients of multi-item groups: gc[n] = sum_q gcp[goff_q + k]

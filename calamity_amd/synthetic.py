@@ -224,3 +224,28 @@ def copy_uvdata(uvd):
     import copy
 
     return copy.deepcopy(uvd)
+
+
+def merge_redundant_groups(prob, truth, start, tol=0.1):
+    """Turn a one-group-per-baseline problem into its ``use_redundancy=True`` form (calibration.py:173-184 with redundant
+    groups as fitting groups): baselines with the same vector (to ``tol`` metres, orientation i -> j) share ONE coefficient
+    vector and one basis row block.  Coefficients of a group are those of its first member; the data are left as they are
+    (no longer exactly representable -- fine for loss / gradient / throughput checks)."""
+    antpos = truth["antpos"]
+    vec = antpos[prob.bl_ant1] - antpos[prob.bl_ant0]
+    key = np.round(vec[:, :2] / tol).astype(np.int64)
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inv = np.asarray(inv).ravel()
+    order = np.argsort(inv, kind="stable")
+    counts = np.bincount(inv)
+    coff = prob.grp_coff
+    c_r = np.concatenate([start["c_r"][coff[g] : coff[g + 1]] for g in first])
+    c_i = np.concatenate([start["c_i"][coff[g] : coff[g + 1]] for g in first])
+    out = FitProblem(
+        nants=prob.nants, nfreqs=prob.nfreqs, basis=prob.basis, grp_basis=prob.grp_basis[first].astype(np.int32),
+        grp_bl_start=np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), bl_ant0=prob.bl_ant0[order], bl_ant1=prob.bl_ant1[order],
+        bl_rowblk=np.zeros(prob.nbls, dtype=np.int32), data_r=prob.data_r[order], data_i=prob.data_i[order], wgts=prob.wgts[order],
+        sky_r=None if prob.sky_r is None else prob.sky_r[order], sky_i=None if prob.sky_i is None else prob.sky_i[order],
+    )
+    out.validate()
+    return out, dict(start, c_r=c_r, c_i=c_i)

@@ -22,6 +22,8 @@ def child(args):
         prob, start = pickle.load(open(args.cache, "rb"))
     else:
         prob, truth, start = synthetic.make_config(args.config, max_bls=args.max_bls, with_sky=True)
+        if args.redundant:
+            prob, start = synthetic.merge_redundant_groups(prob, truth, start)
         if args.cache:
             import pickle
             pickle.dump((prob, start), open(args.cache, "wb"), protocol=4)
@@ -58,6 +60,7 @@ if __name__ == "__main__":
     ap.add_argument("--layout", default="stream")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--reg", action="store_true")
+    ap.add_argument("--redundant", action="store_true", help="merge redundant baselines into shared-coefficient groups")
     ap.add_argument("--cache", default="/tmp/kbench_problem.pkl")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("libs", nargs="*")
