@@ -265,7 +265,7 @@ def main():
     # measured streaming peaks of this box and, for orientation, the only configuration the
     # reference publishes a rate for (tutorial notebook: 15 antennas, 105 baselines x 200 channels, Adamax, 61.77 steps/s
     # on a P100) -- single-GPU runs only, after the solvers above have released their memory
-    peaks, tutorial = None, None
+    peaks, tutorial, redundant = None, None, None
     if rank == 0 and world == 1 and not args.no_shared:
         for s_ in solvers:
             s_.synchronize()
@@ -288,6 +288,21 @@ def main():
         tutorial = {"steps_per_s": 5000 / (time.perf_counter() - t0), "config": f"{tp.nants} antennas, {tp.nbls} baselines x 200 channels, Adamax lr 1e-2, fp32",
                     "reference_published_steps_per_s": 61.77, "reference_hardware": "Tesla P100, TensorFlow eager (examples/Calamity_Tutorial.ipynb:1178)"}
         ts.close()
+        # BASELINE config 5: the same array with every redundant set as ONE fitting group (shared coefficients)
+        if args.config == "hera350" and args.max_bls is None:
+            rp, rstart = synthetic.merge_redundant_groups(prob, truth, start)
+            rs = HipFitSolver(dtype=dtype)
+            rs.set_problem(rp, layout="shared")
+            rs.set_params(rstart["g_r"], rstart["g_i"], rstart["c_r"], rstart["c_i"])
+            rs.set_optimizer(args.optimizer, learning_rate=1e-2)
+            rs.run(5, record=False)
+            rs.synchronize()
+            t0 = time.perf_counter()
+            rs.run(200, record=True, tol=0.0)
+            rs.synchronize()
+            redundant = {"steps_per_s": 200 / (time.perf_counter() - t0), "config": f"{rp.ngrps} fitting groups (redundant sets, up to "
+                         f"{int(np.diff(rp.grp_bl_start).max())} baselines each) over the same {rp.nbls} baselines, sum nvec = {rp.ncoeffs}"}
+            rs.close()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -342,6 +357,7 @@ def main():
                 "device_memory_GB": solvers[0].memory_bytes() / 1e9 * len(solvers),
                 "shared_layout": shared,
                 "tutorial_notebook_config": tutorial,
+                "redundant_groups_config": redundant,
             },
         }
         if not args.no_cpu_baseline:

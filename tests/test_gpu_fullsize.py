@@ -160,3 +160,30 @@ def test_hera350_against_the_c_oracle(hera350):
     assert np.allclose(losses, olosses, rtol=1e-4)
     assert relnorm(g_r, og_r) <= 1e-3 and relnorm(c_r, oc_r) <= 1e-3 and relnorm(c_i, oc_i) <= 1e-3
     s.close()
+
+
+def test_hera350_redundant_groups_against_the_c_oracle():
+    """BASELINE config 5 (shared multi-baseline fitting groups): every redundant set of the hex array is one fitting group
+    (up to 330 baselines share a coefficient vector and one basis row block).  Loss and gradients, fp64 and fp32, both
+    layouts, with and without the regulariser, against the C restatement."""
+    from oracle.ref_c import CRef
+
+    p0, truth, start0 = synthetic.make_config("hera350", with_sky=True)
+    p, start = synthetic.merge_redundant_groups(p0, truth, start0)
+    assert p.ngrps < p0.ngrps / 10 and np.diff(p.grp_bl_start).max() > 100
+    start = perturbed(p, start, 4)
+    c = CRef(p, np.float64, nthreads=16)
+    for reg in (False, True):
+        pr, pi = (float(np.sum(p.sky_r * p.wgts)) * 0.9, float(np.sum(p.sky_i * p.wgts)) * 1.1) if reg else (0.0, 0.0)
+        c.set_regularization("sum" if reg else None, pr, pi)
+        ref = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        for dtype, tl, tg in ((np.float64, 1e-10, 1e-10), (np.float32, 1e-5, 2e-4)):
+            for layout in ("stream", "shared"):
+                s = solver_for(p, start, dtype, layout)
+                if reg:
+                    s.set_regularization("sum", pr, pi)
+                out = s.eval_grads()
+                assert abs(out[0] - ref[0]) <= tl * abs(ref[0]), (dtype, layout, reg)
+                for a, b in zip(out[1:], ref[1:]):
+                    assert relnorm(a, b) <= tg, (dtype, layout, reg)
+                s.close()
