@@ -11,11 +11,11 @@
 //   finalize_kernel    : loss.numpy(), the use_min bookkeeping and the tolerance test of the python loop (:699-717),
 //                        kept on the device so a step needs no host synchronisation.
 //
-// Design (MI355X): the basis is stored tile-major in HBM -- per baseline [channel block][vector][FB channels] --
-// so one workgroup streams each (baseline, channel block) tile exactly once with 16-byte coalesced loads, parks it in
-// LDS (row stride padded by 16 B: conflict-free ds_read_b32 along channels for A c and ds_read_b128 along vectors for
-// A^T gbar_v), and runs forward AND adjoint from that single HBM read.  The next tile's loads are issued before the
-// current tile is consumed (register double buffer), several workgroups per CU keep >64 KB per CU in flight.
+// Design (MI355X): the basis is stored tile-major in HBM -- per baseline [channel block][vector][FB channels] -- so one
+// workgroup streams each (baseline, channel block) tile exactly once with 16-byte coalesced loads and runs forward AND
+// adjoint out of the registers the tile was loaded into (process_item); LDS carries only per-channel vectors.  Several
+// workgroups per CU keep > 100 KB per CU in flight.  Fitting groups of several baselines go through process_group_item,
+// which shares one tile load / forward / adjoint among the baselines of a redundant run.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -517,8 +517,9 @@ template <> struct FbSet<double> { static constexpr int fb_max = 64; static cons
 // (run, channel block) the tile is loaded once, the forward runs once, the per-channel stage runs for every baseline
 // of the run (kThreads / FB baselines at a time, one thread per (baseline, channel)) and one adjoint takes the sum.
 // With 20x fewer basis products than baselines on a redundant HERA-350 the pass is bound by the per-sample arrays.
-// Work item = a range of (run, channel block) units of one group; runs are cut to at most kRunMax baselines by the host.
-constexpr int kRunMax = 64;
+// Work item = a range of (run, channel block) units of one group; runs are cut to at most kRunMax baselines by the host
+// (64 -> 256 took 4 % off the redundant HERA-350 pass: fewer tile loads / forwards / adjoints per baseline).
+constexpr int kRunMax = 256;
 
 template <typename T, int FB, int MODE, bool REG>
 __device__ __forceinline__ void process_group_item(const FusedArgs<T>& A, const Item it, unsigned char* smem, int item_idx) {
