@@ -360,7 +360,7 @@ def main():
                 "redundant_groups_config": redundant,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(prob, start, dtype, args.optimizer, args.cpu_sample_bls, args.reg)
             out["cpu_baseline"]["strong"] = cpu_baseline_strong(prob, start, dtype, args.optimizer, args.reg == "sum")
         print(json.dumps(out))
