@@ -100,3 +100,36 @@ def test_more_vectors_than_a_tile_holds_is_reported():
         s.set_problem(p, layout="stream")
     assert e.value.code == -5 and "897" in str(e.value)
     s.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_model_and_init_on_multi_baseline_groups(dtype):
+    """cal_solver_model (yield_fg_model_array, calibration.py:402-444) and cal_solver_init_coeffs (the A^T (d [w != 0]) part
+    of tensorize_fg_coeffs, :875-902) for groups of many baselines, with and without several row blocks."""
+    from calamity_amd.solver import HipFitSolver
+
+    tol = 1e-11 if dtype == np.float64 else 2e-5
+    for rowblocks in (False, True):
+        p, start = random_problem([5, 60, 130, 300], [4, 7, 70, 20], seed=6, rowblocks=rowblocks)
+        F = p.nfreqs
+        coff = p.grp_coff
+        for layout in ("stream", "shared"):
+            s = HipFitSolver(dtype=dtype)
+            s.set_problem(p, layout=layout)
+            s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+            m_r, m_i = s.model()
+            s.init_coeffs(p.data_r, p.data_i)
+            _, _, c_r, c_i = s.get_params()
+            for g in range(p.ngrps):
+                blk = p.basis[p.grp_basis[g]]
+                cg = start["c_r"][coff[g]:coff[g + 1]] + 1j * start["c_i"][coff[g]:coff[g + 1]]
+                acc = np.zeros(blk.shape[1], dtype=np.complex128)
+                for b in range(p.grp_bl_start[g], p.grp_bl_start[g + 1]):
+                    A = blk[p.bl_rowblk[b] * F:(p.bl_rowblk[b] + 1) * F]
+                    v = A @ cg
+                    assert np.linalg.norm((m_r[b] + 1j * m_i[b]) - v) <= tol * max(np.linalg.norm(v), 1e-30)
+                    msk = ~np.isclose(p.wgts[b], 0.0)
+                    acc += A.T @ ((p.data_r[b] + 1j * p.data_i[b]) * msk)
+                got = c_r[coff[g]:coff[g + 1]] + 1j * c_i[coff[g]:coff[g + 1]]
+                assert np.linalg.norm(got - acc) <= tol * np.linalg.norm(acc)
+            s.close()
