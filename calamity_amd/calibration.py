@@ -842,60 +842,58 @@ def read_calibrate_and_model_dpss(
 
 
 def input_output_parser():
-    """Input / output / selection / device arguments -- calibration.py:1820-1858."""
+    """Input / output / selection / device arguments (names, types and defaults of calibration.py:1820-1858)."""
     ap = argparse.ArgumentParser()
     sp = ap.add_argument_group("Input and Output Arguments.")
-    sp.add_argument("--input_data_files", type=str, nargs="+", help="paths to data files to calibrate.", required=True)
-    sp.add_argument("--input_model_files", type=str, nargs="+", help="paths to model files to set overal amplitude and phase.")
-    sp.add_argument("--input_gain_files", type=str, nargs="+", help="paths to gains to use as a staring point.")
-    sp.add_argument("--resid_outfilename", type=str, default=None, help="postfix for resid output file.")
-    sp.add_argument("--model_outfilename", type=str, default=None, help="postfix for foreground model file.")
-    sp.add_argument("--gain_outfilename", type=str, default=None, help="path for writing fitted gains.")
-    # the reference's default is the string "False" (truthy), :1831
-    sp.add_argument("--clobber", action="store_true", default="False", help="Overwrite existing outputs.")
-    sp.add_argument("--x_orientation", default="east", type=str, help="x_orientation of feeds to set in output gains.")
-    sp.add_argument("--bllen_min", default=0.0, type=float, help="minimum baseline length to include in calibration and outputs.")
-    sp.add_argument("--bllen_max", default=np.inf, type=float, help="maximum baseline length to include in calbration and outputs.")
-    sp.add_argument("--bl_ew_min", default=0.0, type=float, help="minimum EW baseline component to include in calibration and outputs.")
-    sp.add_argument("--ex_ants", default=None, type=int, nargs="+", help="Antennas to exclude from calibration and modeling.")
-    sp.add_argument("--select_ants", default=None, type=int, nargs="+", help="Antennas to select exclusively for calibration and modeling.")
-    sp.add_argument("--gpu_index", default=None, type=int, help="Index of GPU to run on (if on a multi-GPU machine).")
-    sp.add_argument("--gpu_memory_limit", default=None, type=int, help="Limit GPU memory use to this many GBytes.")
-    sp.add_argument("--precision", default=32, type=int, help="Number of bits to keep track of.")
+    sp.add_argument("--input_data_files", type=str, nargs="+", required=True, help="visibility files to fit")
+    sp.add_argument("--input_model_files", type=str, nargs="+", help="sky-model files that fix the overall amplitude and phase")
+    sp.add_argument("--input_gain_files", type=str, nargs="+", help="gain files to start from")
+    sp.add_argument("--resid_outfilename", type=str, default=None, help="where to write the residual visibilities")
+    sp.add_argument("--model_outfilename", type=str, default=None, help="where to write the foreground model")
+    sp.add_argument("--gain_outfilename", type=str, default=None, help="where to write the fitted gains")
+    # the reference's default is the string "False" (truthy), :1831 -- kept
+    sp.add_argument("--clobber", action="store_true", default="False", help="replace existing output files")
+    sp.add_argument("--x_orientation", default="east", type=str, help="x_orientation recorded in the output gains")
+    sp.add_argument("--bllen_min", default=0.0, type=float, help="shortest baseline kept [m]")
+    sp.add_argument("--bllen_max", default=np.inf, type=float, help="longest baseline kept [m]")
+    sp.add_argument("--bl_ew_min", default=0.0, type=float, help="baselines need an east-west extent above this [m]")
+    sp.add_argument("--ex_ants", default=None, type=int, nargs="+", help="antennas to leave out")
+    sp.add_argument("--select_ants", default=None, type=int, nargs="+", help="use only these antennas")
+    sp.add_argument("--gpu_index", default=None, type=int, help="which GPU of the node to run on")
+    sp.add_argument("--gpu_memory_limit", default=None, type=int, help="refuse fits that need more device memory than this [GiB]")
+    sp.add_argument("--precision", default=32, type=int, help="32 or 64 bit arithmetic")
     return ap
 
 
 def fitting_argparser():
-    """General fitting arguments -- calibration.py:1861-1930."""
+    """General fitting arguments (names, types and defaults of calibration.py:1861-1930)."""
     ap = input_output_parser()
     sp = ap.add_argument_group("General Fitting Arguments.")
-    sp.add_argument("--tol", type=float, default=1e-14, help="Stop gradient descent after cost function converges to within this value.")
-    sp.add_argument("--optimizer", type=str, default="Adamax", help="First order optimizer to use for gradient descent.")
-    sp.add_argument("--maxsteps", type=int, default=10000, help="Max number of steps to iterate during optimization.")
-    sp.add_argument("--verbose", default=False, action="store_true", help="lots of text ouputs.")
-    sp.add_argument("--use_min", default=False, action="store_true",
-                    help="Use params for mimimum cost function derived. Otherwise, use the params last visited by the descent. Avoids momentum overshoot.")
-    sp.add_argument("--use_redundancy", default=False, action="store_true", help="Model redundant visibilities with the same set of foreground parameters.")
-    sp.add_argument("--correct_model", default=True, action="store_true", help="Remove gain effects from foreground model.")
-    sp.add_argument("--correct_resid", default=False, action="store_true", help="Apply fitted gains to the fitted residuals.")
-    sp.add_argument("--graph_mode", default=False, action="store_true", help="Accepted for compatibility; there is no tracing compiler on this path.")
-    sp.add_argument("--init_guesses_from_previous_time_step", default=False, action="store_true",
-                    help="initialize gain and foreground guesses from previous time step when calibrating multiple times.")
-    sp.add_argument("--learning_rate", type=float, default=1e-2, help="gradient descent learning rate.")
-    sp.add_argument("--red_tol", type=float, default=1.0, help="Tolerance for determining redundancy between baselines [meters].")
-    sp.add_argument("--skip_threshold", type=float, default=0.5, help="Skip and flag time/polarization if more then this fractionf of data is flagged.")
-    sp.add_argument("--model_regularization", type=str, default="post_hoc")
-    sp.add_argument("--nsamples_in_weights", default=False, action="store_true", help="Weight contributions to MSE by nsamples.")
-    sp.add_argument("--use_model_snr_weights", default=False, action="store_true", help="If True, weight contributions to MSE as proportional to SNR.")
-    sp.add_argument("--use_autocorrs_in_weights", default=False, action="store_true", help="If True, use autocorrelations to derive relative SNR weights.")
+    sp.add_argument("--tol", type=float, default=1e-14, help="stop when the loss changes by less than this between steps")
+    sp.add_argument("--optimizer", type=str, default="Adamax", help="Adam or Adamax")
+    sp.add_argument("--maxsteps", type=int, default=10000, help="upper bound on recorded descent steps")
+    sp.add_argument("--verbose", default=False, action="store_true", help="print progress")
+    sp.add_argument("--use_min", default=False, action="store_true", help="return the parameters of the lowest loss seen instead of the last ones")
+    sp.add_argument("--use_redundancy", default=False, action="store_true", help="one set of foreground coefficients per redundant group")
+    sp.add_argument("--correct_model", default=True, action="store_true", help="divide the fitted gains out of the model")
+    sp.add_argument("--correct_resid", default=False, action="store_true", help="calibrate the residuals with the fitted gains")
+    sp.add_argument("--graph_mode", default=False, action="store_true", help="accepted for compatibility; nothing is traced on this path")
+    sp.add_argument("--init_guesses_from_previous_time_step", default=False, action="store_true", help="warm-start each time from the previous one")
+    sp.add_argument("--learning_rate", type=float, default=1e-2, help="optimizer step size")
+    sp.add_argument("--red_tol", type=float, default=1.0, help="baselines closer than this are redundant [m]")
+    sp.add_argument("--skip_threshold", type=float, default=0.5, help="flag a (time, polarization) whose unflagged fraction is below this")
+    sp.add_argument("--model_regularization", type=str, default="post_hoc", help="sum, post_hoc or None")
+    sp.add_argument("--nsamples_in_weights", default=False, action="store_true", help="multiply the weights by nsamples")
+    sp.add_argument("--use_model_snr_weights", default=False, action="store_true", help="weight samples by the model's signal to noise")
+    sp.add_argument("--use_autocorrs_in_weights", default=False, action="store_true", help="inverse-variance weights from the autocorrelations")
     return ap
 
 
 def dpss_fit_argparser():
-    """DPSS-specific arguments on top of the general ones -- calibration.py:1933-1942."""
+    """DPSS-specific arguments on top of the general ones (calibration.py:1933-1942)."""
     ap = fitting_argparser()
     sp = ap.add_argument_group("DPSS Specific Fitting Arguments.")
-    sp.add_argument("--horizon", default=1.0, type=float, help="Fraction of horizon delay to model with DPSS modes.")
-    sp.add_argument("--min_dly", default=0.0, type=float, help="Minimum delay [ns] to model with DPSS modes.")
-    sp.add_argument("--offset", default=0.0, type=float, help="Offset from horizon delay [ns] to model with DPSS modes.")
+    sp.add_argument("--horizon", default=1.0, type=float, help="fraction of the horizon delay covered by the basis")
+    sp.add_argument("--min_dly", default=0.0, type=float, help="smallest delay half-width of a basis [ns]")
+    sp.add_argument("--offset", default=0.0, type=float, help="delay added beyond the horizon [ns]")
     return ap
