@@ -239,7 +239,7 @@ struct SolverT final : cal_solver {
     if (nbls < 2048 && !getenv("CALAMITY_HIP_FORCE_MFMA")) want_mfma = false;
     for (int g = 0; g < ngrps && want_mfma; ++g) want_mfma = (d->grp_bl_start[g + 1] - d->grp_bl_start[g]) == 1;
     for (int u = 0; u < nbasis && want_mfma; ++u) want_mfma = d->basis_nrowblk[u] == 1 && d->basis_nvec[u] <= 32 * kMaxNT;
-    if ((long long)(nbls + 1) * (nfreqs + kChunk) >= (1LL << 31)) want_mfma = false;  // the dense kernel uses 32-bit sample offsets
+    if ((long long)(nbls + 1) * (nfreqs + kChunk) >= (1LL << 29)) want_mfma = false;  // the dense kernel uses 32-bit BYTE offsets of 8-byte samples
     if (want_mfma) fb_used_max = std::max(fb_used_max, kChunk);
     fpad = (nfreqs + fb_used_max - 1) / fb_used_max * fb_used_max;
     lds_bytes = 0;

@@ -345,30 +345,45 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int slot = half * 8 + j;
-      ob[j] = (unsigned)s_bl[slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col);
-      og0[j] = (unsigned)s_bl[16 + slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col);
-      og1[j] = (unsigned)s_bl[32 + slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col);
+      // BYTE offsets (of a float for ob, of a float2 for og0 / og1): scalar base + unsigned 32-bit byte offset is the form
+      // hipcc turns into `global_load v, v_off, s[base]`; with element offsets it builds a 64-bit address pair per load
+      // (207 v_lshl_add_u64 and 40 registers spilled to scratch in this branch before)
+      ob[j] = ((unsigned)s_bl[slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col)) * 4u;
+      og0[j] = ((unsigned)s_bl[16 + slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col)) * 8u;
+      og1[j] = ((unsigned)s_bl[32 + slot] * (unsigned)A.fpad + (unsigned)(w4 * 32 + col)) * 8u;
     }
     auto request = [&](int ci, ElemIn& E) {
-      const float* dr = A.data_r + ci * kChunk;  // scalar bases of this chunk
-      const float* di = A.data_i + ci * kChunk;
-      const float* wg = A.wgts + ci * kChunk;
-      const float2* gn = A.gains + ci * kChunk;
+      // address = array base (kernel argument, scalar) + 32-bit byte offset (lane offset + chunk offset), added per
+      // load.  Written with the chunk folded into the base instead, loop-invariant code motion turned every load address
+      // into a loop-invariant 64-bit VGPR pair: 80 registers, spilled to scratch and reloaded behind a full vmcnt(0)
+      // wait in front of every load -- the element waves ran their loads one at a time.
+      const char* dr = reinterpret_cast<const char*>(A.data_r);
+      const char* di = reinterpret_cast<const char*>(A.data_i);
+      const char* wg = reinterpret_cast<const char*>(A.wgts);
+      const char* gn = reinterpret_cast<const char*>(A.gains);
+      const unsigned c4 = (unsigned)ci * (kChunk * 4u), c8 = (unsigned)ci * (kChunk * 8u);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        E.dr[j] = dr[ob[j]];
-        E.di[j] = di[ob[j]];
-        E.w[j] = wg[ob[j]];
-        E.g0[j] = gn[og0[j]];
-        E.g1[j] = gn[og1[j]];
+        E.dr[j] = *reinterpret_cast<const float*>(dr + (ob[j] + c4));
+        E.di[j] = *reinterpret_cast<const float*>(di + (ob[j] + c4));
+        E.w[j] = *reinterpret_cast<const float*>(wg + (ob[j] + c4));
+        E.g0[j] = *reinterpret_cast<const float2*>(gn + (og0[j] + c8));
+        E.g1[j] = *reinterpret_cast<const float2*>(gn + (og1[j] + c8));
       }
+      // Drain the wave's vector-memory queue once per tick.  With this request left in flight across the barrier and
+      // under the other set's process() (its eight gbar_G stores included) the gradients differed from run to run at
+      // HERA-350 size, although every compiler-inserted wait looked sufficient; a counted wait (vmcnt(40)) did not cure
+      // it, the full drain does (results bit-identical to the previous, serialised, element code) and costs nothing
+      // measurable: the loads of one tick are all in flight together, which is what hides their latency.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
     const float al_r = A.use_alpha ? (float)A.state->alpha_r : 0.f, al_i = A.use_alpha ? (float)A.state->alpha_i : 0.f;
     auto process = [&](int ci, const ElemIn& E) {
       const f32x4* vin = reinterpret_cast<const f32x4*>(s_v + (size_t)(ci & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + half * 8);
       f32x4* gout = reinterpret_cast<f32x4*>(s_g + (size_t)(ci & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + half * 8);
-      float2* qo = A.q0 + ci * kChunk;
+      char* qo = reinterpret_cast<char*>(A.q0);
+      const unsigned qc8 = (unsigned)ci * (kChunk * 8u);
       float lt = 0.f, st_r = 0.f, st_i = 0.f;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
             float2 q;
             q.x = vr * e_r + vi * e_i;
             q.y = vr * e_i - vi * e_r;
-            qo[ob[j]] = q;
+            *reinterpret_cast<float2*>(qo + (2u * ob[j] + qc8)) = q;
           }
         }
         if (GRAD) {
