@@ -187,3 +187,29 @@ def test_hera350_redundant_groups_against_the_c_oracle():
                 for a, b in zip(out[1:], ref[1:]):
                     assert relnorm(a, b) <= tg, (dtype, layout, reg)
                 s.close()
+
+
+def test_hera350_results_are_bitwise_reproducible(hera350):
+    """No float atomics anywhere and fixed summation orders: repeated evaluations on the same solver must agree bit for
+    bit, for every kernel family (general kernel on both layouts and precisions, dense kernel, group kernel).  Guards
+    against synchronisation slips, which show up as run-to-run differences at this size first."""
+    p, start = hera350
+    truth = {"antpos": synthetic.hex_positions(p.nants)}
+    cases = [(p, start, np.float32, "stream"), (p, start, np.float32, "shared"), (p, start, np.float64, "stream")]
+    pr, sr = synthetic.merge_redundant_groups(p, truth, start)
+    cases.append((pr, sr, np.float32, "shared"))
+    for prob, st, dtype, layout in cases:
+        s = solver_for(prob, st, dtype, layout)
+        s.set_regularization("sum", float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts)))
+        first = s.eval_grads()
+        for _ in range(3):
+            again = s.eval_grads()
+            assert again[0] == first[0]
+            for a, b in zip(again[1:], first[1:]):
+                assert np.array_equal(a, b), (dtype, layout)
+        s.set_regularization(None)
+        first = s.eval_grads()
+        for _ in range(3):
+            again = s.eval_grads()
+            assert again[0] == first[0] and all(np.array_equal(a, b) for a, b in zip(again[1:], first[1:])), (dtype, layout)
+        s.close()
