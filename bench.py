@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--max-bls", type=int, default=None, help="bounded sample of the baselines (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shared", action="store_true", help="skip the extra shared-layout (MFMA) measurement")
+    ap.add_argument("--extras", action="store_true", help="also time the tutorial-notebook and the redundant-groups configurations (they launch "
+                    "the same kernels at other sizes, so a rocprofv3 --stats summary of such a run no longer averages the headline launches alone)")
     ap.add_argument("--cpu-sample-bls", type=int, default=192)
     return ap.parse_args()
 
@@ -275,6 +277,7 @@ def main():
             peaks["busy_shader_clock_MHz"] = _lib.busy_clock_mhz(0)
         except Exception as e:  # noqa: BLE001 -- a probe must not take the benchmark down
             peaks = {"error": str(e)}
+    if rank == 0 and world == 1 and args.extras:
         tp, _, tstart = synthetic.make_problem(15, 200, f0=100e6, df=100e3, seed=0)
         ts = HipFitSolver(dtype=np.float32)
         ts.set_problem(tp, layout="shared")

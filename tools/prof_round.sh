@@ -15,4 +15,5 @@ echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc -o write --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
 echo "write done"
 python3 bench.py --steps 20 --warmup 3 > $out/bench.log 2>&1
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --extras > $out/bench_extras.log 2>&1
 tail -1 $out/bench.log | cut -c1-400
