@@ -54,7 +54,9 @@ enum cal_layout {
  * bl in [grp_bl_start[g], grp_bl_start[g+1]).  Basis block u is row-major
  * [basis_nrowblk[u] * nfreqs][basis_nvec[u]] starting at basis_data + basis_offset[u] elements
  * ("Nfreqs x Ncomponents", modeling.py:288-289); baseline bl uses rows
- * [bl_rowblk[bl] * nfreqs, (bl_rowblk[bl] + 1) * nfreqs). */
+ * [bl_rowblk[bl] * nfreqs, (bl_rowblk[bl] + 1) * nfreqs).  Consecutive baselines of a group with the same row block
+ * (a redundant set, use_redundancy=True) share one forward / adjoint product on the device.
+ * Limits: basis_nvec <= 896 (CAL_ERR_UNSUPPORTED beyond); all index arrays are validated (CAL_ERR_INVALID). */
 typedef struct cal_problem_desc {
   int32_t nants;
   int32_t nfreqs;
