@@ -1,5 +1,5 @@
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from calamity_amd import synthetic
 from calamity_amd.solver import HipFitSolver
 import pickle
