@@ -149,43 +149,57 @@ def tensorize_data(
     (``* nsamples`` / ``* UVFlag.weights``) divided by their sum over ALL baselines and channels (:282-303).
     """
     ants_map_inv = {ants_map[i]: i for i in ants_map}
+    # One pass over the blt axis: (ant1, ant2) -> row of this time; then every chunk is a fancy-indexed gather instead of
+    # a python loop with a key lookup per baseline (1.3 s per call at HERA-350).
+    tsel = np.where(np.isclose(np.asarray(uvdata.time_array), time, rtol=0.0, atol=1e-7))[0]
+    row_of = {(int(a), int(b)): int(t) for a, b, t in zip(np.asarray(uvdata.ant_1_array)[tsel], np.asarray(uvdata.ant_2_array)[tsel], tsel)}
+    pols = np.asarray(uvdata.polarization_array)
+    polnum = polstr2num(polarization, x_orientation=uvdata.x_orientation)
+    swap = {-7: -8, -8: -7, -3: -4, -4: -3}  # conjugating swaps the feeds of cross-hand products
+    pind = int(np.where(pols == polnum)[0][0])
+    pind_conj = np.where(pols == swap.get(polnum, polnum))[0]
+    if weights is not None:
+        wsel = np.where(np.isclose(np.asarray(weights.time_array), time, rtol=0.0, atol=1e-7))[0]
+        wrow_of = {(int(a), int(b)): int(t) for a, b, t in zip(np.asarray(weights.ant_1_array)[wsel], np.asarray(weights.ant_2_array)[wsel], wsel)}
+        wpol = int(np.where(np.asarray(weights.polarization_array) == polstr2num(polarization, x_orientation=weights.x_orientation))[0][0])
     data_r, data_i, wgts = [], [], []
     wgtsum = 0.0
     for chunk in corr_inds:
         ngrps, nbls = len(chunk), len(chunk[0])
-        dr = np.zeros((ngrps, nbls, uvdata.Nfreqs), dtype=dtype)
-        di = np.zeros_like(dr)
-        w = np.zeros_like(dr)
-        for gnum, fitgrp in enumerate(chunk):
-            for bnum, (i, j) in enumerate(fitgrp):
-                ap = ants_map_inv[i], ants_map_inv[j]
-                dinds1, dinds2, pol_ind = uvdata._key2inds(ap + (polarization,))
-                if len(dinds1) > 0:
-                    dinds, conjugate, pind = dinds1, False, pol_ind[0]
-                else:
-                    dinds, conjugate, pind = dinds2, True, pol_ind[1]
-                pind = int(np.atleast_1d(pind)[0])
-                dind = _time_ind(uvdata.time_array, dinds, time)
-                data = uvdata.data_array[dind, 0, :, pind] / data_scale_factor
-                iflags = ~uvdata.flag_array[dind, 0, :, pind]
-                nsamples = uvdata.nsample_array[dind, 0, :, pind]
-                if conjugate:
-                    data = np.conj(data)
-                dr[gnum, bnum] = data.real.astype(dtype)
-                di[gnum, bnum] = data.imag.astype(dtype)
-                if weights is None:
-                    wrow = iflags.astype(dtype)
-                else:
-                    winds = weights.antpair2ind(*ap) if ap in weights.get_antpairs() else weights.antpair2ind(*ap[::-1])
-                    wind = _time_ind(weights.time_array, winds, time)
-                    polnum = np.where(weights.polarization_array == polstr2num(polarization, x_orientation=weights.x_orientation))[0][0]
-                    wrow = weights.weights_array[wind, 0, :, polnum].astype(dtype) * iflags
-                if nsamples_in_weights:
-                    wrow = wrow * nsamples
-                w[gnum, bnum] = wrow
-                wgtsum += np.sum(w[gnum, bnum])
-        data_r.append(dr)
-        data_i.append(di)
+        rows = np.empty(ngrps * nbls, dtype=np.int64)
+        conj = np.zeros(ngrps * nbls, dtype=bool)
+        wrows = np.empty(ngrps * nbls, dtype=np.int64)
+        n = 0
+        for fitgrp in chunk:
+            for i, j in fitgrp:
+                ap = (ants_map_inv[i], ants_map_inv[j])
+                r = row_of.get(ap)
+                if r is None:
+                    r = row_of[ap[::-1]]  # KeyError if the pair is in the data in neither order, like _key2inds
+                    conj[n] = True
+                rows[n] = r
+                if weights is not None:
+                    wr = wrow_of.get(ap)
+                    wrows[n] = wrow_of[ap[::-1]] if wr is None else wr
+                n += 1
+        any_conj = bool(conj.any())
+        if any_conj and len(pind_conj) == 0:
+            raise KeyError(f"polarization {polarization}: the conjugate product is not in the data")
+        pcol = np.where(conj, int(pind_conj[0]) if len(pind_conj) else pind, pind)
+        data = np.asarray(uvdata.data_array)[rows, 0, :, pcol] / data_scale_factor
+        iflags = ~np.asarray(uvdata.flag_array)[rows, 0, :, pcol]
+        if any_conj:
+            data = np.where(conj[:, None], np.conj(data), data)
+        if weights is None:
+            w = iflags.astype(dtype)
+        else:
+            w = np.asarray(weights.weights_array)[wrows, 0, :, wpol].astype(dtype) * iflags
+        if nsamples_in_weights:
+            w = w * np.asarray(uvdata.nsample_array)[rows, 0, :, pcol]
+        w = np.ascontiguousarray(w, dtype=dtype).reshape(ngrps, nbls, uvdata.Nfreqs)
+        wgtsum += float(np.sum(w, dtype=np.float64))
+        data_r.append(np.ascontiguousarray(data.real, dtype=dtype).reshape(ngrps, nbls, uvdata.Nfreqs))
+        data_i.append(np.ascontiguousarray(data.imag, dtype=dtype).reshape(ngrps, nbls, uvdata.Nfreqs))
         wgts.append(w)
     wgts = [(w / wgtsum).astype(dtype) for w in wgts]
     return data_r, data_i, wgts
