@@ -636,19 +636,22 @@ def calibrate_and_model_tensor(
 
 
 def _insert_model_rows(uvdata, time, polarization, ants_map, prob, m_r, m_i, scale_factor):
-    """insert_model_into_uvdata_tensor (calibration.py:741-795) from per-baseline rows instead of cubes."""
+    """insert_model_into_uvdata_tensor (calibration.py:741-795) from per-baseline rows instead of cubes: one lookup table
+    for the time slice, then a single scatter."""
     ants_inv = {v: k for k, v in ants_map.items()}
-    antpairs_data = set(uvdata.get_antpairs())
     polnum = np.where(uvdata.polarization_array == polstr2num(polarization, x_orientation=uvdata.x_orientation))[0][0]
+    tsel = np.where(np.isclose(np.asarray(uvdata.time_array), time, rtol=0.0, atol=1e-7))[0]
+    row_of = {(int(a), int(b)): int(t) for a, b, t in zip(np.asarray(uvdata.ant_1_array)[tsel], np.asarray(uvdata.ant_2_array)[tsel], tsel)}
+    rows = np.empty(prob.nbls, dtype=np.int64)
+    sign = np.ones(prob.nbls)
     for b in range(prob.nbls):
         ap = (ants_inv[int(prob.bl_ant0[b])], ants_inv[int(prob.bl_ant1[b])])
-        if ap in antpairs_data:
-            dind = _time_ind(uvdata.time_array, uvdata.antpair2ind(ap), time)
-            row = m_r[b] + 1j * m_i[b]
-        else:
-            dind = _time_ind(uvdata.time_array, uvdata.antpair2ind(ap[::-1]), time)
-            row = m_r[b] - 1j * m_i[b]
-        uvdata.data_array[dind, 0, :, polnum] = row * scale_factor
+        r = row_of.get(ap)
+        if r is None:  # stored in the reversed order: the model of (j, i) is the conjugate
+            r = row_of[ap[::-1]]
+            sign[b] = -1.0
+        rows[b] = r
+    uvdata.data_array[rows, 0, :, polnum] = (np.asarray(m_r) + 1j * sign[:, None] * np.asarray(m_i)) * scale_factor
 
 
 def calibrate_and_model_dpss(
