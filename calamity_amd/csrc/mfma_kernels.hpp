@@ -95,6 +95,12 @@ __device__ __forceinline__ void ring_load(f32x4_t& dst, const f32x4_t* sbase, un
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 1) : "memory"); \
     __builtin_amdgcn_sched_barrier(0);                               \
   } while (0)
+// Every phase ends with kRing requests whose data nobody reads (they keep the count in RING_WAIT constant).  They must have
+// landed before the next phase requests into the same registers: two loads in flight to ONE register are not guaranteed
+// to write it in issue order (the compiler never creates that situation: it waits on such a write-after-write), and a
+// late discarded load overwrote fresh operands -- gradients that differed from run to run, but only once the element
+// waves stopped being the slow side of every barrier, which until then had given those requests time to land.
+#define RING_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 template <bool GRAD>
 __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArgs A) {
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
         for (int j = 0; j < 16; ++j) acc[j] = acc2[j] = 0.f;
         const f32x4* tile = akf4 + ((size_t)(k * 4 + w4) * ngk) * 64;  // scalar base; item g at + 64 g
         auto src = [&](int g) { return tile + (g < ngk ? g : ngk - 1) * 64; };
+        RING_DRAIN();
         ring_load(R0, src(0), voff);
         ring_load(R1, src(1), voff);
         ring_load(R2, src(2), voff);
@@ -248,6 +255,7 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
 #pragma unroll
           for (int v = 0; v < 4; ++v) a[v] = gp[(8 * cg + 2 * v) * kSW];
         };
+        RING_DRAIN();
         ring_load(R0, src(0), voff);
         ring_load(R1, src(1), voff);
         ring_load(R2, src(2), voff);
@@ -370,12 +378,6 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
         E.g0[j] = *reinterpret_cast<const float2*>(gn + (og0[j] + c8));
         E.g1[j] = *reinterpret_cast<const float2*>(gn + (og1[j] + c8));
       }
-      // Drain the wave's vector-memory queue once per tick.  With this request left in flight across the barrier and
-      // under the other set's process() (its eight gbar_G stores included) the gradients differed from run to run at
-      // HERA-350 size, although every compiler-inserted wait looked sufficient; a counted wait (vmcnt(40)) did not cure
-      // it, the full drain does (results bit-identical to the previous, serialised, element code) and costs nothing
-      // measurable: the loads of one tick are all in flight together, which is what hides their latency.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
     const float al_r = A.use_alpha ? (float)A.state->alpha_r : 0.f, al_i = A.use_alpha ? (float)A.state->alpha_i : 0.f;
