@@ -321,7 +321,8 @@ def main():
                 if "fused_basis_kernel" in k and ", 1, false>" in k:
                     traffic, traffic_src = v["hbm_bytes"], os.path.relpath(pmc_path, ROOT)
         out = {
-            "metric": "Adam steps/sec (chi2 eval/sec in extra), HERA-350 1024ch DPSS; %HBM roofline",
+            "metric": "Adam steps/sec (chi2 eval/sec in extra), " + {"hera350": "HERA-350", "hera37": "HERA-37", "tutorial": "tutorial-scale"}.get(args.config, args.config)
+                      + f" {prob.nfreqs}ch DPSS; %HBM roofline",
             "value": value,
             "unit": "steps/s",
             "n_gpus": world,
