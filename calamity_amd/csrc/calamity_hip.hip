@@ -913,19 +913,13 @@ struct SolverT final : cal_solver {
     const long long gn = 2LL * nants * fpad;
     T* gsnap = gains_snap.p ? gains_snap.as<T>() : gains.as<T>();
     T* csnap = coef_snap.p ? coef_snap.as<T>() : coef.as<T>();
-    if (opt.optimizer == CAL_OPT_ADAM) {
-      hipLaunchKernelGGL((adam_kernel<T, 0>), dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, stream, gains.as<T>(), comm.as<T>(),
-                         gains_m.as<T>(), gains_v.as<T>(), gsnap, gn, st);
-      if (!freeze_model)
-        hipLaunchKernelGGL((adam_kernel<T, 0>), dim3((unsigned)((2LL * ncoef + 255) / 256)), dim3(256), 0, stream, coef.as<T>(),
-                           grad_c0(), coef_m.as<T>(), coef_v.as<T>(), csnap, 2LL * ncoef, st);
-    } else {
-      hipLaunchKernelGGL((adam_kernel<T, 1>), dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, stream, gains.as<T>(), comm.as<T>(),
-                         gains_m.as<T>(), gains_v.as<T>(), gsnap, gn, st);
-      if (!freeze_model)
-        hipLaunchKernelGGL((adam_kernel<T, 1>), dim3((unsigned)((2LL * ncoef + 255) / 256)), dim3(256), 0, stream, coef.as<T>(),
-                           grad_c0(), coef_m.as<T>(), coef_v.as<T>(), csnap, 2LL * ncoef, st);
-    }
+    const AdamSet<T> ga{gains.as<T>(), comm.as<T>(), gains_m.as<T>(), gains_v.as<T>(), gsnap, gn};
+    const AdamSet<T> ca{coef.as<T>(), grad_c0(), coef_m.as<T>(), coef_v.as<T>(), csnap, freeze_model ? 0LL : 2LL * ncoef};
+    const int nblk_a = (int)((ga.n + 255) / 256), nblk_b = (int)((ca.n + 255) / 256);
+    if (opt.optimizer == CAL_OPT_ADAM)
+      hipLaunchKernelGGL((adam2_kernel<T, 0>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st);
+    else
+      hipLaunchKernelGGL((adam2_kernel<T, 1>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st);
     HIP_TRY(hipGetLastError());
     return CAL_OK;
   }

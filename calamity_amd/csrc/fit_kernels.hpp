@@ -6,7 +6,7 @@
 //                        reverse-mode adjoints tf.GradientTape produces for them (:664-666): A^T gbar_v and gbar_G.
 //   gain_grad_kernel   : the scatter-add that is the gradient of tf.gather (:1594-1597) -- done as a sorted
 //                        per-antenna segmented reduction, deterministic, no float atomics.
-//   adam_kernel        : opt.apply_gradients (:667) for tf.optimizers.Adam / Adamax (Keras semantics), applied to
+//   adam2_kernel       : opt.apply_gradients (:667) for tf.optimizers.Adam / Adamax (Keras semantics), applied to
 //                        the re and im variables independently (:596-603).
 //   finalize_kernel    : loss.numpy(), the use_min bookkeeping and the tolerance test of the python loop (:699-717),
 //                        kept on the device so a step needs no host synchronisation.
@@ -1050,29 +1050,36 @@ __global__ void combine_coeff_kernel(T* __restrict__ g0_r, T* __restrict__ g0_i,
   g0_i[i] += ar * g1_i[i] + ai * g1_r[i];
 }
 
-// ---- Keras Adam / Adamax on a flat real array (re and im planes are independent real variables)
+// ---- Keras Adam / Adamax on flat real arrays (re and im planes are independent real variables, :596-603):
+//   m <- b1 m + (1 - b1) g;  Adam: v <- b2 v + (1 - b2) g^2, p <- p - lr_t m / (sqrt(v) + eps), lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
+//   Adamax: u <- max(b2 u, |g|), p <- p - lr / (1 - b1^t) m / (u + eps);  epsilon outside the bias correction.
+// both parameter sets in one launch (one launch less per step matters for problems whose whole step is ~20 us): blocks
+// [0, nblk_a) update set a (the gains), the rest set b (the coefficients).
+template <typename T>
+struct AdamSet { T* p; const T* g; T* m; T* v; T* snap; long long n; };
 template <typename T, int OPT>
-__global__ __launch_bounds__(256) void adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m,
-                                                    T* __restrict__ v, T* __restrict__ snap, long long n, const DevState* st) {
+__global__ __launch_bounds__(256) void adam2_kernel(const AdamSet<T> a, const AdamSet<T> b, int nblk_a, const DevState* st) {
   if (st->done) return;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool first = (int)blockIdx.x < nblk_a;
+  const AdamSet<T>& S = first ? a : b;
+  const long long i = (long long)(first ? blockIdx.x : blockIdx.x - nblk_a) * blockDim.x + threadIdx.x;
+  if (i >= S.n) return;
   const T b1 = (T)st->beta1, b2 = (T)st->beta2, eps = (T)st->eps;
-  const T gi = g[i];
-  const T mi = b1 * m[i] + ((T)1 - b1) * gi;
-  T pi = p[i];
+  const T gi = S.g[i];
+  const T mi = b1 * S.m[i] + ((T)1 - b1) * gi;
+  T pi = S.p[i];
   if (OPT == 0) {
-    const T vi = b2 * v[i] + ((T)1 - b2) * gi * gi;
-    v[i] = vi;
+    const T vi = b2 * S.v[i] + ((T)1 - b2) * gi * gi;
+    S.v[i] = vi;
     pi -= (T)st->lr_t * mi / (sqrt(vi) + eps);
   } else {
-    const T ui = fmax(b2 * v[i], fabs(gi));
-    v[i] = ui;
+    const T ui = fmax(b2 * S.v[i], fabs(gi));
+    S.v[i] = ui;
     pi -= (T)st->lr_u * mi / (ui + eps);
   }
-  m[i] = mi;
-  p[i] = pi;
-  if (st->improved) snap[i] = pi;
+  S.m[i] = mi;
+  S.p[i] = pi;
+  if (st->improved) S.snap[i] = pi;
 }
 
 // ---- setup kernels -------------------------------------------------------------------------------------------
