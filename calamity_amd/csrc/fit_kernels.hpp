@@ -282,9 +282,10 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     const int ch = (tid + FB * (tau % (kThreads / FB))) % kThreads;  // this thread's channel in the per-channel stage
     if (ch < FB) {
       if (MODE != MODE_MODEL) {
-        d_r = A.data_r[o_row + ch];
-        d_i = A.data_i[o_row + ch];
-        w = A.wgts[o_row + ch];
+        // read once per pass: non-temporal, like the tiles of the streaming layout
+        d_r = __builtin_nontemporal_load(A.data_r + o_row + ch);
+        d_i = __builtin_nontemporal_load(A.data_i + o_row + ch);
+        w = __builtin_nontemporal_load(A.wgts + o_row + ch);
       }
       if (MODE == MODE_LOSS || MODE == MODE_GRAD) {
         g0 = A.gains[(long long)ant.x * A.fpad + fbk * FB + ch];
