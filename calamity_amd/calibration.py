@@ -15,10 +15,12 @@ gradient-descent fitter: ``calibrate_and_model_dpss`` (:1503-1584) -> ``calibrat
 There is no CPU fallback: without the HIP library / a GPU these functions raise.
 """
 import argparse
+import concurrent.futures
 import copy
 import datetime
 import json
 import os
+import threading
 
 import numpy as np
 
@@ -267,7 +269,9 @@ def get_solver(fg_model_comps, dtype=np.float32, layout=None, device=None):
     layout = layout or os.environ.get("CALAMITY_AMD_LAYOUT", "shared")
     if device is None:
         device = _DEVICE["index"] if _DEVICE["index"] is not None else int(os.environ.get("CALAMITY_AMD_DEVICE", "0"))
-    key = (dtype.str, layout, device)
+    # one solver per calling thread: a handle is not re-entrant, and concurrent fits of different (pol, time) slices
+    # (calibrate_and_model_tensor, parallel_fits > 1) each need their own device buffers and stream
+    key = (dtype.str, layout, device, threading.get_ident())
     if key not in cache:
         shell = copy.copy(fg_model_comps)
         shell.data_r = shell.data_i = shell.wgts = None
@@ -511,11 +515,18 @@ def calibrate_and_model_tensor(
     init_guesses_from_previous_time_step=False,
     skip_threshold=0.5,
     use_model_snr_weights=False,
+    parallel_fits=None,
     **opt_kwargs,
 ):
     """Simultaneous calibration and foreground fitting -- calibration.py:963-1331, same arguments, defaults and
     returns ``(model, resid, gains, fit_history)``.  See SURVEY.md Appendix A for the behaviours kept (the input
-    ``uvdata`` is not modified; a supplied ``gains`` object IS modified in place and returned)."""
+    ``uvdata`` is not modified; a supplied ``gains`` object IS modified in place and returned).
+
+    ``parallel_fits`` (not in the reference; default 1, or the environment variable CALAMITY_AMD_PARALLEL_FITS) fits that
+    many (polarization, time) slices concurrently, each on its own solver and HIP stream.  The slices are independent
+    fits unless ``init_guesses_from_previous_time_step`` is set (then this is ignored), every kernel is deterministic, so
+    the results are identical to the sequential loop; small arrays, whose steps are launch-latency bound, gain almost
+    linearly."""
     antpairs_data = uvdata.get_antpairs()
     if not include_autos:
         antpairs_data = set([ap for ap in antpairs_data if ap[0] != ap[1]])
@@ -551,79 +562,107 @@ def calibrate_and_model_tensor(
     )
     echo(f"{datetime.datetime.now()}Finished Converting Foreground Modeling Components to Tensors...\n", verbose=verbose)
     del fg_model_comps_dict
-    solver = get_solver(fg_model_comps, dtype)
     prob = fg_model_comps
+    if parallel_fits is None:
+        parallel_fits = int(os.environ.get("CALAMITY_AMD_PARALLEL_FITS", "1"))
+    if init_guesses_from_previous_time_step:
+        parallel_fits = 1
+    times = np.unique(uvdata.time_array)
+
+    def fit_slice(polnum, pol, time_index, time, carry):
+        """One (polarization, time) slice: calibration.py:1167-1330.  ``carry`` holds the parameters handed from one time
+        to the next when init_guesses_from_previous_time_step is set."""
+        solver = get_solver(fg_model_comps, dtype)
+        hist = None
+        g_r, g_i, fg_r, fg_i = carry.get("g_r"), carry.get("g_i"), carry.get("fg_r"), carry.get("fg_i")
+        echo(f"{datetime.datetime.now()} Working on time {time_index + 1} of {uvdata.Ntimes}...\n", verbose=verbose)
+        bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
+        frac_unflagged = np.count_nonzero(~uvdata.flag_array[bltsel, 0, :, polnum]) / (uvdata.Nbls * uvdata.Nfreqs)
+        if frac_unflagged >= skip_threshold:
+            rmsdata = np.sqrt(np.mean(np.abs(uvdata.data_array[bltsel, 0, :, polnum][~uvdata.flag_array[bltsel, 0, :, polnum]]) ** 2.0))
+            echo(f"{datetime.datetime.now()} Tensorizing data...\n", verbose=verbose)
+            data_r, data_i, wgts = tensorize_data(
+                uvdata, corr_inds=corr_inds, ants_map=ants_map, polarization=pol, time=time, data_scale_factor=rmsdata,
+                weights=weights, nsamples_in_weights=nsamples_in_weights, dtype=dtype,
+            )
+            if sky_model is not None:
+                echo(f"{datetime.datetime.now()} Tensorizing sky model...\n", verbose=verbose)
+                sky_model_r, sky_model_i, _ = tensorize_data(
+                    sky_model, corr_inds=corr_inds, ants_map=ants_map, polarization=pol, time=time, data_scale_factor=rmsdata,
+                    weights=weights, dtype=dtype,
+                )
+            else:
+                sky_model_r, sky_model_i = None, None
+            if carry["first_time"] or not init_guesses_from_previous_time_step:
+                carry["first_time"] = False
+                echo(f"{datetime.datetime.now()} Tensorizing Gains...\n", verbose=verbose)
+                g_r, g_i = tensorize_gains(gains, dtype=dtype, time=time, polarization=pol)
+                echo(f"{datetime.datetime.now()} Tensorizing Foreground coeffs...\n", verbose=verbose)
+                # tensorize_fg_coeffs x 2 (calibration.py:1219-1233): one device pass gives both components
+                w_flat = _flatten(wgts, prob)
+                zeros = np.zeros_like(w_flat)
+                solver.set_data(zeros, zeros, w_flat)
+                c_r, c_i = _init_coeffs(solver, prob, _flatten(sky_model_r, prob), _flatten(sky_model_i, prob))
+                fg_r = coeffs_to_chunks(prob, c_r, dtype)
+                fg_i = coeffs_to_chunks(prob, c_i, dtype)
+                if use_model_snr_weights:
+                    m_r, m_i = solver.model()
+                    w_new = (np.square(m_r.astype(np.float64)) + np.square(m_i.astype(np.float64))) * w_flat
+                    w_new = w_new / np.sum(w_new)
+                    start = 0
+                    new_wgts = []
+                    for w in wgts:
+                        n = w.shape[0] * w.shape[1]
+                        new_wgts.append(w_new[start : start + n].reshape(w.shape).astype(dtype))
+                        start += n
+                    wgts = new_wgts
+            (g_r, g_i, fg_r, fg_i, hist) = fit_gains_and_foregrounds(
+                g_r=g_r, g_i=g_i, fg_r=fg_r, fg_i=fg_i, data_r=data_r, data_i=data_i, wgts=wgts, fg_comps=fg_model_comps,
+                corr_inds=corr_inds, optimizer=optimizer, use_min=use_min, freeze_model=freeze_model,
+                notebook_progressbar=notebook_progressbar, verbose=verbose, tol=tol, dtype=dtype, maxsteps=maxsteps,
+                graph_mode=graph_mode, n_profile_steps=n_profile_steps, profile_log_dir=profile_log_dir,
+                sky_model_r=sky_model_r, sky_model_i=sky_model_i, model_regularization=model_regularization, **opt_kwargs,
+            )
+            # yield_fg_model_array x 2 + insert_model_into_uvdata_tensor (calibration.py:1271-1292) without the
+            # nants x nants cubes: one A c pass for both components, rows written straight back
+            solver.set_params(c_r=coeffs_from_chunks(prob, fg_r), c_i=coeffs_from_chunks(prob, fg_i))
+            m_r, m_i = solver.model()
+            _insert_model_rows(model, time, pol, ants_map, prob, m_r, m_i, scale_factor=rmsdata)
+            insert_gains_into_uvcal(uvcal=gains, time=time, polarization=pol, gains_re=g_r, gains_im=g_i)
+        else:
+            echo(f"{datetime.datetime.now()}: Only {frac_unflagged * 100}-percent of data unflagged. Skipping...\n", verbose=verbose)
+            flag_poltime(resid, time=time, polarization=pol)
+            flag_poltime(gains, time=time, polarization=pol)
+            flag_poltime(model, time=time, polarization=pol)
+            pass  # the reference's fit_history[polnum] = "skipped!" (:1309) is overwritten at the end of the pol loop (:1321)
+        if not freeze_model and model_regularization == "post_hoc" and np.any(~model.flag_array[bltsel]):
+            renormalize(
+                uvdata_reference_model=sky_model, uvdata_deconv=model, gains=gains, polarization=pol, time=time,
+                additional_flags=uvdata.flag_array,
+            )
+        carry.update(g_r=g_r, g_i=g_i, fg_r=fg_r, fg_i=fg_i)
+        return hist
+
+    # one pool for the whole call: its threads (and with them their solvers, get_solver) serve every polarization
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=parallel_fits) if parallel_fits > 1 and len(times) > 1 else None
     for polnum, pol in enumerate(uvdata.get_pols()):
         echo(f"{datetime.datetime.now()} Working on pol {pol}, {polnum + 1} of {uvdata.Npols}...\n", verbose=verbose)
         fit_history_p = {}
-        first_time = True
-        for time_index, time in enumerate(np.unique(uvdata.time_array)):
-            echo(f"{datetime.datetime.now()} Working on time {time_index + 1} of {uvdata.Ntimes}...\n", verbose=verbose)
-            bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
-            frac_unflagged = np.count_nonzero(~uvdata.flag_array[bltsel, 0, :, polnum]) / (uvdata.Nbls * uvdata.Nfreqs)
-            if frac_unflagged >= skip_threshold:
-                rmsdata = np.sqrt(np.mean(np.abs(uvdata.data_array[bltsel, 0, :, polnum][~uvdata.flag_array[bltsel, 0, :, polnum]]) ** 2.0))
-                echo(f"{datetime.datetime.now()} Tensorizing data...\n", verbose=verbose)
-                data_r, data_i, wgts = tensorize_data(
-                    uvdata, corr_inds=corr_inds, ants_map=ants_map, polarization=pol, time=time, data_scale_factor=rmsdata,
-                    weights=weights, nsamples_in_weights=nsamples_in_weights, dtype=dtype,
-                )
-                if sky_model is not None:
-                    echo(f"{datetime.datetime.now()} Tensorizing sky model...\n", verbose=verbose)
-                    sky_model_r, sky_model_i, _ = tensorize_data(
-                        sky_model, corr_inds=corr_inds, ants_map=ants_map, polarization=pol, time=time, data_scale_factor=rmsdata,
-                        weights=weights, dtype=dtype,
-                    )
-                else:
-                    sky_model_r, sky_model_i = None, None
-                if first_time or not init_guesses_from_previous_time_step:
-                    first_time = False
-                    echo(f"{datetime.datetime.now()} Tensorizing Gains...\n", verbose=verbose)
-                    g_r, g_i = tensorize_gains(gains, dtype=dtype, time=time, polarization=pol)
-                    echo(f"{datetime.datetime.now()} Tensorizing Foreground coeffs...\n", verbose=verbose)
-                    # tensorize_fg_coeffs x 2 (calibration.py:1219-1233): one device pass gives both components
-                    w_flat = _flatten(wgts, prob)
-                    zeros = np.zeros_like(w_flat)
-                    solver.set_data(zeros, zeros, w_flat)
-                    c_r, c_i = _init_coeffs(solver, prob, _flatten(sky_model_r, prob), _flatten(sky_model_i, prob))
-                    fg_r = coeffs_to_chunks(prob, c_r, dtype)
-                    fg_i = coeffs_to_chunks(prob, c_i, dtype)
-                    if use_model_snr_weights:
-                        m_r, m_i = solver.model()
-                        w_new = (np.square(m_r.astype(np.float64)) + np.square(m_i.astype(np.float64))) * w_flat
-                        w_new = w_new / np.sum(w_new)
-                        start = 0
-                        new_wgts = []
-                        for w in wgts:
-                            n = w.shape[0] * w.shape[1]
-                            new_wgts.append(w_new[start : start + n].reshape(w.shape).astype(dtype))
-                            start += n
-                        wgts = new_wgts
-                (g_r, g_i, fg_r, fg_i, fit_history_p[time_index]) = fit_gains_and_foregrounds(
-                    g_r=g_r, g_i=g_i, fg_r=fg_r, fg_i=fg_i, data_r=data_r, data_i=data_i, wgts=wgts, fg_comps=fg_model_comps,
-                    corr_inds=corr_inds, optimizer=optimizer, use_min=use_min, freeze_model=freeze_model,
-                    notebook_progressbar=notebook_progressbar, verbose=verbose, tol=tol, dtype=dtype, maxsteps=maxsteps,
-                    graph_mode=graph_mode, n_profile_steps=n_profile_steps, profile_log_dir=profile_log_dir,
-                    sky_model_r=sky_model_r, sky_model_i=sky_model_i, model_regularization=model_regularization, **opt_kwargs,
-                )
-                # yield_fg_model_array x 2 + insert_model_into_uvdata_tensor (calibration.py:1271-1292) without the
-                # nants x nants cubes: one A c pass for both components, rows written straight back
-                solver.set_params(c_r=coeffs_from_chunks(prob, fg_r), c_i=coeffs_from_chunks(prob, fg_i))
-                m_r, m_i = solver.model()
-                _insert_model_rows(model, time, pol, ants_map, prob, m_r, m_i, scale_factor=rmsdata)
-                insert_gains_into_uvcal(uvcal=gains, time=time, polarization=pol, gains_re=g_r, gains_im=g_i)
-            else:
-                echo(f"{datetime.datetime.now()}: Only {frac_unflagged * 100}-percent of data unflagged. Skipping...\n", verbose=verbose)
-                flag_poltime(resid, time=time, polarization=pol)
-                flag_poltime(gains, time=time, polarization=pol)
-                flag_poltime(model, time=time, polarization=pol)
-                fit_history[polnum] = "skipped!"
-            if not freeze_model and model_regularization == "post_hoc" and np.any(~model.flag_array[bltsel]):
-                renormalize(
-                    uvdata_reference_model=sky_model, uvdata_deconv=model, gains=gains, polarization=pol, time=time,
-                    additional_flags=uvdata.flag_array,
-                )
+        if pool is not None:
+            futures = {ti: pool.submit(fit_slice, polnum, pol, ti, t, {"first_time": True}) for ti, t in enumerate(times)}
+            for ti, fut in futures.items():
+                hist = fut.result()
+                if hist is not None:
+                    fit_history_p[ti] = hist
+        else:
+            carry = {"first_time": True}
+            for time_index, time in enumerate(times):
+                hist = fit_slice(polnum, pol, time_index, time, carry)
+                if hist is not None:
+                    fit_history_p[time_index] = hist
         fit_history[polnum] = fit_history_p
+    if pool is not None:
+        pool.shutdown()
     model_with_gains = cal_utils.apply_gains(model, gains, inverse=True)
     if not correct_model:
         model = model_with_gains
