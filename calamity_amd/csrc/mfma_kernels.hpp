@@ -101,6 +101,10 @@ __device__ __forceinline__ void ring_load(f32x4_t& dst, const f32x4_t* sbase, un
 // late discarded load overwrote fresh operands -- gradients that differed from run to run, but only once the element
 // waves stopped being the slow side of every barrier, which until then had given those requests time to land.
 #define RING_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// A ring register whose last request nobody reads is, to the compiler, free from that request on -- but the data lands
+// later, into whatever the register has been given to meanwhile.  RING_KEEP (placed behind a drain) reads all six, so they
+// stay allocated until their last request has landed.
+#define RING_KEEP() asm volatile("" ::"v"(R0), "v"(R1), "v"(R2), "v"(R3), "v"(R4), "v"(R5))
 
 template <bool GRAD>
 __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArgs A) {
@@ -180,6 +184,33 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
     const f32x4* sc4 = reinterpret_cast<const f32x4*>(s_c);
     const unsigned voff = (unsigned)lane * 16u;
     f32x4 R0, R1, R2, R3, R4, R5;  // the operand ring (kRing = 6 register quads)
+    R0 = R1 = R2 = R3 = R4 = R5 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // items of the adjoint phase of this wave (wave constants) and the operand address of an item of either phase; both
+    // clamp the item index, so an address always lies inside this panel's packed operand blocks
+    const int ng_per = (kChunk / 8) / nkq;  // channel groups (8 channels = 4 k-steps) of this wave: 16, 8 or 4
+    const int cg0 = kq * ng_per;
+    const int two = t1 >= 0 ? 1 : 0;
+    const int nitem = ng_per << two;
+    const bool has_b = GRAD && t0 >= 0;
+    auto f_addr = [&](int kk, int g) { return akf4 + ((size_t)(kk * 4 + w4) * ngk + (g < ngk ? g : ngk - 1)) * 64; };
+    auto b_addr = [&](int ci, int i) {
+      i = i < nitem ? i : nitem - 1;
+      const int cg = cg0 + (i >> two), t = (i & two) ? t1 : t0;
+      return afk4 + ((size_t)(ci * (kChunk / 8) + cg) * NT + t) * 64;
+    };
+    // Phase chaining: the last kRing requests of a phase (which used to fetch data nobody reads, only to keep the count of
+    // RING_WAIT constant) fetch the FIRST kRing items of the wave's next phase -- across the barrier too, the packed basis
+    // does not depend on the element waves -- so that phase starts with its operands in flight instead of an exposed L2
+    // round trip.  No register ever has two loads in flight.  nx_kind: 0 none, 1 forward of chunk nx_k, 2 adjoint of nx_k.
+    auto first_phase_of_tick = [&](int kk, int& kind, int& kx) {
+      kind = 0;
+      kx = 0;
+      if (!GRAD) return;  // the forward-only pass is bound by its element waves: chaining only adds scalar work there
+      if (kk >= nticks) return;
+      if (kk < nchunks) { kind = 1; kx = kk; }
+      else if (has_b && kk >= 2) { kind = 2; kx = kk - 2; }
+    };
+    bool primed = false;  // the ring already holds (in flight) the first kRing items of the phase about to start
     for (int k = 0; k < nticks; ++k) {
       WS_STAMP(sblk, k, 0);
       if (k < nchunks) {
@@ -189,15 +220,23 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
         for (int j = 0; j < 16; ++j) acc[j] = acc2[j] = 0.f;
         const f32x4* tile = akf4 + ((size_t)(k * 4 + w4) * ngk) * 64;  // scalar base; item g at + 64 g
         auto src = [&](int g) { return tile + (g < ngk ? g : ngk - 1) * 64; };
-        RING_DRAIN();
-        ring_load(R0, src(0), voff);
-        ring_load(R1, src(1), voff);
-        ring_load(R2, src(2), voff);
-        ring_load(R3, src(3), voff);
-        ring_load(R4, src(4), voff);
-        ring_load(R5, src(5), voff);
+        int nx_kind, nx_k;
+        if (has_b && k >= 2) { nx_kind = 2; nx_k = k - 2; }
+        else first_phase_of_tick(k + 1, nx_kind, nx_k);
+        auto nxt = [&](int j) { return nx_kind == 1 ? f_addr(nx_k, j) : nx_kind == 2 ? b_addr(nx_k, j) : src(ngk - 1); };
+        if (!primed) {
+          RING_DRAIN();
+          RING_KEEP();
+          ring_load(R0, src(0), voff);
+          ring_load(R1, src(1), voff);
+          ring_load(R2, src(2), voff);
+          ring_load(R3, src(3), voff);
+          ring_load(R4, src(4), voff);
+          ring_load(R5, src(5), voff);
+        }
+        primed = nx_kind != 0;
         f32x4 a_cur = (sc4 + 0)[lane], a_nxt;
-#define F_STEP(RJ, J)                                                                            \
+#define F_STEP(RJ, J, NEXTSRC)                                                                   \
   {                                                                                              \
     const int g = g0 + (J);                                                                      \
     a_nxt = (sc4 + (g + 1 < ngk ? g + 1 : ngk - 1) * 64)[lane];                                  \
@@ -209,17 +248,25 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
       acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], RJ[3], acc2, 0, 0, 0);               \
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
-    ring_load(RJ, src(g + kRing), voff);                                                         \
+    ring_load(RJ, NEXTSRC, voff);                                                                \
     a_cur = a_nxt;                                                                               \
   }
-        for (int g0 = 0; g0 < ngk; g0 += kRing) {
-          F_STEP(R0, 0)
-          F_STEP(R1, 1)
-          F_STEP(R2, 2)
-          F_STEP(R3, 3)
-          F_STEP(R4, 4)
-          F_STEP(R5, 5)
+        int g0 = 0;
+        for (; g0 + kRing < ngk; g0 += kRing) {
+          F_STEP(R0, 0, src(g + kRing))
+          F_STEP(R1, 1, src(g + kRing))
+          F_STEP(R2, 2, src(g + kRing))
+          F_STEP(R3, 3, src(g + kRing))
+          F_STEP(R4, 4, src(g + kRing))
+          F_STEP(R5, 5, src(g + kRing))
         }
+        // last group of steps: its requests belong to the next phase
+        F_STEP(R0, 0, nxt(0))
+        F_STEP(R1, 1, nxt(1))
+        F_STEP(R2, 2, nxt(2))
+        F_STEP(R3, 3, nxt(3))
+        F_STEP(R4, 4, nxt(4))
+        F_STEP(R5, 5, nxt(5))
 #undef F_STEP
         // accumulator regs 4 q .. 4 q + 3 of this lane = rows 8 q + 4 half + 0..3 of column (channel) w4*32 + col
         f32x4* vout = reinterpret_cast<f32x4*>(s_v + (size_t)(k & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + 4 * half);
@@ -238,10 +285,6 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
         // ---- B(k-2): rows = (slot, re|im), columns = vectors of tile t, K = this wave's slice of the chunk's channels.
         // item i = (channel group cg0 + i / ntl, tile i % ntl), ntl = 1 or 2 vector tiles per wave; 4 MFMAs per item
         const int ci = k - 2;
-        const int ng_per = (kChunk / 8) / nkq;  // channel groups (8 channels = 4 k-steps) of this wave: 16, 8 or 4
-        const int cg0 = kq * ng_per;
-        const int two = t1 >= 0 ? 1 : 0;
-        const int nitem = ng_per << two;
         const float* gp = s_g + (size_t)(ci & 1) * kChunk * kSW + half * kSW + col;       // + (8 cg + 2 v) kSW
         const f32x4* bp = afk4 + ((size_t)(ci * (kChunk / 8)) * NT) * 64;                  // scalar; + (cg NT + t) 64
         auto src = [&](int i) {
@@ -255,18 +298,25 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
 #pragma unroll
           for (int v = 0; v < 4; ++v) a[v] = gp[(8 * cg + 2 * v) * kSW];
         };
-        RING_DRAIN();
-        ring_load(R0, src(0), voff);
-        ring_load(R1, src(1), voff);
-        ring_load(R2, src(2), voff);
-        ring_load(R3, src(3), voff);
-        ring_load(R4, src(4), voff);
-        ring_load(R5, src(5), voff);
+        int nx_kind, nx_k;
+        first_phase_of_tick(k + 1, nx_kind, nx_k);
+        auto nxt = [&](int j) { return nx_kind == 1 ? f_addr(nx_k, j) : nx_kind == 2 ? b_addr(nx_k, j) : src(nitem - 1); };
+        if (!primed) {
+          RING_DRAIN();
+          RING_KEEP();
+          ring_load(R0, src(0), voff);
+          ring_load(R1, src(1), voff);
+          ring_load(R2, src(2), voff);
+          ring_load(R3, src(3), voff);
+          ring_load(R4, src(4), voff);
+          ring_load(R5, src(5), voff);
+        }
+        primed = nx_kind != 0;
         float a_cur[4], a_nxt[4];
         lds_a(0, a_cur);
         // even items accumulate into gacc0, odd items into gacc1: with two tiles that is tile t0 / t1, with one tile two
         // independent chains of the same tile (kRing is even, so the parity of an item is the parity of its ring slot)
-#define B_STEP(RJ, J, GACC)                                                                      \
+#define B_STEP(RJ, J, GACC, NEXTSRC)                                                             \
   {                                                                                              \
     const int it = i0 + (J);                                                                     \
     lds_a(it + 1, a_nxt);                                                                        \
@@ -278,17 +328,25 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
       GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], RJ[3], GACC, 0, 0, 0);               \
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
-    ring_load(RJ, src(it + kRing), voff);                                                        \
+    ring_load(RJ, NEXTSRC, voff);                                                                \
     a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; a_cur[2] = a_nxt[2]; a_cur[3] = a_nxt[3];          \
   }
-        for (int i0 = 0; i0 < nitem; i0 += kRing) {
-          B_STEP(R0, 0, gacc0)
-          B_STEP(R1, 1, gacc1)
-          B_STEP(R2, 2, gacc0)
-          B_STEP(R3, 3, gacc1)
-          B_STEP(R4, 4, gacc0)
-          B_STEP(R5, 5, gacc1)
+        int i0 = 0;
+        for (; i0 + kRing < nitem; i0 += kRing) {
+          B_STEP(R0, 0, gacc0, src(it + kRing))
+          B_STEP(R1, 1, gacc1, src(it + kRing))
+          B_STEP(R2, 2, gacc0, src(it + kRing))
+          B_STEP(R3, 3, gacc1, src(it + kRing))
+          B_STEP(R4, 4, gacc0, src(it + kRing))
+          B_STEP(R5, 5, gacc1, src(it + kRing))
         }
+        // last group of steps: its requests belong to the next phase
+        B_STEP(R0, 0, gacc0, nxt(0))
+        B_STEP(R1, 1, gacc1, nxt(1))
+        B_STEP(R2, 2, gacc0, nxt(2))
+        B_STEP(R3, 3, gacc1, nxt(3))
+        B_STEP(R4, 4, gacc0, nxt(4))
+        B_STEP(R5, 5, gacc1, nxt(5))
 #undef B_STEP
       }
       WS_STAMP(sblk, k, 2);
@@ -298,7 +356,8 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
       if (sblk >= 0 && lane == 0 && (k == 0 || k == nticks - 1)) { g_ws_stamps[sblk][wave][k == 0 ? 14 : 15][0] = (long long)__builtin_amdgcn_s_memrealtime(); g_ws_stamps[sblk][wave][14][1] = nvec; g_ws_stamps[sblk][wave][14][2] = NT; g_ws_stamps[sblk][wave][14][3] = t0 * 100 + t1 * 10 + nkq; }
 #endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the ring's trailing (discarded) requests
+    RING_DRAIN();  // retire the last phase's trailing requests
+    RING_KEEP();
     if (!GRAD) return;
     if (t1 < 0) {
 #pragma unroll
