@@ -42,7 +42,58 @@ def parse():
     ap.add_argument("--extras", action="store_true", help="also time the tutorial-notebook and the redundant-groups configurations (they launch "
                     "the same kernels at other sizes, so a rocprofv3 --stats summary of such a run no longer averages the headline launches alone)")
     ap.add_argument("--cpu-sample-bls", type=int, default=192)
+    ap.add_argument("--dist-rehearsal", type=int, default=0, metavar="T",
+                    help="with ONE rank (plain or under torch.distributed.run --nproc-per-node 1): take the multi-rank code path anyway -- "
+                         "T batched time slices, group partition, gloo rendezvous, unique id broadcast, RCCL communicator of one rank, "
+                         "grouped all-reduce every step -- so that path is exercised on a one-GPU box")
     return ap.parse_args()
+
+
+def host_info():
+    """CPU model and core counts of the box the CPU baselines run on (north_star: 'core count stated')."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return dict(cpu_model=model, cpu_count=os.cpu_count(), usable_cores=usable)
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: ties a committed PMC summary to the code it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("fit_kernels.hpp", "mfma_kernels.hpp", "calamity_hip.hip"):
+        with open(os.path.join(ROOT, "calamity_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_sharded_job(config, rank, world, ntimes, reg=False, max_bls=None):
+    """This rank's share of a job of ``ntimes`` time slices: the same 1/world of every slice's baselines (balanced by
+    basis bytes), batched into ONE problem (slice t keeps its own gains: antenna index + t * nants), so one solver and
+    one all-reduce per step serve all slices.  Returns (problem, start, nants of one slice)."""
+    from calamity_amd import distributed as D
+    from calamity_amd import synthetic
+
+    cache = {}
+    sel = lambda nvec, gb: D.partition_groups(nvec, gb, np.ones(len(nvec)), world)[rank]  # noqa: E731
+    cfg_seed = list(synthetic.CONFIGS).index(config)
+    parts = []
+    for t in range(ntimes):
+        p_t, _, s_t = synthetic.make_config(config, seed=cfg_seed + 100 * t, data_seed=100000 * (t + 1) + rank, bl_sel=sel,
+                                            operator_cache=cache, with_sky=reg, max_bls=max_bls)
+        parts.append((p_t, s_t))
+    prob, start = D.batch_time_slices(parts)
+    return prob, start, parts[0][0].nants
 
 
 def cpu_baseline(prob, start, dtype, optimizer, sample_bls, reg):
@@ -91,26 +142,31 @@ def cpu_baseline(prob, start, dtype, optimizer, sample_bls, reg):
     )
 
 
-def cpu_baseline_strong(prob, start, dtype, optimizer, reg):
+def cpu_baseline_strong(prob, start, dtype, optimizer, reg, same_updates=0):
     """Strong CPU baseline: the C / OpenMP restatement (oracle/ref_c.c) -- un-padded, forward and
     adjoint fused per baseline, unique basis blocks shared, every host core -- on the FULL job for a bounded time."""
     from oracle.ref_c import CRef
 
-    cores = min(os.cpu_count() or 1, 16)
+    cores = host_info()["usable_cores"]  # every core this process may run on
     c = CRef(prob, dtype, nthreads=cores)
     if reg:
         c.set_regularization("sum", float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts)))
     state = [start["g_r"], start["g_i"], start["c_r"], start["c_i"]]
-    mom, t, n = None, 0, 0
-    g_r, g_i, c_r, c_i, _, mom = c.fit(*state, 1, optimizer=optimizer, learning_rate=1e-2)
+    mom, n = None, 0
+    g_r, g_i, c_r, c_i, ls, mom = c.fit(*state, 1, optimizer=optimizer, learning_rate=1e-2)
+    losses = [float(ls[0])]  # pre-update loss of update k (k = 0: the start parameters)
     t0 = time.perf_counter()
-    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 50):
-        g_r, g_i, c_r, c_i, _, mom = c.fit(g_r, g_i, c_r, c_i, 1, optimizer=optimizer, learning_rate=1e-2, moments=mom, t0=n + 1)
+    # at least as many updates as the GPU run applied (so the loss after the same number of updates can be put beside
+    # the GPU's), then up to ~10 s
+    while n < max(2, same_updates) or (time.perf_counter() - t0 < 10.0 and n < 50):
+        g_r, g_i, c_r, c_i, ls, mom = c.fit(g_r, g_i, c_r, c_i, 1, optimizer=optimizer, learning_rate=1e-2, moments=mom, t0=n + 1)
+        losses.append(float(ls[0]))
         n += 1
     dt = (time.perf_counter() - t0) / n
     return dict(value=1.0 / dt, unit="steps/s", cores=cores, kind="port",
+                loss_before_update=losses[: same_updates + 1],
                 sample=f"full job, {n} Adam steps of the C/OpenMP restatement (ragged, fused, shared unique basis blocks, "
-                       f"{np.dtype(dtype).name}); {dt * 1e3:.0f} ms per step")
+                       f"{np.dtype(dtype).name}) on {cores} threads; {dt * 1e3:.0f} ms per step")
 
 
 def torch_sum_int(dist, vals):
@@ -145,15 +201,20 @@ def main():
 
     dtype = {"f32": np.float32, "f64": np.float64, None: np.float64 if args.config == "hera37" else np.float32}[args.dtype]
     dist = None
-    if world > 1:
+    if args.dist_rehearsal and world != 1:
+        raise SystemExit("--dist-rehearsal is a one-rank run")
+    sharded = world > 1 or args.dist_rehearsal > 0  # the multi-rank code path (also taken by the one-rank rehearsal)
+    if sharded:
         import torch.distributed as dist  # rendezvous + barrier only (gloo, CPU); the data path is RCCL inside the library
 
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29611")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     t_setup = time.perf_counter()
-    ntimes = world
+    ntimes = world if world > 1 else max(args.dist_rehearsal, 1)
     solvers = []
-    if world == 1:
+    if not sharded:
         prob, truth, start = synthetic.make_config(args.config, max_bls=args.max_bls, with_sky=args.reg == "sum")
         full_nbls, full_ncoeffs, full_nants = prob.nbls, prob.ncoeffs, prob.nants
         s = HipFitSolver(dtype=dtype, device=0)
@@ -161,29 +222,18 @@ def main():
         s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
         solvers.append(s)
     else:
-        from calamity_amd import distributed as D
-
-        # N time slices; this rank owns the same 1/N of the baselines (balanced by basis bytes) of every slice and fits
-        # them in ONE solver (slice t keeps its own gains: antenna index + t * nants) -> one all-reduce per step
-        cache = {}
-        sel = lambda nvec, gb: D.partition_groups(nvec, gb, np.ones(len(nvec)), world)[rank]  # noqa: E731
-        cfg_seed = list(synthetic.CONFIGS).index(args.config)
-        parts = []
-        for t in range(ntimes):
-            p_t, _, s_t = synthetic.make_config(args.config, seed=cfg_seed + 100 * t, data_seed=100000 * (t + 1) + rank, bl_sel=sel,
-                                                operator_cache=cache, with_sky=args.reg == "sum", max_bls=args.max_bls)
-            parts.append((p_t, s_t))
-        full_nants = parts[0][0].nants
-        prob, start = D.batch_time_slices(parts)
+        # N time slices; this rank owns the same 1/N of the baselines of every slice -> one all-reduce per step
+        prob, start, full_nants = build_sharded_job(args.config, rank, world, ntimes, reg=args.reg == "sum", max_bls=args.max_bls)
+        truth = None
         tot = torch_sum_int(dist, [prob.nbls // ntimes, prob.ncoeffs // ntimes])
         full_nbls, full_ncoeffs = tot
         uid = [comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        # CALAMITY_BENCH_DEVICE: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
-        s = HipFitSolver(dtype=dtype, device=int(os.environ.get("CALAMITY_BENCH_DEVICE", local_rank)))
+        s = HipFitSolver(dtype=dtype, device=local_rank)
+        # communicator first: set_problem then agrees the kernel path and the steps per host synchronisation over the ranks
+        s.comm_init(uid[0], rank, world)
         s.set_problem(prob, layout=args.layout)
         s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
-        s.comm_init(uid[0], rank, world)
         solvers.append(s)
     for s in solvers:
         if args.reg == "sum":
@@ -201,15 +251,14 @@ def main():
             dist.barrier()
 
     def run_steps(n, record):
-        for s in solvers:
-            s.run(n, record=record, tol=0.0)
+        return [s.run(n, record=record, tol=0.0)[0] for s in solvers][0]
 
     run_steps(args.warmup, False) if args.warmup > 0 else None
     for s in solvers:
         s.timing_enable(True)
     sync()
     t0 = time.perf_counter()
-    run_steps(args.steps, True)
+    timed_losses = run_steps(args.steps, True)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -234,7 +283,7 @@ def main():
     # the SHARED layout of the same workload (baselines of one delay alias ONE basis block; fp32 MFMA GEMM path): measured
     # in the same run and reported beside the headline, against its own bounds
     shared = None
-    if world == 1 and args.layout == "stream" and not args.no_shared and dtype == np.float32 and args.reg == "none":
+    if not sharded and args.layout == "stream" and not args.no_shared and dtype == np.float32 and args.reg == "none":
         s2 = HipFitSolver(dtype=dtype, device=0)
         s2.set_problem(prob, layout="shared")
         s2.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
@@ -268,7 +317,7 @@ def main():
     # reference publishes a rate for (tutorial notebook: 15 antennas, 105 baselines x 200 channels, Adamax, 61.77 steps/s
     # on a P100) -- single-GPU runs only, after the solvers above have released their memory
     peaks, tutorial, redundant = None, None, None
-    if rank == 0 and world == 1 and not args.no_shared:
+    if rank == 0 and not sharded and not args.no_shared:
         for s_ in solvers:
             s_.synchronize()
         try:
@@ -277,7 +326,7 @@ def main():
             peaks["busy_shader_clock_MHz"] = _lib.busy_clock_mhz(0)
         except Exception as e:  # noqa: BLE001 -- a probe must not take the benchmark down
             peaks = {"error": str(e)}
-    if rank == 0 and world == 1 and args.extras:
+    if rank == 0 and not sharded and args.extras:
         tp, _, tstart = synthetic.make_problem(15, 200, f0=100e6, df=100e3, seed=0)
         ts = HipFitSolver(dtype=np.float32)
         ts.set_problem(tp, layout="shared")
@@ -314,12 +363,17 @@ def main():
         achieved = tim["algorithmic_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.config}_{'f32' if dtype == np.float32 else 'f64'}_{args.layout}.json")
-        if world == 1 and args.max_bls is None and args.reg == "none" and os.path.exists(pmc_path):
+        if not sharded and args.max_bls is None and args.reg == "none" and os.path.exists(pmc_path):
             # HBM bytes per launch of the same kernel on the same workload, from separate rocprofv3 --pmc FETCH_SIZE /
-            # WRITE_SIZE passes (tools/pmc_summary.py; gfx950 corrections of MI355X_MICROARCH.md applied there)
-            for k, v in json.load(open(pmc_path))["kernels"].items():
-                if "fused_basis_kernel" in k and ", 1, false>" in k:
-                    traffic, traffic_src = v["hbm_bytes"], os.path.relpath(pmc_path, ROOT)
+            # WRITE_SIZE passes (tools/pmc_summary.py; gfx950 corrections of MI355X_MICROARCH.md applied there).  The
+            # summary records the hash of the kernel sources it was measured on: a stale one is not reported.
+            pmc = json.load(open(pmc_path))
+            if pmc.get("kernel_source_hash") == kernel_source_hash():
+                for k, v in pmc["kernels"].items():
+                    if "fused_basis_kernel" in k and ", 1, false>" in k:
+                        traffic, traffic_src = v["hbm_bytes"], os.path.relpath(pmc_path, ROOT)
+            else:
+                traffic_src = f"{os.path.relpath(pmc_path, ROOT)} is stale (measured on other kernel sources): not reported"
         out = {
             "metric": "Adam steps/sec (chi2 eval/sec in extra), " + {"hera350": "HERA-350", "hera37": "HERA-37", "tutorial": "tutorial-scale"}.get(args.config, args.config)
                       + f" {prob.nfreqs}ch DPSS; %HBM roofline",
@@ -339,7 +393,8 @@ def main():
                             f"(sum nvec = {full_ncoeffs}) per time slice, {ntimes} time slice(s), optimizer {args.optimizer} lr 1e-2, "
                             f"model_regularization {args.reg}",
                 "layout": args.layout,
-                "parallelism": f"every slice's baselines sharded over {world} GPUs (one process each), one RCCL all-reduce of the gain gradients + loss scalars per step" if world > 1 else "single GPU",
+                "parallelism": (f"every slice's baselines sharded over {world} GPUs (one process each), one RCCL all-reduce of the gain gradients + loss scalars per step"
+                                + (" [one-rank rehearsal of the multi-rank path]" if world == 1 else "")) if sharded else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -357,6 +412,11 @@ def main():
             },
             "extra": {
                 "chi2_evals_per_s": chi2_rate,
+                # recorded (pre-update) losses of the timed steps: the steps did optimise; summed over the job's slices
+                "loss_first": float(timed_losses[0]) if len(timed_losses) else None,
+                "loss_last": float(timed_losses[-1]) if len(timed_losses) else None,
+                "losses": [float(v) for v in timed_losses] if len(timed_losses) <= 64 else None,
+                "updates_before_loss_last": args.warmup + len(timed_losses) - 1,
                 "setup_s": t_setup,
                 "device_memory_GB": solvers[0].memory_bytes() / 1e9 * len(solvers),
                 "shared_layout": shared,
@@ -364,9 +424,15 @@ def main():
                 "redundant_groups_config": redundant,
             },
         }
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
+        if not args.no_cpu_baseline and not sharded:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(prob, start, dtype, args.optimizer, args.cpu_sample_bls, args.reg)
-            out["cpu_baseline"]["strong"] = cpu_baseline_strong(prob, start, dtype, args.optimizer, args.reg == "sum")
+            nupd = args.warmup + args.steps - 1
+            strong = cpu_baseline_strong(prob, start, dtype, args.optimizer, args.reg == "sum", same_updates=nupd if nupd <= 64 else 0)
+            # the C restatement's loss after the same number of updates as the GPU's last recorded loss (outside the timed region)
+            lb = strong.pop("loss_before_update")
+            strong["loss_after_same_updates"] = lb[nupd] if len(lb) > nupd else None
+            out["cpu_baseline"]["strong"] = strong
+            out["cpu_baseline"]["host"] = host_info()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -13,6 +13,7 @@ CAL_F32, CAL_F64 = 0, 1
 CAL_OPT_ADAM, CAL_OPT_ADAMAX = 0, 1
 CAL_REG_NONE, CAL_REG_SUM = 0, 1
 CAL_LAYOUT_STREAM, CAL_LAYOUT_SHARED = 0, 1
+CAL_PATH_AUTO, CAL_PATH_GENERAL, CAL_PATH_DENSE = 0, 1, 2
 CAL_COMM_ID_BYTES = 128
 CAL_ERR_NONFINITE = -6
 
@@ -34,6 +35,7 @@ class ProblemDesc(C.Structure):
         ("bl_ant1", C.c_void_p),
         ("bl_rowblk", C.c_void_p),
         ("layout", C.c_int32),
+        ("kernel_path", C.c_int32),
     ]
 
 

@@ -142,7 +142,9 @@ struct SolverT final : cal_solver {
   DevBuf mf_akf4, mf_afk4, mf_panels, mf_bl_coff;
   int mf_npanels = 0;
   size_t mf_ws_lds = 0;
-  bool mf_ok = false, mf_ws = true;
+  bool mf_ok = false;
+  int steps_per_sync = 1;                      // train steps enqueued between two host synchronisations of run()
+  DevBuf agree_buf;
   DevState* h_state = nullptr;                 // pinned mirror
   // settings
   cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7};
@@ -232,19 +234,34 @@ struct SolverT final : cal_solver {
                     d->basis_nvec[u], (int)(kTileBytes / sizeof(T) / FbSet<T>::fb_min));
       fb_used_max = std::max(fb_used_max, fb_u[u]);
     }
-    // the dense path tiles channels in chunks of kChunk
-    bool want_mfma = std::is_same<T, float>::value && layout == CAL_LAYOUT_SHARED && !getenv("CALAMITY_HIP_NO_MFMA");
+    // Row padding is a function of nfreqs alone (never of this rank's basis blocks or kernel choice): every rank of a
+    // sharded fit must lay the gains out identically and all-reduce the same number of reals.  pw = min(128,
+    // next_pow2(nfreqs)) is a multiple of every tile width in use and, for nfreqs > 64, of the dense kernel's chunk.
+    int pw = 8;
+    while (pw < 128 && pw < nfreqs) pw *= 2;
+    if (fb_used_max > pw) return fail(CAL_ERR_INVALID, "set_problem: internal error: tile width %d exceeds the row padding %d", fb_used_max, pw);
+    fpad = (nfreqs + pw - 1) / pw * pw;
+    if (d->kernel_path != CAL_PATH_AUTO && d->kernel_path != CAL_PATH_GENERAL && d->kernel_path != CAL_PATH_DENSE)
+      return fail(CAL_ERR_INVALID, "set_problem: bad kernel_path %d", d->kernel_path);
+    // dense (matrix-core) path: eligibility, then -- for CAL_PATH_AUTO -- whether the problem fills the chip
+    bool dense_ok = layout == CAL_LAYOUT_SHARED && fpad % kChunk == 0;
+    for (int g = 0; g < ngrps && dense_ok; ++g) dense_ok = (d->grp_bl_start[g + 1] - d->grp_bl_start[g]) == 1;
+    for (int u = 0; u < nbasis && dense_ok; ++u) dense_ok = d->basis_nrowblk[u] == 1 && d->basis_nvec[u] <= DenseCfg<T>::max_nvec;
+    // the dense kernels address the per-sample arrays with 32-bit BYTE offsets; the widest sample is one (re, im) pair
+    if ((long long)(nbls + 2) * fpad * 2 * (long long)sizeof(T) >= (1LL << 32)) dense_ok = false;
+    if (d->kernel_path == CAL_PATH_DENSE && !dense_ok)
+      return fail(CAL_ERR_UNSUPPORTED, "set_problem: CAL_PATH_DENSE needs the SHARED layout, one baseline per fitting group, "
+                  "basis_nvec <= %d and nfreqs > 64", DenseCfg<T>::max_nvec);
     // a panel of 16 baselines occupies one CU for 60-70 us whatever the problem size; below ~2000 baselines the panels do
     // not fill the chip and the general kernel (one workgroup per baseline) is 2-3x faster (HERA-37 fp32: 25 vs 71 us)
-    if (nbls < 2048 && !getenv("CALAMITY_HIP_FORCE_MFMA")) want_mfma = false;
-    for (int g = 0; g < ngrps && want_mfma; ++g) want_mfma = (d->grp_bl_start[g + 1] - d->grp_bl_start[g]) == 1;
-    for (int u = 0; u < nbasis && want_mfma; ++u) want_mfma = d->basis_nrowblk[u] == 1 && d->basis_nvec[u] <= 32 * kMaxNT;
-    if ((long long)(nbls + 1) * (nfreqs + kChunk) >= (1LL << 29)) want_mfma = false;  // the dense kernel uses 32-bit BYTE offsets of 8-byte samples
-    if (want_mfma) fb_used_max = std::max(fb_used_max, kChunk);
-    fpad = (nfreqs + fb_used_max - 1) / fb_used_max * fb_used_max;
+    bool want_mfma = dense_ok && d->kernel_path != CAL_PATH_GENERAL && (d->kernel_path == CAL_PATH_DENSE || nbls >= 2048);
+    if (nccl) {  // one path for all ranks: the exchange payload of the "sum" regulariser differs between the two
+      int v = want_mfma ? 1 : 0;
+      CAL_TRY(agree_min(v));
+      want_mfma = v != 0;
+    }
     lds_bytes = 0;
     for (int u = 0; u < nbasis; ++u) lds_bytes = std::max(lds_bytes, lds_for(fb_u[u]));
-    if (const char* x = getenv("CALAMITY_HIP_X_LDS")) lds_bytes += (size_t)atoi(x);  // occupancy experiments only
     for (int b = 0; b < d->nbls; ++b) {
       if (d->bl_ant0[b] < 0 || d->bl_ant0[b] >= nants || d->bl_ant1[b] < 0 || d->bl_ant1[b] >= nants)
         return fail(CAL_ERR_INVALID, "set_problem: baseline %d has an antenna index outside [0, %d)", b, nants);
@@ -346,14 +363,14 @@ struct SolverT final : cal_solver {
         std::vector<int> uorder(nbasis);
         std::iota(uorder.begin(), uorder.end(), 0);
         std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
-        // Optional XCD-aware order (CALAMITY_HIP_XCD_LISTS=1): workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
+        // XCD-aware order (not the default, see no_xcd): workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
         // 4 MB L2), so all panels of one basis block go to ONE XCD (its operand copies, ~1 MB, then stay L2-resident
         // there); blocks are spread over XCDs by greedy longest-processing-time balancing of the MFMA work.  The kernel
         // maps block b to panel (b % 8) * per_xcd + b / 8; short lists are padded with empty panels (nvec = 0).
         constexpr int kXcd = 8;
         std::vector<std::vector<PanelItem>> xlist(kXcd);
         std::vector<double> xwork(kXcd, 0.0);
-        const bool no_xcd = getenv("CALAMITY_HIP_XCD_LISTS") == nullptr;  // default: plain heaviest-first order over all XCDs (per-XCD lists measured 3 % slower: imbalance)
+        const bool no_xcd = true;  // plain heaviest-first order over all XCDs (per-XCD lists measured 3 % slower: imbalance)
         size_t rr = 0;
         for (int u : uorder) {
           if (by_u[u].empty()) continue;
@@ -391,7 +408,6 @@ struct SolverT final : cal_solver {
         HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         mf_ws_lds = mfma_ws_lds_bytes(nvec_max);
-        mf_ws = !getenv("CALAMITY_HIP_MFMA_NO_WS");
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_mfma_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_ws_lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_mfma_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_ws_lds));
         mf_ok = true;
@@ -586,6 +602,21 @@ struct SolverT final : cal_solver {
     scratch.release();
     has_problem = true;
     reg = CAL_REG_NONE;
+    // ~ tens of milliseconds of GPU time between two host synchronisations of run(); the same on every rank, or ranks
+    // would notice a tolerance stop after different step counts and issue different numbers of all-reduces
+    steps_per_sync = (int)std::max(1.0, std::min(256.0, 2.0e11 / ((double)basis_bytes + 1.0)));
+    if (nccl) CAL_TRY(agree_min(steps_per_sync));
+    return CAL_OK;
+  }
+
+  // min over the ranks of the communicator (set-up decisions that every rank must take identically)
+  int agree_min(int& v) {
+    if (!nccl) return CAL_OK;
+    if (!agree_buf.p) CAL_TRY(agree_buf.alloc(sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(agree_buf.p, &v, sizeof(int), hipMemcpyHostToDevice, stream));
+    NCCL_TRY(ncclAllReduce(agree_buf.p, agree_buf.p, 1, ncclInt32, ncclMin, nccl, stream));
+    HIP_TRY(hipMemcpyAsync(&v, agree_buf.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return CAL_OK;
   }
 
@@ -769,7 +800,7 @@ struct SolverT final : cal_solver {
     a.nbls = nbls;
     a.runs = runs.as<int2>();
     a.item_base = 0;
-    a.stream_once = (layout == CAL_LAYOUT_STREAM && !getenv("CALAMITY_HIP_NO_NT")) ? 1 : 0;
+    a.stream_once = layout == CAL_LAYOUT_STREAM ? 1 : 0;
     return a;
   }
   // LDS buffer of gbar_G rows (MODE_GRAD); the narrowest tiles have the longest offset table
@@ -815,7 +846,7 @@ struct SolverT final : cal_solver {
     }
     // dense path; with the "sum" regulariser it runs twice: a loss-only pass yields S (hence alpha = 2 (S - P)), then the
     // gradient pass applies e = -2 w r + alpha w directly -- no second adjoint set, no combine kernels
-    const bool use_mfma = mf_ok && mf_ws;
+    const bool use_mfma = mf_ok;
     const bool two_pass = use_mfma && R && grads;
     if (use_mfma) {
       if constexpr (std::is_same<T, float>::value) {
@@ -930,6 +961,7 @@ struct SolverT final : cal_solver {
     h_state->beta2 = opt.beta_2;
     h_state->eps = opt.epsilon;
     h_state->reg = reg == CAL_REG_SUM;
+    h_state->f32 = std::is_same<T, float>::value ? 1 : 0;
     h_state->prior_r = prior_r;
     h_state->prior_i = prior_i;
     HIP_TRY(hipMemcpyAsync(state.p, h_state, sizeof(DevState), hipMemcpyHostToDevice, stream));
@@ -998,8 +1030,7 @@ struct SolverT final : cal_solver {
     CAL_TRY(push_state());
     // steps are enqueued in chunks; the device decides when the loop ends (finalize_kernel) and later steps of a
     // chunk fall through at once, so the host only synchronises once per chunk instead of once per step (:701)
-    const double work = (double)basis_bytes + 1.0;
-    int chunk = (int)std::max(1.0, std::min(256.0, 2.0e11 / work));  // ~ tens of milliseconds of GPU time per chunk
+    const int chunk = steps_per_sync;
     int issued = 0;
     while (issued < r->nsteps) {
       const int n = std::min(chunk, r->nsteps - issued);
@@ -1116,6 +1147,14 @@ struct SolverT final : cal_solver {
     NCCL_TRY(ncclCommInitRank(&nccl, nr, uid, rk));
     nranks = nr;
     rank = rk;
+    if (has_problem) {
+      // a problem set before the communicator existed: agree now (fpad is rank-independent by construction; a rank
+      // that chose the dense path falls back to the general kernel, which runs on the same buffers)
+      int v = mf_ok ? 1 : 0;
+      CAL_TRY(agree_min(v));
+      if (!v) mf_ok = false;
+      CAL_TRY(agree_min(steps_per_sync));
+    }
     return CAL_OK;
   }
 };

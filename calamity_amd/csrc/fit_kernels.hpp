@@ -57,6 +57,7 @@ struct DevState {
   int reg;
   int nonfinite;
   int nupdates;
+  int f32;            // the fit runs in float32: loop decisions compare float32 losses, as loss.numpy() of a float32 fit does (:701, :712)
 };
 
 struct Item {        // one workgroup's share of a fitting group
@@ -226,20 +227,12 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
   auto flush_q = [&]() {
     constexpr int kSlotBytes = FB * (int)sizeof(T2);
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-#ifdef CAL_X_NOQ
-    q_count = 0;  // experiment: no gbar_G stores (results are wrong)
-#endif
     for (int b = tid * 16; b < q_count * kSlotBytes; b += kThreads * 16) {
       const int slot = b / kSlotBytes;
       const int within = b - slot * kSlotBytes;
       const long long o = s_qo[slot];
-#ifdef CAL_X_QNT
-      __builtin_nontemporal_store(*reinterpret_cast<const u4*>(reinterpret_cast<const char*>(s_q) + b),
-                                  reinterpret_cast<u4*>(reinterpret_cast<char*>(A.q0 + o) + within));
-#else
       *reinterpret_cast<u4*>(reinterpret_cast<char*>(A.q0 + o) + within) =
           *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(s_q) + b);
-#endif
       if (REG)
         *reinterpret_cast<u4*>(reinterpret_cast<char*>(A.q1 + o) + within) =
             *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(s_q + C::QT * FB) + b);
@@ -1006,12 +999,16 @@ __global__ void finalize_kernel(DevState* st, const double* __restrict__ scal, d
   if (st->record) {
     if (st->n_recorded < losses_cap) losses[st->n_recorded] = loss;
     st->n_recorded += 1;
-    if (st->use_min && loss < st->min_loss) {
-      st->min_loss = loss;
+    // The reference compares the values loss.numpy() returns (:702, :712): float32 numbers in a float32 fit, so such a
+    // fit stops once its loss stagnates in float32 (difference exactly 0 < tol).  The loss itself is accumulated and
+    // recorded in double here; only the two comparisons see it rounded.
+    const double lc = st->f32 ? (double)(float)loss : loss;
+    if (st->use_min && lc < st->min_loss) {
+      st->min_loss = lc;
       st->improved = 1;
     }
-    if (st->n_recorded_total >= 1 && fabs(loss - st->prev_loss) < st->tol) st->done_after = 1;
-    st->prev_loss = loss;
+    if (st->n_recorded_total >= 1 && fabs(lc - st->prev_loss) < st->tol) st->done_after = 1;
+    st->prev_loss = lc;
     st->n_recorded_total += 1;
   }
 }

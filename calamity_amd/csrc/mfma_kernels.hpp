@@ -23,6 +23,10 @@ constexpr int kMaxNT = 8;         // vector tiles of 32 the adjoint supports (nv
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// which solver dtypes have a dense kernel, and the widest basis block it takes
+template <typename T> struct DenseCfg { static constexpr int max_nvec = 0; };
+template <> struct DenseCfg<float> { static constexpr int max_nvec = 32 * kMaxNT; };
+
 struct PanelItem {
   int bl[kPanel];     // baseline ids (-1: padding slot)
   int nvec, nvp2, nvp32;

@@ -79,27 +79,27 @@ def yield_dpss_model_comps_bl_grp(
 
 
 def get_redundant_grps_data(uvdata, remove_redundancy=False, tol=1.0, include_autos=False):
-    """Antenna pairs organised in redundant groups -- modeling.py:10-81 (same return tuple)."""
-    antpairs = []
-    red_grps, vec_bin_centers, lengths, _ = uvdata.get_redundancies(
-        use_antpos=True, include_conjugates=True, include_autos=include_autos, tol=tol
-    )
-    red_grps = [[uvdata.baseline_to_antnums(bl) for bl in red_grp] for red_grp in red_grps]
-    ap_data = set(uvdata.get_antpairs())
-    red_grps = [[ap for ap in red_grp if ap in ap_data or ap[::-1] in ap_data] for red_grp in red_grps]
-    lengths = [length for length, red_grp in zip(lengths, red_grps) if len(red_grp) > 0]
-    vec_bin_centers = [vbc for vbc, red_grp in zip(vec_bin_centers, red_grps) if len(red_grp) > 0]
-    red_grps = [red_grp for red_grp in red_grps if len(red_grp) > 0]
-    antpairs = set(antpairs)
-    if remove_redundancy:
-        red_grps_t, vec_bin_centers_t, lengths_t = [], [], []
-        for red_grp, vbc, length in zip(red_grps, vec_bin_centers, lengths):
-            for ap in red_grp:
-                red_grps_t.append([ap])
-                vec_bin_centers_t.append(vbc)
-                lengths_t.append(length)
-        red_grps, lengths, vec_bin_centers = red_grps_t, lengths_t, vec_bin_centers_t
-    return antpairs, red_grps, vec_bin_centers, lengths
+    """Redundant groups of the antenna pairs that carry data -- same arguments and return tuple as modeling.py:10-81:
+    ``(antpairs, red_grps, vec_bin_centers, lengths)`` with one bin centre / length per returned group.
+
+    pyuvdata's ``get_redundancies(include_conjugates=True)`` lists every pair of the ARRAY in the orientation of its
+    redundancy convention; a pair counts as present when the data hold it in either orientation.  With
+    ``remove_redundancy`` every kept pair becomes a group of its own that inherits the bin centre and length of the
+    redundant set it came from (that is what the per-baseline DPSS delay is computed from, :293, :364).  The first
+    element is always the empty set, as in the reference (its ``antpairs`` list is never filled, :47, :68)."""
+    groups, centres, lengths, _ = uvdata.get_redundancies(use_antpos=True, include_conjugates=True, include_autos=include_autos, tol=tol)
+    present = set()
+    for i, j in uvdata.get_antpairs():
+        present.add((i, j))
+        present.add((j, i))
+    out_grps, out_centres, out_lengths = [], [], []
+    for bls, centre, length in zip(groups, centres, lengths):
+        kept = [ap for ap in (tuple(uvdata.baseline_to_antnums(bl)) for bl in bls) if ap in present]
+        for members in ([[ap] for ap in kept] if remove_redundancy else [kept] if kept else []):
+            out_grps.append(members)
+            out_centres.append(centre)
+            out_lengths.append(length)
+    return set(), out_grps, out_centres, out_lengths
 
 
 def yield_pbl_dpss_model_comps(

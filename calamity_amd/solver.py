@@ -51,7 +51,8 @@ class HipFitSolver:
         return a
 
     # ---- problem -------------------------------------------------------------------------------------------
-    def set_problem(self, prob: FitProblem, layout="stream"):
+    def set_problem(self, prob: FitProblem, layout="stream", kernel_path="auto"):
+        """``kernel_path``: "auto" (dense matrix-core kernel when eligible and large enough), "general" or "dense"."""
         prob.validate()
         basis = [np.ascontiguousarray(b, dtype=self.dtype) for b in prob.basis]
         sizes = np.asarray([b.size for b in basis], dtype=np.int64)
@@ -73,6 +74,7 @@ class HipFitSolver:
             grp_basis=_ptr(keep[4]), grp_bl_start=_ptr(keep[5]), bl_ant0=_ptr(keep[6]), bl_ant1=_ptr(keep[7]),
             bl_rowblk=_ptr(keep[8]),
             layout={"stream": _lib.CAL_LAYOUT_STREAM, "shared": _lib.CAL_LAYOUT_SHARED}[layout],
+            kernel_path={"auto": _lib.CAL_PATH_AUTO, "general": _lib.CAL_PATH_GENERAL, "dense": _lib.CAL_PATH_DENSE}[kernel_path],
         )
         _lib.check(self._lib.cal_solver_set_problem(self._h, C.byref(d)))
         self.problem = prob

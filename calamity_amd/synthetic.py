@@ -98,7 +98,8 @@ def make_problem(
     for u in range(len(basis)):
         bls = np.where(grp_basis == u)[0]
         idx = coff[bls][None, :] + np.arange(basis[u].shape[1])[:, None]  # (nvec, nb)
-        vis[bls] = (basis[u] @ c_true[idx]).T
+        cu = c_true[idx]
+        vis[bls] = (basis[u] @ np.ascontiguousarray(cu.real)).T + 1j * (basis[u] @ np.ascontiguousarray(cu.imag)).T  # two real GEMMs (the basis is real)
     sig_rms = np.sqrt(np.mean(np.abs(vis) ** 2))
     data = g_true[i_idx] * np.conj(g_true[j_idx]) * vis
     data += noise_frac * sig_rms * (rng.standard_normal(data.shape) + 1j * rng.standard_normal(data.shape)) / np.sqrt(2.0)
@@ -106,7 +107,7 @@ def make_problem(
     wgts = (~flags).astype(np.float64)
     # global normalisation; with a shard the other ranks' baselines are flagged at the same rate in expectation
     wgts /= wgts.sum() * (nbls_slice / nbls)
-    rms = np.sqrt(np.mean(np.abs(data[~flags]) ** 2))
+    rms = np.sqrt(np.sum((data.real**2 + data.imag**2) * wgts) / wgts.sum())  # rms of the unflagged samples (wgts is uniform over them)
     data = data / rms
     prob = FitProblem(
         nants=nants,
@@ -126,11 +127,12 @@ def make_problem(
         prob.sky_r, prob.sky_i = prob.data_r.copy(), prob.data_i.copy()
     # start: unity gains, c0 = A^T (d * mask)
     c0 = np.empty(coff[-1], dtype=np.complex128)
-    dm = data * (~flags)
+    dm = data * (~flags).astype(np.float64)
     for u in range(len(basis)):
         bls = np.where(grp_basis == u)[0]
         idx = coff[bls][None, :] + np.arange(basis[u].shape[1])[:, None]
-        c0[idx] = basis[u].T @ dm[bls].T  # (nvec, nb)
+        du = dm[bls].T
+        c0[idx] = basis[u].T @ np.ascontiguousarray(du.real) + 1j * (basis[u].T @ np.ascontiguousarray(du.imag))  # (nvec, nb)
     truth = dict(c=c_true / rms, g=g_true, rms=rms, freqs=freqs, antpos=antpos, flags=flags)
     start = dict(
         g_r=np.ones((nants, nfreqs)),

@@ -47,6 +47,12 @@ enum cal_layout {
   CAL_LAYOUT_SHARED = 1  /* baselines alias the unique basis blocks (one per distinct delay, the operator_cache
                             of modeling.py:291-301): cache-resident basis */
 };
+enum cal_kernel_path {
+  CAL_PATH_AUTO = 0,    /* dense kernel when the problem is eligible and large enough to fill the chip, else general */
+  CAL_PATH_GENERAL = 1, /* register-direct streaming / group kernels (any dtype, layout, group shape) */
+  CAL_PATH_DENSE = 2    /* matrix-core kernel wherever the problem is eligible (SHARED layout, one baseline per fitting
+                           group, basis_nvec <= 256, nfreqs > 64); CAL_ERR_UNSUPPORTED when it is not */
+};
 
 /* Ragged description of one fit (replaces the zero-padded chunk tensors built by
  * tensorize_fg_model_comps_dict / tensorize_data, calibration.py:104-310).
@@ -56,7 +62,9 @@ enum cal_layout {
  * ("Nfreqs x Ncomponents", modeling.py:288-289); baseline bl uses rows
  * [bl_rowblk[bl] * nfreqs, (bl_rowblk[bl] + 1) * nfreqs).  Consecutive baselines of a group with the same row block
  * (a redundant set, use_redundancy=True) share one forward / adjoint product on the device.
- * Limits: basis_nvec <= 896 (CAL_ERR_UNSUPPORTED beyond); all index arrays are validated (CAL_ERR_INVALID). */
+ * Limits: basis_nvec <= 896 (CAL_ERR_UNSUPPORTED beyond); all index arrays are validated (CAL_ERR_INVALID).
+ * Device rows are padded to a multiple of min(128, next_pow2(nfreqs)) channels: a function of nfreqs alone, so every
+ * rank of a sharded fit uses the same gain layout and all-reduce count. */
 typedef struct cal_problem_desc {
   int32_t nants;
   int32_t nfreqs;
@@ -73,6 +81,7 @@ typedef struct cal_problem_desc {
   const int32_t* bl_ant1;        /* [nbls] */
   const int32_t* bl_rowblk;      /* [nbls] */
   int32_t layout;                /* cal_layout */
+  int32_t kernel_path;           /* cal_kernel_path; with a communicator attached the ranks agree on one path */
 } cal_problem_desc;
 
 typedef struct cal_optimizer_desc { /* **opt_kwargs -> tf.optimizers.X(...), calibration.py:571 */

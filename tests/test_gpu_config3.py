@@ -1,0 +1,72 @@
+"""BASELINE.json config 3 on the HIP path: HERA-350 x 1024 channels x 8 time slices, batched into ONE solver by
+``distributed.batch_time_slices`` (slice t keeps its own gains: antenna index + t * nants).  The reference fits the times
+one after another (calibration.py:1167), so the batched fit must equal 8 independent fits: loss, every gradient and a short
+Adam trajectory are compared per slice with the C restatement (oracle/ref_c.c, fp64).
+
+SHARED layout at full size: all 8 x 61 075 baselines alias the 120 unique basis blocks, i.e. every block is read once for
+all the right-hand sides of all times ("Multiple times") and the dense matrix-core kernel runs.
+STREAM layout (every (slice, baseline) owns its tiles: 8 x 24.9 GB at full size) on a bounded sample of the baselines."""
+import numpy as np
+import pytest
+
+from calamity_amd import distributed as D
+from calamity_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+NT = 8
+
+
+def relnorm(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def make_slices(max_bls):
+    cache, parts = {}, []
+    for t in range(NT):
+        p, _, s = synthetic.make_config("hera350", seed=2 + 100 * t, operator_cache=cache, max_bls=max_bls)
+        for k in ("data_r", "data_i", "wgts"):  # the fit runs in fp32: halve the host memory of 8 full-size slices
+            setattr(p, k, getattr(p, k).astype(np.float32))
+        rng = np.random.default_rng(1000 + t)
+        s["g_r"] = 1.0 + 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+        s["g_i"] = 0.05 * rng.standard_normal((p.nants, p.nfreqs))
+        parts.append((p, s))
+    return parts
+
+
+@pytest.mark.parametrize("layout,max_bls", [("shared", None), ("stream", 6000)])
+def test_eight_batched_time_slices_equal_independent_fits(layout, max_bls):
+    from calamity_amd.solver import HipFitSolver
+    from oracle.ref_c import CRef
+
+    parts = make_slices(max_bls)
+    prob, start = D.batch_time_slices(parts)
+    na, nb, nc = parts[0][0].nants, parts[0][0].nbls, parts[0][0].ncoeffs
+    assert prob.nants == NT * na and prob.nbls == NT * nb and len(prob.basis) == len(parts[0][0].basis)
+    s = HipFitSolver(dtype=np.float32)
+    s.set_problem(prob, layout=layout)
+    s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    loss, g_r, g_i, c_r, c_i = s.eval_grads()
+    s.set_optimizer("Adam", learning_rate=1e-2)
+    nsteps = 5
+    losses, _, nupd = s.run(nsteps, record=True, tol=0.0)
+    assert nupd == nsteps
+    fg_r, fg_i, fc_r, fc_i = s.get_params()
+    s.close()
+
+    ref_loss, ref_losses = 0.0, np.zeros(nsteps)
+    for t, (p, st) in enumerate(parts):
+        c = CRef(p, np.float64, nthreads=16)
+        ga, ca = slice(t * na, (t + 1) * na), slice(t * nc, (t + 1) * nc)
+        l, og_r, og_i, oc_r, oc_i = c.loss_grads(st["g_r"], st["g_i"], st["c_r"], st["c_i"])
+        ref_loss += l
+        assert relnorm(g_r[ga], og_r) <= 1e-4 and relnorm(g_i[ga], og_i) <= 1e-4, (layout, t)
+        assert relnorm(c_r[ca], oc_r) <= 1e-4 and relnorm(c_i[ca], oc_i) <= 1e-4, (layout, t)
+        tg_r, tg_i, tc_r, tc_i, tl, _ = c.fit(st["g_r"], st["g_i"], st["c_r"], st["c_i"], nsteps, optimizer="Adam", learning_rate=1e-2)
+        ref_losses += tl
+        assert relnorm(fg_r[ga], tg_r) <= 1e-3 and relnorm(fg_i[ga], tg_i) <= 1e-3, (layout, t)
+        assert relnorm(fc_r[ca], tc_r) <= 1e-3 and relnorm(fc_i[ca], tc_i) <= 1e-3, (layout, t)
+        del c
+    # the recorded loss of the batched fit is the sum of the slices' losses
+    assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert np.allclose(losses, ref_losses, rtol=1e-4)

@@ -40,11 +40,11 @@ def oracle_inputs(p, start):
     return ch, fg_r, fg_i
 
 
-def make_solver(p, start, dtype, layout="stream", reg=False):
+def make_solver(p, start, dtype, layout="stream", reg=False, kernel_path="auto"):
     from calamity_amd.solver import HipFitSolver
 
     s = HipFitSolver(dtype=dtype)
-    s.set_problem(p, layout=layout)
+    s.set_problem(p, layout=layout, kernel_path=kernel_path)
     s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
     if reg:
         s.set_regularization("sum", np.sum(p.sky_r * p.wgts), np.sum(p.sky_i * p.wgts))
@@ -101,10 +101,9 @@ def test_short_trajectory(dtype, optimizer, reg):
 
 
 @pytest.mark.parametrize("reg", [False, True])
-def test_short_trajectory_dense_path(reg, monkeypatch):
+def test_short_trajectory_dense_path(reg):
     """fp32 + SHARED layout + one baseline per group -> the MFMA path (two passes per step with the "sum" regulariser).
-    Problems this small normally take the general kernel; the environment switch forces the dense one."""
-    monkeypatch.setenv("CALAMITY_HIP_FORCE_MFMA", "1")
+    Problems this small normally take the general kernel; kernel_path="dense" asks for the dense one."""
     p, start = make_case(seed=6, nants=12, nfreqs=200, with_sky=reg, perturb=False)
     ch, fg_r, fg_i = oracle_inputs(p, start)
     out = R.fit_gains_and_foregrounds(
@@ -112,7 +111,7 @@ def test_short_trajectory_dense_path(reg, monkeypatch):
         maxsteps=30, optimizer="Adam", learning_rate=1e-2, sky_model_r=ch["sky_model_r"], sky_model_i=ch["sky_model_i"],
         model_regularization="sum" if reg else None,
     )
-    s = make_solver(p, start, np.float32, "shared", reg)
+    s = make_solver(p, start, np.float32, "shared", reg, kernel_path="dense")
     s.set_optimizer("Adam", learning_rate=1e-2)
     s.run(1, record=False)
     losses, stopped, nupd = s.run(30, record=True, tol=1e-14)

@@ -35,7 +35,7 @@ def random_problem(nvecs, bls_per_grp, nants=9, nfreqs=200, seed=0, rowblocks=Fa
     return p, start
 
 
-def check(p, start, dtypes=(np.float64, np.float32), layouts=("stream", "shared"), regs=(False, True)):
+def check(p, start, dtypes=(np.float64, np.float32), layouts=("stream", "shared"), regs=(False, True), kernel_path="auto"):
     from calamity_amd.solver import HipFitSolver
 
     c = CRef(p, np.float64)
@@ -47,7 +47,7 @@ def check(p, start, dtypes=(np.float64, np.float32), layouts=("stream", "shared"
             tol_l, tol_g = (1e-10, 1e-10) if dtype == np.float64 else (2e-5, 2e-4)
             for layout in layouts:
                 s = HipFitSolver(dtype=dtype)
-                s.set_problem(p, layout=layout)
+                s.set_problem(p, layout=layout, kernel_path=kernel_path)
                 s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
                 if reg:
                     s.set_regularization("sum", pr, pi)
@@ -71,17 +71,16 @@ def test_row_blocks_inside_groups():
     check(p, start)
 
 
-def test_dense_path_vector_counts(monkeypatch):
+def test_dense_path_vector_counts():
     """One baseline per group, nvec <= 256: fp32 + shared layout takes the MFMA kernel (nvec padded to 8 / 32 inside);
-    forced here, problems below ~2000 baselines normally take the general kernel."""
-    monkeypatch.setenv("CALAMITY_HIP_FORCE_MFMA", "1")
+    requested explicitly, problems below ~2000 baselines normally take the general kernel."""
     nvecs = [1, 7, 8, 9, 31, 32, 33, 64, 100, 129, 224, 255, 256] * 3
     p, start = random_problem(nvecs, [1] * len(nvecs), nants=12, nfreqs=1024, seed=3)
     # make same-shape groups share one basis block, as the operator cache does: panels of several baselines
     first = {}
     for g, n in enumerate(nvecs):
         p.grp_basis[g] = first.setdefault(n, g)
-    check(p, start, dtypes=(np.float32,), layouts=("shared",))
+    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense")
 
 
 def test_many_channels_few_groups_split_items():
