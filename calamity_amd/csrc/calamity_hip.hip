@@ -139,7 +139,7 @@ struct SolverT final : cal_solver {
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
-  DevBuf mf_akf4, mf_afk4, mf_panels, mf_bl_coff;
+  DevBuf mf_ops, mf_panels, mf_bl_coff;        // mf_ops: every block's packed forward operand, then every block's packed adjoint operand
   int mf_npanels = 0;
   size_t mf_ws_lds = 0;
   bool mf_ok = false;
@@ -249,6 +249,11 @@ struct SolverT final : cal_solver {
     for (int u = 0; u < nbasis && dense_ok; ++u) dense_ok = d->basis_nrowblk[u] == 1 && d->basis_nvec[u] <= DenseCfg<T>::max_nvec;
     // the dense kernels address the per-sample arrays with 32-bit BYTE offsets; the widest sample is one (re, im) pair
     if ((long long)(nbls + 2) * fpad * 2 * (long long)sizeof(T) >= (1LL << 32)) dense_ok = false;
+    // ... and its packed operands (two MFMA-native copies of every unique block) with 32-bit byte offsets from one base
+    long long dense_op_elems = 0;
+    for (int u = 0; u < nbasis && dense_ok; ++u)
+      dense_op_elems += (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256 + (long long)(fpad / 8) * ((d->basis_nvec[u] + 31) / 32) * 256;
+    if (dense_op_elems * 4 >= (1LL << 32)) dense_ok = false;
     if (d->kernel_path == CAL_PATH_DENSE && !dense_ok)
       return fail(CAL_ERR_UNSUPPORTED, "set_problem: CAL_PATH_DENSE needs the SHARED layout, one baseline per fitting group, "
                   "basis_nvec <= %d and nfreqs > 64", DenseCfg<T>::max_nvec);
@@ -350,11 +355,11 @@ struct SolverT final : cal_solver {
           okf4[u + 1] = okf4[u] + (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256;
           ofk4[u + 1] = ofk4[u] + (long long)(fpad / 8) * (nvp32[u] / 32) * 256;
         }
-        CAL_TRY(mf_akf4.alloc((size_t)okf4[nbasis] * sizeof(float), false));
-        CAL_TRY(mf_afk4.alloc((size_t)ofk4[nbasis] * sizeof(float), false));
+        for (int u = 0; u <= nbasis; ++u) ofk4[u] += okf4[nbasis];  // adjoint operands behind the forward ones, one buffer
+        CAL_TRY(mf_ops.alloc((size_t)ofk4[nbasis] * sizeof(float), false));
         for (int u = 0; u < nbasis; ++u)
           hipLaunchKernelGGL(mfma_pack_kernel, dim3(grid_for(okf4[u + 1] - okf4[u] + ofk4[u + 1] - ofk4[u])), dim3(256), 0, stream,
-                             raw.as<float>() + d->basis_offset[u], mf_akf4.as<float>() + okf4[u], mf_afk4.as<float>() + ofk4[u], nfreqs, fpad,
+                             raw.as<float>() + d->basis_offset[u], mf_ops.as<float>() + okf4[u], mf_ops.as<float>() + ofk4[u], nfreqs, fpad,
                              d->basis_nvec[u], nvp32[u]);
         HIP_TRY(hipGetLastError());
         // panels of kPanel baselines with the same basis, heaviest first
@@ -370,7 +375,7 @@ struct SolverT final : cal_solver {
         constexpr int kXcd = 8;
         std::vector<std::vector<PanelItem>> xlist(kXcd);
         std::vector<double> xwork(kXcd, 0.0);
-        const bool no_xcd = true;  // plain heaviest-first order over all XCDs (per-XCD lists measured 3 % slower: imbalance)
+        const bool no_xcd = true;  // plain heaviest-first order over all XCDs (per-XCD lists measured 3-5 % slower, twice)
         size_t rr = 0;
         for (int u : uorder) {
           if (by_u[u].empty()) continue;
@@ -851,8 +856,7 @@ struct SolverT final : cal_solver {
     if (use_mfma) {
       if constexpr (std::is_same<T, float>::value) {
         MfmaArgs m{};
-        m.a_kf4 = mf_akf4.as<float>();
-        m.a_fk4 = mf_afk4.as<float>();
+        m.ops = mf_ops.as<float>();
         m.panels = mf_panels.as<PanelItem>();
         m.bl_ant = bl_ant.as<int2>();
         m.bl_coff = mf_bl_coff.as<int>();

@@ -31,13 +31,13 @@ struct PanelItem {
   int bl[kPanel];     // baseline ids (-1: padding slot)
   int nvec, nvp2, nvp32;
   int pad;
+  // element offsets into MfmaArgs::ops (the whole buffer stays below 4 GB: the kernel adds 32-bit byte offsets to ONE base)
   long long a_kf4;    // packed forward operand  [F/32][nvp8/8][64 lanes][4]: lane (col, half), u -> A[32 fb + col][8 g + 2 u + half]
   long long a_fk4;    // packed adjoint operand  [F/8][nvp32/32][64 lanes][4]: lane (col, half), u -> A[8 cg + 2 u + half][32 t + col]
 };
 
 struct MfmaArgs {
-  const float* a_kf4;
-  const float* a_fk4;
+  const float* ops;            // packed operands of every basis block
   const PanelItem* panels;
   const int2* bl_ant;
   const int* bl_coff;          // coefficient offset of each baseline's group
@@ -66,10 +66,7 @@ struct MfmaArgs {
 //   tick k:  matrix waves   F(k): V chunk k -> s_v[k&1]          and  B(k-2): adjoint with s_g[(k-2)&1]
 //            element waves  E(k-1): s_v[(k-1)&1] -> s_g[(k-1)&1], then request chunk k's inputs
 //   one workgroup barrier per tick; VALU work of the element wave overlaps the MFMAs of the matrix wave on its SIMD.
-#ifndef CAL_WS_THREADS
-#define CAL_WS_THREADS 512
-#endif
-constexpr int kWsThreads = CAL_WS_THREADS;  // 256 = timing experiment without element waves (results are wrong)
+constexpr int kWsThreads = 512;  // 4 matrix waves + 4 element waves
 #ifdef CAL_WS_STAMP
 // diagnostic build only: per-wave cycle stamps of a few workgroups (never read by the kernels)
 __device__ long long g_ws_stamps[8][8][16][4];  // [block slot][wave][tick][stamp]
@@ -84,31 +81,39 @@ constexpr int kSW = 36;  // LDS row stride of the V / gbar chunk buffers [channe
                          // walks the 16 bank quads, so ds_read/write_b128 by 16 consecutive channels are conflict-free
 
 
-// ---- hand-scheduled operand stream of the matrix waves.
+// ---- operand stream of the matrix waves: an LDS ring filled by direct-to-LDS loads.
 // hipcc places the s_waitcnt for a load in front of its first use, and around loop back-edges it falls back to draining the
 // queue (vmcnt(0)) -- measured: every 4-MFMA group then exposes a full L2 round trip (~500-900 cycles) and the matrix pipe
-// idles half of the time.  The basis operands are therefore requested with inline-asm loads the compiler does not track, a
-// fixed number of groups ahead (ring of kRing register quads), and consumed behind explicit counted waits.
-constexpr int kRing = 6;
+// idles half of the time.  So the packed basis operands are requested a fixed number of positions ahead (kRing) with
+// loads the compiler does not track, and consumed behind explicit counted waits.  The loads are LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 B = one 1-KB ring slot per instruction, no register destination): an inline-asm
+// load INTO REGISTERS is only safe while hipcc never copies or re-assigns the destination before the data has landed, and
+// nothing guarantees that (a register ring worked for one shape of these loops and silently broke -- renamed slots, moves
+// of registers with a load in flight -- when the loops were restructured).  With the data in LDS every register the
+// compiler sees is written by an instruction it tracks (ds_read_b128 of the slot, behind the counted wait).
+constexpr int kRing = 4;                    // (4 and 8 slots measured the same: the stream is not latency-bound) slots (1 KB each) per matrix wave; vmcnt counts the wave's DMAs in issue order
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void ring_load(f32x4_t& dst, const f32x4_t* sbase, unsigned voff_bytes) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+__device__ __forceinline__ const f32x4_t* uniform_ptr(const f32x4_t* p) {  // tell the compiler the pointer is wave-uniform ("s" operands)
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const f32x4_t*>(((unsigned long long)hi << 32) | lo);
 }
-#define RING_WAIT()                                                  \
-  do {                                                               \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 1) : "memory"); \
-    __builtin_amdgcn_sched_barrier(0);                               \
+// slot at LDS byte address lds_slot (wave-uniform) <- 64 x 16 B at sbase + lane_bytes + item_bytes.  M0 carries the LDS
+// address of an LDS-DMA and is not preserved by the compiler around an asm: saved, set and restored in ONE statement.
+__device__ __forceinline__ void ring_issue(unsigned lds_slot, const f32x4_t* sbase, unsigned lane_bytes, unsigned item_bytes) {
+  const unsigned vo = lane_bytes + item_bytes;
+  sbase = uniform_ptr(sbase);  // under scalar-register pressure hipcc parks a base in vector registers and would hand THOSE to the asm
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_slot), "v"(vo), "s"(sbase)
+               : "memory");
+}
+#define RING_WAIT(N)                                            \
+  do {                                                          \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                          \
   } while (0)
-// Every phase ends with kRing requests whose data nobody reads (they keep the count in RING_WAIT constant).  They must have
-// landed before the next phase requests into the same registers: two loads in flight to ONE register are not guaranteed
-// to write it in issue order (the compiler never creates that situation: it waits on such a write-after-write), and a
-// late discarded load overwrote fresh operands -- gradients that differed from run to run, but only once the element
-// waves stopped being the slow side of every barrier, which until then had given those requests time to land.
-#define RING_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// A ring register whose last request nobody reads is, to the compiler, free from that request on -- but the data lands
-// later, into whatever the register has been given to meanwhile.  RING_KEEP (placed behind a drain) reads all six, so they
-// stay allocated until their last request has landed.
-#define RING_KEEP() asm volatile("" ::"v"(R0), "v"(R1), "v"(R2), "v"(R3), "v"(R4), "v"(R5))
 
 template <bool GRAD>
 __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArgs A) {
@@ -134,7 +139,8 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
   const int NT = nvp32 / 32;
   const int ngk = (nvec + 7) / 8;  // forward k-groups of 8 vectors (4 k-steps)
 
-  float* s_c = reinterpret_cast<float*>(smem_raw);          // [ngk][64 lanes][4] packed coefficient operand
+  unsigned char* s_ring = smem_raw;                         // [4 matrix waves][kRing][1 KB] operand ring, lowest LDS addresses
+  float* s_c = reinterpret_cast<float*>(smem_raw + 4 * kRing * 1024);  // [ngk][64 lanes][4] packed coefficient operand
   float* s_v = s_c + (size_t)ngk * 256;                     // [2][kChunk][kSW]  model visibilities, rows = (slot, re|im)
   float* s_g = s_v + 2 * (size_t)kChunk * kSW;              // [2][kChunk][kSW]  gbar_v
   int* s_bl = reinterpret_cast<int*>(s_g + 2 * (size_t)kChunk * kSW);  // [16] baseline, [16] ant0, [16] ant1
@@ -162,11 +168,7 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
   }
   __syncthreads();
 
-#ifdef CAL_MF_DEBUG_CHUNKS
-  const int nchunks = CAL_MF_DEBUG_CHUNKS;  // timing experiment only (results are wrong)
-#else
   const int nchunks = A.fpad / kChunk;
-#endif
   const int nticks = nchunks + (GRAD ? 2 : 1);
 #ifdef CAL_WS_STAMP
   const int sblk = (blockIdx.x >= 2048 && blockIdx.x < 2056) ? (int)blockIdx.x - 2048 : -1;
@@ -175,103 +177,140 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
   if (is_matrix) {
     // ================================================= matrix waves ==============================================
     __builtin_amdgcn_s_setprio(2);  // the matrix wave's issue slots come first on the SIMD it shares with an element wave
-    int t0, t1 = -1, kq = 0, nkq = 1;
-    if (NT == 1) { t0 = 0; kq = w4; nkq = 4; }
-    else if (NT == 2) { t0 = w4 & 1; kq = w4 >> 1; nkq = 2; }
-    else if (NT <= 4) { t0 = w4 < NT ? w4 : -1; }
-    else { t0 = w4; t1 = w4 + 4 < NT ? w4 + 4 : -1; }
-    f32x16 gacc0, gacc1;
+    // Adjoint work of a chunk = NT vector tiles x 16 channel groups (1 item = 8 channels x 32 vectors = 4 MFMAs), split
+    // evenly whatever NT is.  Tiles come in groups of four, one WHOLE tile per wave (segments 0 and 1: tiles w4, w4 + 4).
+    // The r = NT % 4 tiles left over are split along K: their 16 r items, flattened tile-major, are cut into four runs of
+    // 4 r, one per wave -- a run touches one or two tiles (segments 2 and 3).  Every wave runs exactly 4 NT items per chunk,
+    // owns one accumulator per segment (at most four) and every segment length is a multiple of 4, which keeps the
+    // accumulator of each step static (a segment = whole half-rounds of the operand ring).  The partial sums of the
+    // K-split tiles meet in LDS once, at the end of the panel.
+    const int nfull4 = NT >> 2;                 // whole tiles of this wave: 0, 1 or 2
+    const int nrem = NT & 3;
+    const int nfullt = nfull4 * 4;
+    const int n0 = nfull4 > 0 ? 16 : 0, n1 = nfull4 > 1 ? 16 : 0;
+    const int rs = 4 * nrem * w4;               // this wave's run of the flattened (tile, channel group) list of the K-split tiles
+    const int t2 = nfullt + (rs >> 4), c2 = rs & 15;
+    const int n2 = nrem == 0 ? 0 : (16 - c2 < 4 * nrem ? 16 - c2 : 4 * nrem);
+    const int n3 = 4 * nrem - n2;               // continues in the next tile at channel group 0
+    const int e0 = n0, e1 = e0 + n1, e2 = e1 + n2;
+    const int nitem = e2 + n3;                  // = 4 NT
+    f32x16 gacc0, gacc1, gacc2, gacc3;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) gacc0[j] = gacc1[j] = 0.f;
-    const f32x4* akf4 = reinterpret_cast<const f32x4*>(A.a_kf4 + P.a_kf4);   // scalar bases
-    const f32x4* afk4 = reinterpret_cast<const f32x4*>(A.a_fk4 + P.a_fk4);
+    for (int j = 0; j < 16; ++j) gacc0[j] = gacc1[j] = gacc2[j] = gacc3[j] = 0.f;
+    const f32x4* ops = reinterpret_cast<const f32x4*>(A.ops);  // ONE scalar base for every operand request
+    const unsigned fblk = (unsigned)P.a_kf4 * 4u, bblk = (unsigned)P.a_fk4 * 4u;  // byte offsets of this panel's two packed blocks
     const f32x4* sc4 = reinterpret_cast<const f32x4*>(s_c);
     const unsigned voff = (unsigned)lane * 16u;
-    f32x4 R0, R1, R2, R3, R4, R5;  // the operand ring (kRing = 6 register quads)
-    R0 = R1 = R2 = R3 = R4 = R5 = f32x4{0.f, 0.f, 0.f, 0.f};
-    // items of the adjoint phase of this wave (wave constants) and the operand address of an item of either phase; both
-    // clamp the item index, so an address always lies inside this panel's packed operand blocks
-    const int ng_per = (kChunk / 8) / nkq;  // channel groups (8 channels = 4 k-steps) of this wave: 16, 8 or 4
-    const int cg0 = kq * ng_per;
-    const int two = t1 >= 0 ? 1 : 0;
-    const int nitem = ng_per << two;
-    const bool has_b = GRAD && t0 >= 0;
-    auto f_addr = [&](int kk, int g) { return akf4 + ((size_t)(kk * 4 + w4) * ngk + (g < ngk ? g : ngk - 1)) * 64; };
-    auto b_addr = [&](int ci, int i) {
-      i = i < nitem ? i : nitem - 1;
-      const int cg = cg0 + (i >> two), t = (i & two) ? t1 : t0;
-      return afk4 + ((size_t)(ci * (kChunk / 8) + cg) * NT + t) * 64;
+    // this wave's operand ring: LDS byte address of slot 0 (for the DMA) and this lane's quad of a slot (for the read back)
+    const unsigned ring_lds = (unsigned)reinterpret_cast<unsigned long long>(s_ring + w4 * kRing * 1024);
+    const f32x4* ring_rd = reinterpret_cast<const f32x4*>(s_ring + w4 * kRing * 1024) + lane;
+    // What a step needs per position -- the operand's byte offset and, in the adjoint phase, the LDS offset of its gbar rows
+    // -- is wave-uniform but awkward to compute (segments, clamps); done with scalar code in every step it cost more than
+    // the step's MFMAs hide.  Each lane computes the entry of ONE position once per panel (vector compares and selects)
+    // and a step fetches its entry with v_readlane:
+    //   lanes 0-31  : adjoint position p = lane     -> (cg NT + t) KB, offset of its operand inside an adjoint chunk
+    //   lanes 32-63 : adjoint position p = lane-32  -> byte offset of channel group cg inside a gbar chunk buffer
+    unsigned tabB;
+    {
+      int p = lane & 31;
+      p = p < nitem ? p : nitem - 1;
+      int t, cg;
+      if (p < e0) { t = w4; cg = p; }
+      else if (p < e1) { t = w4 + 4; cg = p - e0; }
+      else if (p < e2) { t = t2; cg = c2 + (p - e1); }
+      else { t = t2 + 1; cg = p - e2; }
+      tabB = lane < 32 ? (unsigned)(cg * NT + t) * 1024u : (unsigned)(8 * cg * kSW) * 4u;
+    }
+    auto tab = [&](int i) { return (unsigned)__builtin_amdgcn_readlane((int)tabB, i); };
+    // byte offset (from `ops`) of forward chunk kk of this wave / of adjoint chunk ci
+    auto f_base = [&](int kk) { return fblk + (unsigned)((kk * 4 + w4) * ngk) * 1024u; };
+    auto b_base = [&](int ci) { return bblk + (unsigned)(ci * (kChunk / 8) * NT) * 1024u; };
+    // offset of position q of a phase of `kind` (1 forward, 2 adjoint) whose chunk starts at `base`; q < 32, clamped
+    auto pos_off = [&](int kind, unsigned base, int q) {
+      const unsigned of = (unsigned)(q < ngk ? q : ngk - 1) << 10;
+      const unsigned ob = tab(q & 31);
+      return base + (kind == 2 ? ob : of);
     };
-    // Phase chaining: the last kRing requests of a phase (which used to fetch data nobody reads, only to keep the count of
-    // RING_WAIT constant) fetch the FIRST kRing items of the wave's next phase -- across the barrier too, the packed basis
-    // does not depend on the element waves -- so that phase starts with its operands in flight instead of an exposed L2
-    // round trip.  No register ever has two loads in flight.  nx_kind: 0 none, 1 forward of chunk nx_k, 2 adjoint of nx_k.
-    auto first_phase_of_tick = [&](int kk, int& kind, int& kx) {
-      kind = 0;
-      kx = 0;
-      if (!GRAD) return;  // the forward-only pass is bound by its element waves: chaining only adds scalar work there
-      if (kk >= nticks) return;
-      if (kk < nchunks) { kind = 1; kx = kk; }
-      else if (has_b && kk >= 2) { kind = 2; kx = kk - 2; }
+    // The stream of positions runs through all phases of the panel: a step at position p requests position p + kRing, past
+    // the end of its phase a position of the wave's NEXT phase -- across the barrier too, the packed basis does not depend
+    // on the element waves -- so a phase starts with its first operands in LDS instead of an exposed L2 round trip.
+    // kind: 0 none, 1 forward of chunk kx, 2 adjoint of chunk kx.
+    // (a phase shorter than the ring would need requests two phases ahead: panels with nvec <= 56 do not chain)
+    const bool chain_ok = GRAD && ngk >= kRing && nitem >= kRing;
+    auto phase_after_F = [&](int k, int& kind, int& kx) {  // what this wave runs after F(k)
+      kind = 0; kx = 0;
+      if (!chain_ok) return;  // also: the forward-only pass is bound by its element waves, chaining only adds scalar work there
+      if (k >= 2) { kind = 2; kx = k - 2; }
+      else if (k + 1 < nchunks) { kind = 1; kx = k + 1; }
+      else if (k + 1 < nticks && k + 1 >= 2) { kind = 2; kx = k - 1; }
     };
-    bool primed = false;  // the ring already holds (in flight) the first kRing items of the phase about to start
+    auto phase_after_B = [&](int k, int& kind, int& kx) {  // what this wave runs after B(k - 2), i.e. in tick k + 1
+      kind = 0; kx = 0;
+      if (!chain_ok || k + 1 >= nticks) return;
+      if (k + 1 < nchunks) { kind = 1; kx = k + 1; }
+      else { kind = 2; kx = k - 1; }
+    };
+    int cons = 0;         // stream index of the position the next step consumes; its slot is cons % kRing
+    bool primed = false;  // the ring already holds (landed or in flight) the first kRing positions of the phase about to start
+    f32x4 r_cur = f32x4{0.f, 0.f, 0.f, 0.f}, r_nxt;  // operand quad of the current / the next position
+    // start a phase the previous one did not chain to: retire whatever is in flight, request kRing positions, read the first
+#define RING_PRIME(KIND, BASE)                                                                   \
+  {                                                                                              \
+    RING_WAIT(0);                                                                                \
+    for (int j = 0; j < kRing; ++j) ring_issue(ring_lds + (unsigned)((cons + j) & (kRing - 1)) * 1024u, ops, voff, pos_off(KIND, BASE, j)); \
+    RING_WAIT(kRing - 1);                                                                        \
+    r_cur = ring_rd[(cons & (kRing - 1)) * 64];                                                  \
+  }
+    // One position = 4 MFMAs (256 cycles of the SIMD's matrix pipe) + everything that feeds the next ones.  A wave issues
+    // in order and an MFMA waits for the pipe, so whatever stands BEHIND the four MFMAs runs in the shadow of the last one
+    // only (64 cycles; measured: 400-560 cycles per position instead of 256 with ~35 instructions and a DMA there).  The
+    // feed work is therefore placed BETWEEN the MFMAs, a piece per 64-cycle gap, and pinned there with scheduling barriers:
+    //   MFMA 0 | A operand of the next position (LDS)            (STEP_A)
+    //   MFMA 1 | next position's operand has landed -> read back (RING_NEXT: all but the kRing - 2 youngest requests)
+    //   MFMA 2 | this position's slot is free (read one step ago) -> request position + kRing into it (RING_REQ)
+    //   MFMA 3 | loop bookkeeping
+#define RING_NEXT()                                        \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  RING_WAIT(kRing - 2);                                    \
+  r_nxt = ring_rd[((cons + 1) & (kRing - 1)) * 64];        \
+  __builtin_amdgcn_sched_barrier(0);
+#define RING_REQ(REQOFF)                                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  ring_issue(ring_lds + (unsigned)(cons & (kRing - 1)) * 1024u, ops, voff, REQOFF);              \
+  __builtin_amdgcn_sched_barrier(0);
+#define RING_ADVANCE() \
+  r_cur = r_nxt;       \
+  ++cons;
     for (int k = 0; k < nticks; ++k) {
       WS_STAMP(sblk, k, 0);
       if (k < nchunks) {
-        // ---- F(k): rows = (slot, re|im), columns = this wave's 32 channels, K = vectors: item = k-group g (4 MFMAs)
+        // ---- F(k): rows = (slot, re|im), columns = this wave's 32 channels, K = vectors: position = k-group g (4 MFMAs)
         f32x16 acc, acc2;  // two accumulator chains
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = acc2[j] = 0.f;
-        const f32x4* tile = akf4 + ((size_t)(k * 4 + w4) * ngk) * 64;  // scalar base; item g at + 64 g
-        auto src = [&](int g) { return tile + (g < ngk ? g : ngk - 1) * 64; };
         int nx_kind, nx_k;
-        if (has_b && k >= 2) { nx_kind = 2; nx_k = k - 2; }
-        else first_phase_of_tick(k + 1, nx_kind, nx_k);
-        auto nxt = [&](int j) { return nx_kind == 1 ? f_addr(nx_k, j) : nx_kind == 2 ? b_addr(nx_k, j) : src(ngk - 1); };
-        if (!primed) {
-          RING_DRAIN();
-          RING_KEEP();
-          ring_load(R0, src(0), voff);
-          ring_load(R1, src(1), voff);
-          ring_load(R2, src(2), voff);
-          ring_load(R3, src(3), voff);
-          ring_load(R4, src(4), voff);
-          ring_load(R5, src(5), voff);
-        }
+        phase_after_F(k, nx_kind, nx_k);
+        const unsigned cur_base = f_base(k);
+        const unsigned nx_base = nx_kind == 1 ? f_base(nx_k) : nx_kind == 2 ? b_base(nx_k) : cur_base;
+        const int nx_kd = nx_kind == 0 ? 1 : nx_kind;  // nothing to chain to: re-request this phase's (clamped) positions
+        if (!primed) RING_PRIME(1, cur_base)
         primed = nx_kind != 0;
         f32x4 a_cur = (sc4 + 0)[lane], a_nxt;
-#define F_STEP(RJ, J, NEXTSRC)                                                                   \
-  {                                                                                              \
-    const int g = g0 + (J);                                                                      \
-    a_nxt = (sc4 + (g + 1 < ngk ? g + 1 : ngk - 1) * 64)[lane];                                  \
-    RING_WAIT();                                                                                 \
-    if (g < ngk) {                                                                               \
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], RJ[0], acc, 0, 0, 0);                 \
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], RJ[1], acc2, 0, 0, 0);               \
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], RJ[2], acc, 0, 0, 0);                 \
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], RJ[3], acc2, 0, 0, 0);               \
-    }                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    ring_load(RJ, NEXTSRC, voff);                                                                \
-    a_cur = a_nxt;                                                                               \
-  }
-        int g0 = 0;
-        for (; g0 + kRing < ngk; g0 += kRing) {
-          F_STEP(R0, 0, src(g + kRing))
-          F_STEP(R1, 1, src(g + kRing))
-          F_STEP(R2, 2, src(g + kRing))
-          F_STEP(R3, 3, src(g + kRing))
-          F_STEP(R4, 4, src(g + kRing))
-          F_STEP(R5, 5, src(g + kRing))
+        for (int g = 0; g < ngk; ++g) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], r_cur[0], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          a_nxt = (sc4 + (g + 1 < ngk ? g + 1 : ngk - 1) * 64)[lane];
+          __builtin_amdgcn_sched_barrier(0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], r_cur[1], acc2, 0, 0, 0);
+          RING_NEXT()
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], r_cur[2], acc, 0, 0, 0);
+          const int q = g + kRing;  // position q of THIS phase, or position q - ngk of the next one
+          RING_REQ(q < ngk ? pos_off(1, cur_base, q) : pos_off(nx_kd, nx_base, q - ngk))
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], r_cur[3], acc2, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          RING_ADVANCE()
+          a_cur = a_nxt;
         }
-        // last group of steps: its requests belong to the next phase
-        F_STEP(R0, 0, nxt(0))
-        F_STEP(R1, 1, nxt(1))
-        F_STEP(R2, 2, nxt(2))
-        F_STEP(R3, 3, nxt(3))
-        F_STEP(R4, 4, nxt(4))
-        F_STEP(R5, 5, nxt(5))
-#undef F_STEP
         // accumulator regs 4 q .. 4 q + 3 of this lane = rows 8 q + 4 half + 0..3 of column (channel) w4*32 + col
         f32x4* vout = reinterpret_cast<f32x4*>(s_v + (size_t)(k & 1) * kChunk * kSW + (w4 * 32 + col) * kSW + 4 * half);
 #pragma unroll
@@ -285,123 +324,107 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
         }
       }
       WS_STAMP(sblk, k, 1);
-      if (GRAD && k >= 2 && t0 >= 0) {
-        // ---- B(k-2): rows = (slot, re|im), columns = vectors of tile t, K = this wave's slice of the chunk's channels.
-        // item i = (channel group cg0 + i / ntl, tile i % ntl), ntl = 1 or 2 vector tiles per wave; 4 MFMAs per item
+      if (GRAD && k >= 2) {
+        // ---- B(k-2): rows = (slot, re|im), columns = vectors of a tile, K = 8 channels of the chunk per position (4 MFMAs)
         const int ci = k - 2;
         const float* gp = s_g + (size_t)(ci & 1) * kChunk * kSW + half * kSW + col;       // + (8 cg + 2 v) kSW
-        const f32x4* bp = afk4 + ((size_t)(ci * (kChunk / 8)) * NT) * 64;                  // scalar; + (cg NT + t) 64
-        auto src = [&](int i) {
-          i = i < nitem ? i : nitem - 1;
-          const int cg = cg0 + (i >> two), t = (i & two) ? t1 : t0;
-          return bp + ((size_t)cg * NT + t) * 64;
-        };
-        auto lds_a = [&](int i, float (&a)[4]) {
-          i = i < nitem ? i : nitem - 1;
-          const int cg = cg0 + (i >> two);
-#pragma unroll
-          for (int v = 0; v < 4; ++v) a[v] = gp[(8 * cg + 2 * v) * kSW];
-        };
         int nx_kind, nx_k;
-        first_phase_of_tick(k + 1, nx_kind, nx_k);
-        auto nxt = [&](int j) { return nx_kind == 1 ? f_addr(nx_k, j) : nx_kind == 2 ? b_addr(nx_k, j) : src(nitem - 1); };
-        if (!primed) {
-          RING_DRAIN();
-          RING_KEEP();
-          ring_load(R0, src(0), voff);
-          ring_load(R1, src(1), voff);
-          ring_load(R2, src(2), voff);
-          ring_load(R3, src(3), voff);
-          ring_load(R4, src(4), voff);
-          ring_load(R5, src(5), voff);
-        }
+        phase_after_B(k, nx_kind, nx_k);
+        const unsigned cur_base = b_base(ci);
+        const unsigned nx_base = nx_kind == 1 ? f_base(nx_k) : nx_kind == 2 ? b_base(nx_k) : cur_base;
+        const int nx_kd = nx_kind == 0 ? 2 : nx_kind;
+        auto lds_a = [&](int p, float (&a)[4]) {  // gbar rows of position p (table entries past the last position repeat it)
+          const float* g8 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(gp) + tab(32 + (p & 31)));
+#pragma unroll
+          for (int v = 0; v < 4; ++v) a[v] = g8[2 * v * kSW];
+        };
+        if (!primed) RING_PRIME(2, cur_base)
         primed = nx_kind != 0;
         float a_cur[4], a_nxt[4];
         lds_a(0, a_cur);
-        // even items accumulate into gacc0, odd items into gacc1: with two tiles that is tile t0 / t1, with one tile two
-        // independent chains of the same tile (kRing is even, so the parity of an item is the parity of its ring slot)
-#define B_STEP(RJ, J, GACC, NEXTSRC)                                                             \
-  {                                                                                              \
-    const int it = i0 + (J);                                                                     \
-    lds_a(it + 1, a_nxt);                                                                        \
-    RING_WAIT();                                                                                 \
-    if (it < nitem) {                                                                            \
-      GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], RJ[0], GACC, 0, 0, 0);               \
-      GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], RJ[1], GACC, 0, 0, 0);               \
-      GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], RJ[2], GACC, 0, 0, 0);               \
-      GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], RJ[3], GACC, 0, 0, 0);               \
-    }                                                                                            \
+        // one loop per segment: the accumulator of a step is static
+#define B_SEG(GACC, PBEG, PEND)                                                                  \
+  for (int pp = (PBEG); pp < (PEND); ++pp) {                                                     \
+    GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], r_cur[0], GACC, 0, 0, 0);              \
     __builtin_amdgcn_sched_barrier(0);                                                           \
-    ring_load(RJ, NEXTSRC, voff);                                                                \
+    lds_a(pp + 1, a_nxt);                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], r_cur[1], GACC, 0, 0, 0);              \
+    RING_NEXT()                                                                                  \
+    GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], r_cur[2], GACC, 0, 0, 0);              \
+    const int q = pp + kRing;                                                                    \
+    RING_REQ(q < nitem ? pos_off(2, cur_base, q) : pos_off(nx_kd, nx_base, q - nitem))           \
+    GACC = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], r_cur[3], GACC, 0, 0, 0);              \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    RING_ADVANCE()                                                                               \
     a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; a_cur[2] = a_nxt[2]; a_cur[3] = a_nxt[3];          \
   }
-        int i0 = 0;
-        for (; i0 + kRing < nitem; i0 += kRing) {
-          B_STEP(R0, 0, gacc0, src(it + kRing))
-          B_STEP(R1, 1, gacc1, src(it + kRing))
-          B_STEP(R2, 2, gacc0, src(it + kRing))
-          B_STEP(R3, 3, gacc1, src(it + kRing))
-          B_STEP(R4, 4, gacc0, src(it + kRing))
-          B_STEP(R5, 5, gacc1, src(it + kRing))
-        }
-        // last group of steps: its requests belong to the next phase
-        B_STEP(R0, 0, gacc0, nxt(0))
-        B_STEP(R1, 1, gacc1, nxt(1))
-        B_STEP(R2, 2, gacc0, nxt(2))
-        B_STEP(R3, 3, gacc1, nxt(3))
-        B_STEP(R4, 4, gacc0, nxt(4))
-        B_STEP(R5, 5, gacc1, nxt(5))
-#undef B_STEP
+        B_SEG(gacc0, 0, e0)
+        B_SEG(gacc1, e0, e1)
+        B_SEG(gacc2, e1, e2)
+        B_SEG(gacc3, e2, nitem)
+#undef B_SEG
       }
       WS_STAMP(sblk, k, 2);
       __syncthreads();
       WS_STAMP(sblk, k, 3);
 #ifdef CAL_WS_STAMP
-      if (sblk >= 0 && lane == 0 && (k == 0 || k == nticks - 1)) { g_ws_stamps[sblk][wave][k == 0 ? 14 : 15][0] = (long long)__builtin_amdgcn_s_memrealtime(); g_ws_stamps[sblk][wave][14][1] = nvec; g_ws_stamps[sblk][wave][14][2] = NT; g_ws_stamps[sblk][wave][14][3] = t0 * 100 + t1 * 10 + nkq; }
+      if (sblk >= 0 && lane == 0 && (k == 0 || k == nticks - 1)) { g_ws_stamps[sblk][wave][k == 0 ? 14 : 15][0] = (long long)__builtin_amdgcn_s_memrealtime(); g_ws_stamps[sblk][wave][14][1] = nvec; g_ws_stamps[sblk][wave][14][2] = NT; g_ws_stamps[sblk][wave][14][3] = nfull4 * 10 + nrem; }
 #endif
     }
-    RING_DRAIN();  // retire the last phase's trailing requests
-    RING_KEEP();
+#undef RING_PRIME
+#undef RING_NEXT
+#undef RING_REQ
+#undef RING_ADVANCE
+    RING_WAIT(0);  // retire the last phase's trailing requests: the epilogue reuses LDS
     if (!GRAD) return;
-    if (t1 < 0) {
+    // ---- coefficient gradients.  Whole tiles are final in their accumulators.  The partial sums of the K-split tiles
+    // (segments 2 and 3 of every wave) meet in LDS -- the V / gbar chunk buffers are idle now -- and wave jr adds, in
+    // fixed order, the parts that belong to tile nfullt + jr and stores it.
+    auto store_tile = [&](const f32x16& g, int t) {
+      const int n = t * 32 + col;
+      if (n < nvec) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) gacc0[j] += gacc1[j];
-    }
-    // ---- coefficient gradients: sum the K-slices of different matrix waves through LDS, then store
-    if (nkq > 1) {
-      float* s_x = s_v;  // [4 waves][16 regs][64 lanes] = 16 KB, inside the (now idle) s_v double buffer
-#pragma unroll
-      for (int j = 0; j < 16; ++j) s_x[(w4 * 16 + j) * 64 + lane] = gacc0[j];
-    }
-    __syncthreads();  // pairs with the element waves' barrier after their tick loop
-    if (nkq > 1 && kq == 0) {
-      const float* s_x = s_v;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float v = gacc0[j];
-        for (int q = 1; q < nkq; ++q) v += s_x[((w4 + q * (NT == 1 ? 1 : 2)) * 16 + j) * 64 + lane];
-        gacc0[j] = v;
-      }
-    }
-    if (kq == 0 && t0 >= 0) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = tt == 0 ? t0 : t1;
-        if (t < 0) continue;
-        const int n = t * 32 + col;
-        if (n < nvec) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
-            const int b = P.bl[slot];
-            if (b >= 0) {
-              const int coff = A.bl_coff[b];
-              A.gc_r[coff + n] = tt == 0 ? gacc0[j] : gacc1[j];
-              A.gc_i[coff + n] = tt == 0 ? gacc0[j + 8] : gacc1[j + 8];
-            }
+        for (int j = 0; j < 8; ++j) {
+          const int slot = (j & 3) + 8 * (j >> 2) + 4 * half;
+          const int b = P.bl[slot];
+          if (b >= 0) {
+            const int coff = A.bl_coff[b];
+            A.gc_r[coff + n] = g[j];
+            A.gc_i[coff + n] = g[j + 8];
           }
         }
       }
+    };
+    float* s_x = s_v;  // [wave][segment 2 | 3][16 regs][64 lanes] = 32 KB inside the s_v / s_g buffers (72 KB)
+    if (n2 > 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s_x[((w4 * 2 + 0) * 16 + j) * 64 + lane] = gacc2[j];
+    }
+    if (n3 > 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s_x[((w4 * 2 + 1) * 16 + j) * 64 + lane] = gacc3[j];
+    }
+    __syncthreads();  // pairs with the element waves' barrier after their tick loop
+    if (n0 > 0) store_tile(gacc0, w4);
+    if (n1 > 0) store_tile(gacc1, w4 + 4);
+    if (w4 < nrem) {
+      f32x16 g;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) g[j] = 0.f;
+      for (int w = 0; w < 4; ++w) {  // the runs of the four waves, in wave order (fixed summation order)
+        const int ws = 4 * nrem * w, wt = ws >> 4, wc = ws & 15;
+        const int wn2 = 16 - wc < 4 * nrem ? 16 - wc : 4 * nrem, wn3 = 4 * nrem - wn2;
+        if (wt == w4) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) g[j] += s_x[((w * 2 + 0) * 16 + j) * 64 + lane];
+        }
+        if (wn3 > 0 && wt + 1 == w4) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) g[j] += s_x[((w * 2 + 1) * 16 + j) * 64 + lane];
+        }
+      }
+      store_tile(g, nfullt + w4);
     }
   } else {
     // ================================================= element waves =============================================
@@ -492,25 +515,21 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
     __syncthreads();  // tick 0: nothing to consume yet
     for (int k = 1; k < nticks; k += 2) {
       WS_STAMP(sblk, k, 0);
-#ifndef CAL_WS_X_NOELEM
       if (k <= nchunks) {
         process(k - 1, X);
         WS_STAMP(sblk, k, 1);
         if (k + 1 < nchunks) request(k + 1, X);
       }
-#endif
       WS_STAMP(sblk, k, 2);
       __syncthreads();
       WS_STAMP(sblk, k, 3);
       if (k + 1 < nticks) {
-#ifndef CAL_WS_X_NOELEM
         WS_STAMP(sblk, k + 1, 0);
         if (k + 1 <= nchunks) {
           process(k, Y);
           WS_STAMP(sblk, k + 1, 1);
           if (k + 2 < nchunks) request(k + 2, Y);
         }
-#endif
         WS_STAMP(sblk, k + 1, 2);
         __syncthreads();
         WS_STAMP(sblk, k + 1, 3);
@@ -535,7 +554,8 @@ __global__ __launch_bounds__(kWsThreads) void fused_mfma_ws_kernel(const MfmaArg
 }
 
 inline size_t mfma_ws_lds_bytes(int nvec_max) {
-  return ((size_t)((nvec_max + 7) / 8) * 256 + 4 * (size_t)kChunk * kSW) * sizeof(float) + 48 * sizeof(int) + 12 * sizeof(double) + 64;
+  return 4 * (size_t)kRing * 1024 + ((size_t)((nvec_max + 7) / 8) * 256 + 4 * (size_t)kChunk * kSW) * sizeof(float) + 48 * sizeof(int) +
+         12 * sizeof(double) + 64;
 }
 
 // packed MFMA-native operand layouts of the wave-specialised kernel (see PanelItem)
