@@ -16,7 +16,7 @@
 #include <vector>
 
 #include "fit_kernels.hpp"
-#include "mfma_kernels.hpp"
+#include "dense_kernels.hpp"
 #include <cstdlib>
 #include <type_traits>
 
@@ -141,7 +141,8 @@ struct SolverT final : cal_solver {
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels, mf_bl_coff;        // mf_ops: every block's packed forward operand, then every block's packed adjoint operand
   int mf_npanels = 0;
-  size_t mf_ws_lds = 0;
+  int mf_split = 0;                            // panels [0, mf_split) have more than 4 vector tiles (kernel instance with 8 accumulator tiles)
+  size_t mf_lds_grad = 0, mf_lds_loss = 0;
   bool mf_ok = false;
   int steps_per_sync = 1;                      // train steps enqueued between two host synchronisations of run()
   DevBuf agree_buf;
@@ -353,7 +354,7 @@ struct SolverT final : cal_solver {
           nvp32[u] = (d->basis_nvec[u] + 31) / 32 * 32;
           nvec_max = std::max(nvec_max, d->basis_nvec[u]);
           okf4[u + 1] = okf4[u] + (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256;
-          ofk4[u + 1] = ofk4[u] + (long long)(fpad / 8) * (nvp32[u] / 32) * 256;
+          ofk4[u + 1] = ofk4[u] + (long long)(fpad / 32) * (nvp32[u] / 32) * 4 * 256;
         }
         for (int u = 0; u <= nbasis; ++u) ofk4[u] += okf4[nbasis];  // adjoint operands behind the forward ones, one buffer
         CAL_TRY(mf_ops.alloc((size_t)ofk4[nbasis] * sizeof(float), false));
@@ -368,41 +369,28 @@ struct SolverT final : cal_solver {
         std::vector<int> uorder(nbasis);
         std::iota(uorder.begin(), uorder.end(), 0);
         std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
-        // XCD-aware order (not the default, see no_xcd): workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
-        // 4 MB L2), so all panels of one basis block go to ONE XCD (its operand copies, ~1 MB, then stay L2-resident
-        // there); blocks are spread over XCDs by greedy longest-processing-time balancing of the MFMA work.  The kernel
-        // maps block b to panel (b % 8) * per_xcd + b / 8; short lists are padded with empty panels (nvec = 0).
-        constexpr int kXcd = 8;
-        std::vector<std::vector<PanelItem>> xlist(kXcd);
-        std::vector<double> xwork(kXcd, 0.0);
-        const bool no_xcd = true;  // plain heaviest-first order over all XCDs (per-XCD lists measured 3-5 % slower, twice)
-        size_t rr = 0;
-        for (int u : uorder) {
-          if (by_u[u].empty()) continue;
-          int x = (int)(std::min_element(xwork.begin(), xwork.end()) - xwork.begin());
-          const int npan = (int)((by_u[u].size() + kPanel - 1) / kPanel);
-          xwork[x] += (double)npan * (nvp2[u] + nvp32[u]);
-          for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
-            PanelItem pi{};
-            for (int k = 0; k < kPanel; ++k) pi.bl[k] = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
-            pi.a_kf4 = okf4[u];
-            pi.a_fk4 = ofk4[u];
-            pi.nvec = d->basis_nvec[u];
-            pi.nvp2 = nvp2[u];
-            pi.nvp32 = nvp32[u];
-            if (no_xcd) x = (int)(rr++ % kXcd);
-            xlist[x].push_back(pi);
-          }
-        }
-        size_t per_xcd = 0;
-        for (auto& l : xlist) per_xcd = std::max(per_xcd, l.size());
-        PanelItem empty{};
-        for (int k = 0; k < kPanel; ++k) empty.bl[k] = -1;
+        // Two launch classes: panels with more than four vector tiles first, then the rest; inside a class the heaviest
+        // panels come first (the hardware dispatches workgroups in index order, so the tail is made of the lightest).
+        // Per-XCD panel lists (all panels of a basis block on one XCD, its packed operands L2-resident there: the L2 hit
+        // rate of the operand requests is only 55-65 % without them) measured 3-5 % SLOWER with every generation of this
+        // kernel: panels of one block then walk the same lines in step.
         std::vector<PanelItem> h_panels;
-        h_panels.reserve(per_xcd * kXcd);
-        for (auto& l : xlist) {
-          h_panels.insert(h_panels.end(), l.begin(), l.end());
-          h_panels.insert(h_panels.end(), per_xcd - l.size(), empty);
+        mf_split = 0;
+        for (int cls = 0; cls < 2; ++cls) {
+          for (int u : uorder) {
+            if ((nvp32[u] > 128) != (cls == 0)) continue;
+            for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
+              PanelItem pi{};
+              for (int k = 0; k < kPanel; ++k) pi.bl[k] = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+              pi.a_kf4 = okf4[u];
+              pi.a_fk4 = ofk4[u];
+              pi.nvec = d->basis_nvec[u];
+              pi.nvp2 = nvp2[u];
+              pi.nvp32 = nvp32[u];
+              h_panels.push_back(pi);
+            }
+          }
+          if (cls == 0) mf_split = (int)h_panels.size();
         }
         mf_npanels = (int)h_panels.size();
         CAL_TRY(mf_panels.alloc(h_panels.size() * sizeof(PanelItem), false));
@@ -412,9 +400,12 @@ struct SolverT final : cal_solver {
         CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
         HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        mf_ws_lds = mfma_ws_lds_bytes(nvec_max);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_mfma_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_ws_lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_mfma_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_ws_lds));
+        mf_lds_grad = dense_lds_bytes(nvec_max, true);
+        mf_lds_loss = dense_lds_bytes(nvec_max, false);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
         mf_ok = true;
       }
     }
@@ -828,6 +819,18 @@ struct SolverT final : cal_solver {
         hipLaunchKernelGGL((fused_group_kernel<T, MODE, false>), dim3(nitems - nitems_simple), dim3(kThreads), lds_group_bytes, stream, a);
     }
   }
+  // the dense pass: panels with more than four vector tiles (kernel instance with eight accumulator tiles per wave), then the rest
+  template <bool GRAD> void launch_dense(MfmaArgs m) {
+    const size_t lds = GRAD ? mf_lds_grad : mf_lds_loss;
+    if (mf_split > 0) {
+      m.panel_base = 0;
+      hipLaunchKernelGGL((fused_dense_kernel<GRAD, 8>), dim3(mf_split), dim3(kDenseThreads), lds, stream, m);
+    }
+    if (mf_npanels > mf_split) {
+      m.panel_base = mf_split;
+      hipLaunchKernelGGL((fused_dense_kernel<GRAD, 4>), dim3(mf_npanels - mf_split), dim3(kDenseThreads), lds, stream, m);
+    }
+  }
   T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
   T* grad_c1() { return gc_direct ? gcp1.as<T>() : gc1.as<T>(); }
 
@@ -875,7 +878,7 @@ struct SolverT final : cal_solver {
         m.nbls = nbls;
         m.use_alpha = 0;
         if (two_pass) {
-          hipLaunchKernelGGL(fused_mfma_ws_kernel<false>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
+          launch_dense<false>(m);
           hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                              ant_ptr.as<int>(), ant_ent.as<int2>(), comm.as<T2>(), comm.as<T2>(), comm.as<T2>(), 0, fpad, part.as<double>(),
                              mf_npanels, scal.as<double>(), st);
@@ -883,10 +886,7 @@ struct SolverT final : cal_solver {
           hipLaunchKernelGGL(alpha_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>());
           m.use_alpha = 1;
         }
-        if (grads)
-          hipLaunchKernelGGL(fused_mfma_ws_kernel<true>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
-        else
-          hipLaunchKernelGGL(fused_mfma_ws_kernel<false>, dim3(mf_npanels), dim3(kWsThreads), mf_ws_lds, stream, m);
+        if (grads) launch_dense<true>(m); else launch_dense<false>(m);
       }
     } else {
       if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
@@ -1166,10 +1166,10 @@ struct SolverT final : cal_solver {
 // ================================================================================================================
 extern "C" {
 
-#ifdef CAL_WS_STAMP
-int cal_debug_read_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(calk::g_ws_stamps), sizeof(calk::g_ws_stamps)); }
-#endif
 
+#ifdef CAL_STAMP
+int cal_debug_read_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(calk::g_dense_stamps), sizeof(calk::g_dense_stamps)); }
+#endif
 const char* cal_last_error(void) { return g_err.c_str(); }
 const char* cal_version(void) { return "calamity_hip 0.1 (gfx950)"; }
 
