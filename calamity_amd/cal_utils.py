@@ -1,5 +1,6 @@
 """Unity-gain UVCal from UVData and gain application -- behaviour of /root/reference/calamity/cal_utils.py:7-105,
-written against the duck-typed attribute surface (works with pyuvdata objects of the spw-axis vintage and with
+written against the duck-typed attribute surface (works with pyuvdata objects of either array vintage -- with or
+without the length-1 spw axis -- and with
 calamity_amd.uvcompat containers).  Host-side NumPy; nothing here is on the GPU hot path."""
 import copy
 
@@ -43,7 +44,11 @@ def blank_uvcal_from_uvdata(uvdata):
     uvcal.integration_time = np.mean(uvdata.integration_time)
     uvcal.lst_array = np.unique(uvdata.lst_array)
     uvcal.gain_convention = "divide"  # always "divide" (cal_utils.py:43)
-    shape = (len(uvcal.ant_array), uvcal.Nspws, uvcal.Nfreqs, uvcal.Ntimes, uvcal.Njones)
+    # the gain arrays take the vintage of the data: with or without the length-1 spw axis
+    if np.ndim(uvdata.data_array) == 4:
+        shape = (len(uvcal.ant_array), uvcal.Nspws, uvcal.Nfreqs, uvcal.Ntimes, uvcal.Njones)
+    else:
+        shape = (len(uvcal.ant_array), uvcal.Nfreqs, uvcal.Ntimes, uvcal.Njones)
     uvcal.flag_array = np.zeros(shape, dtype=bool)
     uvcal.quality_array = np.zeros(shape, dtype=np.float64)
     uvcal.x_orientation = uvdata.x_orientation
@@ -68,14 +73,13 @@ def apply_gains(uvdata, gains, inverse=False):
     gt = np.asarray([tmap[t] for t in calibrated.time_array.tolist()])
     for pnum, pol in enumerate(uvdata.get_pols()):
         gindp = np.where(np.asarray(gains.jones_array) == uvcompat.polstr2num(pol, x_orientation=gains.x_orientation))[0][0]
-        g0 = gains.gain_array[a0, 0, :, gt, gindp]  # (Nblts, Nfreqs)
-        g1 = gains.gain_array[a1, 0, :, gt, gindp]
+        g0 = uvcompat.gain4(gains.gain_array)[a0, :, gt, gindp]  # (Nblts, Nfreqs)
+        g1 = uvcompat.gain4(gains.gain_array)[a1, :, gt, gindp]
         gg = g0 * np.conj(g1)
+        data, flags, gflags = uvcompat.vis3(calibrated.data_array), uvcompat.vis3(calibrated.flag_array), uvcompat.gain4(gains.flag_array)
         if not inverse:
-            calibrated.data_array[:, 0, :, pnum] = calibrated.data_array[:, 0, :, pnum] / gg
+            data[:, :, pnum] = data[:, :, pnum] / gg
         else:
-            calibrated.data_array[:, 0, :, pnum] = calibrated.data_array[:, 0, :, pnum] * gg
-        calibrated.flag_array[:, 0, :, pnum] = calibrated.flag_array[:, 0, :, pnum] | (
-            gains.flag_array[a0, 0, :, gt, gindp] | gains.flag_array[a1, 0, :, gt, gindp]
-        )
+            data[:, :, pnum] = data[:, :, pnum] * gg
+        flags[:, :, pnum] = flags[:, :, pnum] | (gflags[a0, :, gt, gindp] | gflags[a1, :, gt, gindp])
     return calibrated

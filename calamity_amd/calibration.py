@@ -28,7 +28,7 @@ from . import cal_utils, modeling, utils
 from .problem import FitProblem, coeffs_from_chunks, coeffs_to_chunks, problem_from_chunks
 from .solver import OPTIMIZERS, HipFitSolver
 from .utils import PBARS, echo
-from .uvcompat import is_uvcal, is_uvdata, polstr2num
+from .uvcompat import freqs_1d, gain4, is_uvcal, is_uvdata, polstr2num, vis3
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -188,16 +188,16 @@ def tensorize_data(
         if any_conj and len(pind_conj) == 0:
             raise KeyError(f"polarization {polarization}: the conjugate product is not in the data")
         pcol = np.where(conj, int(pind_conj[0]) if len(pind_conj) else pind, pind)
-        data = np.asarray(uvdata.data_array)[rows, 0, :, pcol] / data_scale_factor
-        iflags = ~np.asarray(uvdata.flag_array)[rows, 0, :, pcol]
+        data = vis3(np.asarray(uvdata.data_array))[rows, :, pcol] / data_scale_factor
+        iflags = ~vis3(np.asarray(uvdata.flag_array))[rows, :, pcol]
         if any_conj:
             data = np.where(conj[:, None], np.conj(data), data)
         if weights is None:
             w = iflags.astype(dtype)
         else:
-            w = np.asarray(weights.weights_array)[wrows, 0, :, wpol].astype(dtype) * iflags
+            w = vis3(np.asarray(weights.weights_array))[wrows, :, wpol].astype(dtype) * iflags
         if nsamples_in_weights:
-            w = w * np.asarray(uvdata.nsample_array)[rows, 0, :, pcol]
+            w = w * vis3(np.asarray(uvdata.nsample_array))[rows, :, pcol]
         w = np.ascontiguousarray(w, dtype=dtype).reshape(ngrps, nbls, uvdata.Nfreqs)
         wgtsum += float(np.sum(w, dtype=np.float64))
         data_r.append(np.ascontiguousarray(data.real, dtype=dtype).reshape(ngrps, nbls, uvdata.Nfreqs))
@@ -211,7 +211,7 @@ def tensorize_gains(uvcal, polarization, time, dtype=np.float32):
     """UVCal -> ``(Nants, Nfreqs)`` real and imaginary gain arrays -- calibration.py:369-399."""
     polnum = np.where(np.asarray(uvcal.jones_array) == polstr2num(polarization, x_orientation=uvcal.x_orientation))[0][0]
     gindt = np.where(np.isclose(uvcal.time_array, time, atol=1e-7, rtol=0.0))[0][0]
-    g = uvcal.gain_array[:, 0, :, gindt, polnum]
+    g = gain4(uvcal.gain_array)[:, :, gindt, polnum]
     return np.ascontiguousarray(g.real, dtype=dtype), np.ascontiguousarray(g.imag, dtype=dtype)
 
 
@@ -220,20 +220,20 @@ def renormalize(uvdata_reference_model, uvdata_deconv, gains, polarization, time
     computed by the reference but deliberately not applied, :359).  Modifies ``uvdata_deconv`` and ``gains``."""
     polnum_data = np.where(uvdata_deconv.polarization_array == polstr2num(polarization, x_orientation=uvdata_deconv.x_orientation))[0][0]
     bltsel = np.isclose(uvdata_deconv.time_array, time, atol=1e-7, rtol=0.0)
-    selection = ~uvdata_deconv.flag_array[bltsel, :, :, polnum_data] & ~uvdata_reference_model.flag_array[bltsel, :, :, polnum_data]
+    selection = ~uvdata_deconv.flag_array[bltsel, ..., polnum_data] & ~uvdata_reference_model.flag_array[bltsel, ..., polnum_data]
     if additional_flags is not None:
-        selection = selection & ~additional_flags[bltsel, :, :, polnum_data]
+        selection = selection & ~additional_flags[bltsel, ..., polnum_data]
     with np.errstate(divide="ignore", invalid="ignore"):
         data_ratio = (
-            uvdata_reference_model.data_array[bltsel, :, :, polnum_data][selection]
-            / uvdata_deconv.data_array[bltsel, :, :, polnum_data][selection]
+            uvdata_reference_model.data_array[bltsel, ..., polnum_data][selection]
+            / uvdata_deconv.data_array[bltsel, ..., polnum_data][selection]
         )
     data_ratio[~np.isfinite(data_ratio)] = np.nan
     scale_factor = np.sqrt(np.nanmean(np.abs(data_ratio) ** 2.0))
-    uvdata_deconv.data_array[bltsel, :, :, polnum_data] *= scale_factor
+    uvdata_deconv.data_array[bltsel, ..., polnum_data] *= scale_factor
     polnum_gains = np.where(np.asarray(gains.jones_array) == polstr2num(polarization, x_orientation=uvdata_deconv.x_orientation))[0][0]
     gindt = np.where(np.isclose(gains.time_array, time, atol=1e-7, rtol=0.0))[0][0]
-    gains.gain_array[:, :, :, gindt, polnum_gains] *= (scale_factor) ** -0.5
+    gains.gain_array[..., gindt, polnum_gains] *= (scale_factor) ** -0.5
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -459,14 +459,14 @@ def insert_model_into_uvdata_tensor(uvdata, time, polarization, ants_map, red_gr
             else:
                 dind = _time_ind(uvdata.time_array, uvdata.antpair2ind(ap[::-1]), time)
                 model = model_r[i, j] - 1j * model_i[i, j]
-            uvdata.data_array[dind, 0, :, polnum] = model * scale_factor
+            vis3(uvdata.data_array)[dind, :, polnum] = model * scale_factor
 
 
 def insert_gains_into_uvcal(uvcal, time, polarization, gains_re, gains_im):
     """Insert ``(Nants, Nfreqs)`` gain arrays back into a UVCal object -- calibration.py:798-825."""
     polnum = np.where(np.asarray(uvcal.jones_array) == polstr2num(polarization, x_orientation=uvcal.x_orientation))[0][0]
     gindt = np.where(np.isclose(uvcal.time_array, time, atol=1e-7, rtol=0.0))[0][0]
-    uvcal.gain_array[:, 0, :, gindt, polnum] = np.asarray(gains_re) + 1j * np.asarray(gains_im)
+    gain4(uvcal.gain_array)[:, :, gindt, polnum] = np.asarray(gains_re) + 1j * np.asarray(gains_im)
 
 
 def flag_poltime(data_object, time, polarization):
@@ -474,13 +474,13 @@ def flag_poltime(data_object, time, polarization):
     if is_uvdata(data_object):
         bltsel = np.isclose(data_object.time_array, time, atol=1e-7, rtol=0.0)
         polnum = np.where(data_object.polarization_array == polstr2num(polarization, x_orientation=data_object.x_orientation))[0][0]
-        data_object.flag_array[bltsel, :, :, polnum] = True
-        data_object.data_array[bltsel, :, :, polnum] = 0.0
+        data_object.flag_array[bltsel, ..., polnum] = True
+        data_object.data_array[bltsel, ..., polnum] = 0.0
     elif is_uvcal(data_object):
         polnum = np.where(np.asarray(data_object.jones_array) == polstr2num(polarization, x_orientation=data_object.x_orientation))[0][0]
         gindt = np.where(np.isclose(data_object.time_array, time, atol=1e-7, rtol=0.0))[0][0]
-        data_object.gain_array[:, 0, :, gindt, polnum] = 1.0
-        data_object.flag_array[:, 0, :, gindt, polnum] = True
+        gain4(data_object.gain_array)[:, :, gindt, polnum] = 1.0
+        gain4(data_object.flag_array)[:, :, gindt, polnum] = True
     else:
         raise ValueError("only supports data_object that is UVCal or UVData.")
 
@@ -577,9 +577,9 @@ def calibrate_and_model_tensor(
         g_r, g_i, fg_r, fg_i = carry.get("g_r"), carry.get("g_i"), carry.get("fg_r"), carry.get("fg_i")
         echo(f"{datetime.datetime.now()} Working on time {time_index + 1} of {uvdata.Ntimes}...\n", verbose=verbose)
         bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
-        frac_unflagged = np.count_nonzero(~uvdata.flag_array[bltsel, 0, :, polnum]) / (uvdata.Nbls * uvdata.Nfreqs)
+        frac_unflagged = np.count_nonzero(~vis3(uvdata.flag_array)[bltsel, :, polnum]) / (uvdata.Nbls * uvdata.Nfreqs)
         if frac_unflagged >= skip_threshold:
-            rmsdata = np.sqrt(np.mean(np.abs(uvdata.data_array[bltsel, 0, :, polnum][~uvdata.flag_array[bltsel, 0, :, polnum]]) ** 2.0))
+            rmsdata = np.sqrt(np.mean(np.abs(vis3(uvdata.data_array)[bltsel, :, polnum][~vis3(uvdata.flag_array)[bltsel, :, polnum]]) ** 2.0))
             echo(f"{datetime.datetime.now()} Tensorizing data...\n", verbose=verbose)
             data_r, data_i, wgts = tensorize_data(
                 uvdata, corr_inds=corr_inds, ants_map=ants_map, polarization=pol, time=time, data_scale_factor=rmsdata,
@@ -690,7 +690,7 @@ def _insert_model_rows(uvdata, time, polarization, ants_map, prob, m_r, m_i, sca
             r = row_of[ap[::-1]]
             sign[b] = -1.0
         rows[b] = r
-    uvdata.data_array[rows, 0, :, polnum] = (np.asarray(m_r) + 1j * sign[:, None] * np.asarray(m_i)) * scale_factor
+    vis3(uvdata.data_array)[rows, :, polnum] = (np.asarray(m_r) + 1j * sign[:, None] * np.asarray(m_i)) * scale_factor
 
 
 def calibrate_and_model_dpss(
@@ -801,7 +801,7 @@ def get_auto_weights(uvdata, delay_extent=25.0):
         smooth_weights = smooth_weights * ~np.atleast_2d(uvdata.get_flags(bl))
         dinds = data_weights.antpair2ind(*bl[:2])
         polnum = np.where(data_weights.polarization_array == polstr2num(bl[-1], x_orientation=data_weights.x_orientation))[0][0]
-        data_weights.weights_array[dinds, 0, :, polnum] = smooth_weights
+        vis3(data_weights.weights_array)[dinds, :, polnum] = smooth_weights
     return data_weights
 
 
@@ -907,8 +907,9 @@ def input_output_parser():
     sp.add_argument("--resid_outfilename", type=str, default=None, help="where to write the residual visibilities")
     sp.add_argument("--model_outfilename", type=str, default=None, help="where to write the foreground model")
     sp.add_argument("--gain_outfilename", type=str, default=None, help="where to write the fitted gains")
-    # the reference's default is the string "False" (truthy), :1831 -- kept
-    sp.add_argument("--clobber", action="store_true", default="False", help="replace existing output files")
+    # (the reference's default is the STRING "False", which is truthy, so its CLI always overwrites, :1831; here the flag
+    # means what it says)
+    sp.add_argument("--clobber", action="store_true", default=False, help="replace existing output files")
     sp.add_argument("--x_orientation", default="east", type=str, help="x_orientation recorded in the output gains")
     sp.add_argument("--bllen_min", default=0.0, type=float, help="shortest baseline kept [m]")
     sp.add_argument("--bllen_max", default=np.inf, type=float, help="longest baseline kept [m]")

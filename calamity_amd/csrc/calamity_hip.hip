@@ -147,6 +147,9 @@ struct SolverT final : cal_solver {
   int steps_per_sync = 1;                      // train steps enqueued between two host synchronisations of run()
   DevBuf agree_buf;
   DevState* h_state = nullptr;                 // pinned mirror
+  int st_par = 0;                              // which half of `state` is current
+  DevState* st_cur() { return state.as<DevState>() + st_par; }
+  DevState* st_nxt() { return state.as<DevState>() + (st_par ^ 1); }
   // settings
   cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7};
   int reg = CAL_REG_NONE;
@@ -177,7 +180,7 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void**)&h_state, sizeof(DevState), hipHostMallocDefault));
     memset(h_state, 0, sizeof(DevState));
-    CAL_TRY(state.alloc(sizeof(DevState)));
+    CAL_TRY(state.alloc(2 * sizeof(DevState)));  // double-buffered: see step_update_kernel
     CAL_TRY(scal.alloc(4 * sizeof(double)));
     return CAL_OK;
   }
@@ -791,7 +794,7 @@ struct SolverT final : cal_solver {
     a.part = part.as<double>();
     a.model_r = nullptr;
     a.model_i = nullptr;
-    a.state = state.as<DevState>();
+    a.state = st_cur();
     a.fpad = fpad;
     a.nbls = nbls;
     a.runs = runs.as<int2>();
@@ -838,7 +841,7 @@ struct SolverT final : cal_solver {
   int enqueue_pass(bool grads, bool apply_update, int losses_cap) {
     const bool R = reg == CAL_REG_SUM;
     FusedArgs<T> a = fused_args();
-    DevState* st = state.as<DevState>();
+    DevState* st = st_cur();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) {
       if (ev_used == ev_pool.size()) {
@@ -855,6 +858,7 @@ struct SolverT final : cal_solver {
     // dense path; with the "sum" regulariser it runs twice: a loss-only pass yields S (hence alpha = 2 (S - P)), then the
     // gradient pass applies e = -2 w r + alpha w directly -- no second adjoint set, no combine kernels
     const bool use_mfma = mf_ok;
+    const bool Rk = R && !use_mfma;  // the general kernel's two-adjoint-set form of the regulariser
     const bool two_pass = use_mfma && R && grads;
     if (use_mfma) {
       if constexpr (std::is_same<T, float>::value) {
@@ -891,15 +895,15 @@ struct SolverT final : cal_solver {
     } else {
       if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
     }
-    const bool Rk = R && !use_mfma;  // the general kernel's two-adjoint-set form of the regulariser
     const int n_parts = use_mfma ? mf_npanels : nitems;
     if (timing) HIP_TRY(hipEventRecord(e1, stream));
     const size_t gn = (size_t)nants * fpad;
     T2* r0 = comm.as<T2>();
     T2* r1 = r0 + gn;
     T2* r2 = r1 + gn;
+    const bool fused_tail = apply_update && !Rk;  // loop bookkeeping + update (+ partial-gradient sums) in ONE launch: enqueue_update
     if (grads) {
-      if (!gc_direct && !use_mfma) {
+      if (!gc_direct && !use_mfma && !fused_tail) {
         hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
                            gcp0.as<T>() + gcp_len, gc0.as<T>(), gc0.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
                            grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
@@ -932,8 +936,9 @@ struct SolverT final : cal_solver {
       NCCL_TRY(ncclAllReduce(scal.p, scal.p, 4, ncclDouble, ncclSum, nccl, stream));
       NCCL_TRY(ncclGroupEnd());
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>(), losses.as<double>(), losses_cap,
-                       apply_update ? 1 : 0);
+    if (!fused_tail)
+      hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>(), losses.as<double>(), losses_cap,
+                         apply_update ? 1 : 0);
     if (grads && Rk) {
       hipLaunchKernelGGL(combine_gain_kernel<T>, dim3((int)((gn + 255) / 256)), dim3(256), 0, stream, r0, r1, r2, (int)gn, st);
       hipLaunchKernelGGL(combine_coeff_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, grad_c0(), grad_c0() + ncoef,
@@ -943,14 +948,32 @@ struct SolverT final : cal_solver {
     return CAL_OK;
   }
 
-  int enqueue_update(bool freeze_model) {
-    DevState* st = state.as<DevState>();
+  int enqueue_update(bool freeze_model, int losses_cap) {
+    DevState* st = st_cur();
     const long long gn = 2LL * nants * fpad;
     T* gsnap = gains_snap.p ? gains_snap.as<T>() : gains.as<T>();
     T* csnap = coef_snap.p ? coef_snap.as<T>() : coef.as<T>();
     const AdamSet<T> ga{gains.as<T>(), comm.as<T>(), gains_m.as<T>(), gains_v.as<T>(), gsnap, gn};
     const AdamSet<T> ca{coef.as<T>(), grad_c0(), coef_m.as<T>(), coef_v.as<T>(), csnap, freeze_model ? 0LL : 2LL * ncoef};
     const int nblk_a = (int)((ga.n + 255) / 256), nblk_b = (int)((ca.n + 255) / 256);
+    const bool Rk = reg == CAL_REG_SUM && !mf_ok;
+    if (!Rk) {
+      // the common path: finalize + update (+ the partial coefficient-gradient sums of split groups) as one launch
+      PartialSum<T> ps{};
+      if (!gc_direct && !mf_ok && !freeze_model)
+        ps = PartialSum<T>{gcp0.as<T>(), gcp0.as<T>() + gcp_len, coef_grp.as<int>(), grp_coff.as<int>(), grp_item_ptr.as<int>(),
+                           item_goff.as<int>(), ncoef};
+      const unsigned nb = (unsigned)std::max(1, nblk_a + nblk_b);
+      if (opt.optimizer == CAL_OPT_ADAM)
+        hipLaunchKernelGGL((step_update_kernel<T, 0>), dim3(nb), dim3(256), 0, stream, ga, ca, nblk_a, ps, st, st_nxt(), scal.as<double>(),
+                           losses.as<double>(), losses_cap);
+      else
+        hipLaunchKernelGGL((step_update_kernel<T, 1>), dim3(nb), dim3(256), 0, stream, ga, ca, nblk_a, ps, st, st_nxt(), scal.as<double>(),
+                           losses.as<double>(), losses_cap);
+      st_par ^= 1;
+      HIP_TRY(hipGetLastError());
+      return CAL_OK;
+    }
     if (opt.optimizer == CAL_OPT_ADAM)
       hipLaunchKernelGGL((adam2_kernel<T, 0>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st);
     else
@@ -968,11 +991,11 @@ struct SolverT final : cal_solver {
     h_state->f32 = std::is_same<T, float>::value ? 1 : 0;
     h_state->prior_r = prior_r;
     h_state->prior_i = prior_i;
-    HIP_TRY(hipMemcpyAsync(state.p, h_state, sizeof(DevState), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(st_cur(), h_state, sizeof(DevState), hipMemcpyHostToDevice, stream));
     return CAL_OK;
   }
   int pull_state() {
-    HIP_TRY(hipMemcpyAsync(h_state, state.p, sizeof(DevState), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_state, st_cur(), sizeof(DevState), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return CAL_OK;
   }
@@ -1040,7 +1063,7 @@ struct SolverT final : cal_solver {
       const int n = std::min(chunk, r->nsteps - issued);
       for (int s = 0; s < n; ++s) {
         CAL_TRY(enqueue_pass(true, true, r->record ? r->nsteps : 0));
-        CAL_TRY(enqueue_update(r->freeze_model != 0));
+        CAL_TRY(enqueue_update(r->freeze_model != 0, r->record ? r->nsteps : 0));
       }
       issued += n;
       CAL_TRY(pull_state());
@@ -1095,7 +1118,7 @@ struct SolverT final : cal_solver {
     if (!gc_direct)
       hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
                          gcp0.as<T>() + gcp_len, gc0.as<T>(), gc0.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
-                         grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, state.as<DevState>());
+                         grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st_cur());
     HIP_TRY(hipGetLastError());
     // A^T b becomes the coefficient vector (orthonormal-column bases; the host applies the Gram solve otherwise)
     HIP_TRY(hipMemcpyAsync(coef.p, grad_c0(), 2 * (size_t)ncoef * sizeof(T), hipMemcpyDeviceToDevice, stream));

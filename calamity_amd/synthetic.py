@@ -181,13 +181,14 @@ def add_redundant_group(prob, start, rng, nred=3):
 
 
 def make_uvdata(nants=6, nfreqs=64, ntimes=1, f0=100e6, df=400e3, seed=0, eor_db=-50.0, redundant=False, flag_frac=0.0,
-                min_dly=2.0 / 0.3, offset=2.0 / 0.3, extent=60.0):
+                min_dly=2.0 / 0.3, offset=2.0 / 0.3, extent=60.0, future_shapes=False):
     """Small duck-typed UVData sets in the spirit of the reference's test fixtures (test_calibration.py:18-219):
     ``sky_model_projected`` -- smooth foregrounds projected onto each baseline's own DPSS basis, so the model is exactly
     representable (:144-154) -- and ``uvdata`` = projected sky + a flat-spectrum component ``eor_db`` below it
-    (:183-193).  Returns (uvdata, sky_model_projected, dpss_vectors)."""
+    (:183-193).  ``future_shapes``: arrays in the pyuvdata >= 3 layout (no spw axis).
+    Returns (uvdata, sky_model_projected, dpss_vectors)."""
     from . import modeling
-    from .uvcompat import SimpleUVData
+    from .uvcompat import SimpleUVData, vis3
 
     rng = np.random.default_rng(seed)
     if redundant:
@@ -197,7 +198,8 @@ def make_uvdata(nants=6, nfreqs=64, ntimes=1, f0=100e6, df=400e3, seed=0, eor_db
     freqs = f0 + df * np.arange(nfreqs)
     times = 2458000.0 + 2.0 * np.arange(ntimes)
     antpairs = [(i, j) for i in range(nants) for j in range(i + 1, nants)]
-    sky = SimpleUVData(antpos, antpairs, freqs, times)
+    sky = SimpleUVData(antpos, antpairs, freqs, times, future_shapes=future_shapes)
+    sky_vis = vis3(sky.data_array)  # (Nblts, Nfreqs, Npols) view for either layout
     # smooth-spectrum point sources: visibilities confined to the baseline's horizon delay
     nsrc = 12
     lmn = rng.uniform(-0.7, 0.7, size=(nsrc, 2))
@@ -205,13 +207,13 @@ def make_uvdata(nants=6, nfreqs=64, ntimes=1, f0=100e6, df=400e3, seed=0, eor_db
     for n in range(sky.Nblts):
         bvec = antpos[sky.ant_2_array[n]] - antpos[sky.ant_1_array[n]]
         tau = (lmn @ bvec[:2]) / 299792458.0
-        sky.data_array[n, 0, :, 0] = np.sum(flux * np.exp(-2j * np.pi * tau[:, None] * freqs[None, :]), axis=0)
+        sky_vis[n, :, 0] = np.sum(flux * np.exp(-2j * np.pi * tau[:, None] * freqs[None, :]), axis=0)
     dpss_vectors = modeling.yield_pbl_dpss_model_comps(sky, offset=offset, min_dly=min_dly)
     for ap in sky.get_antpairs():
         dinds = sky.antpair2ind(ap)
         key = ((ap,),) if ((ap,),) in dpss_vectors else ((ap[::-1],),)
         A = dpss_vectors[key]
-        sky.data_array[dinds, 0, :, 0] = (A @ (sky.data_array[dinds, 0, :, 0] @ A).T).T
+        sky_vis[dinds, :, 0] = (A @ (sky_vis[dinds, :, 0] @ A).T).T
     uvd = copy_uvdata(sky)
     amp = np.sqrt(np.mean(np.abs(sky.data_array) ** 2)) * 10.0 ** (eor_db / 20.0)
     uvd.data_array = uvd.data_array + amp * (rng.standard_normal(uvd.data_array.shape) + 1j * rng.standard_normal(uvd.data_array.shape)) / np.sqrt(2)

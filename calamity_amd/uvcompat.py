@@ -2,9 +2,10 @@
 
 pyuvdata is not installable in the build environment, so the drop-in entry points
 (``calamity_amd.calibration.calibrate_and_model_dpss`` etc.) are written against the *attribute surface* the
-reference touches (old pyuvdata >= 2.1.5 shapes WITH the spw axis:
-``data_array[Nblts, 1, Nfreqs, Npols]``, ``gain_array[Nants, 1, Nfreqs, Ntimes, Njones]``).  Real pyuvdata objects
-of that vintage duck-type into the same code; these classes implement exactly that surface for tests, the
+reference touches.  Both array vintages are accepted everywhere, by shape: old pyuvdata
+(>= 2.1.5) WITH the spw axis (``data_array[Nblts, 1, Nfreqs, Npols]``, ``gain_array[Nants, 1, Nfreqs, Ntimes, Njones]``,
+the one the reference indexes) and pyuvdata >= 3 without it (``vis3`` / ``gain4`` / ``freqs_1d`` below).  Real pyuvdata
+objects duck-type into the same code; these classes implement exactly that surface for tests, the
 synthetic generator and users without pyuvdata.  They are containers, not a re-implementation of pyuvdata.
 """
 import copy
@@ -33,6 +34,22 @@ def polnum2str(num, x_orientation=None):
     return POLNUM2STR[int(num)]
 
 
+def vis3(arr):
+    """UVData-like array -> view (Nblts, Nfreqs, Npols): old pyuvdata (>= 2.1.5) carries a length-1 spw axis
+    (Nblts, 1, Nfreqs, Npols), pyuvdata >= 3 ("future array shapes") does not.  A view: assignments reach the object."""
+    return arr[:, 0] if np.ndim(arr) == 4 else arr
+
+
+def gain4(arr):
+    """UVCal-like array -> view (Nants, Nfreqs, Ntimes, Njones), with or without the length-1 spw axis."""
+    return arr[:, 0] if np.ndim(arr) == 5 else arr
+
+
+def freqs_1d(obj):
+    f = np.asarray(obj.freq_array)
+    return f[0] if f.ndim == 2 else f
+
+
 def antnums_to_baseline(a1, a2):
     return 2048 * (int(a1) + 1) + (int(a2) + 1) + 2 ** 16
 
@@ -46,7 +63,7 @@ class SimpleUVData:
     """Container with the UVData attributes and methods the calamity path uses."""
 
     def __init__(self, antpos, antpairs, freqs, times, pols=(-5,), data=None, flags=None, nsamples=None, antnums=None,
-                 x_orientation=None):
+                 x_orientation=None, future_shapes=False):
         antpos = np.asarray(antpos, dtype=np.float64)
         self.antenna_numbers = np.arange(len(antpos)) if antnums is None else np.asarray(antnums)
         self.antenna_positions = antpos  # ENU, metres (pyuvdata stores ECEF; only differences are used here)
@@ -65,15 +82,19 @@ class SimpleUVData:
         self.time_array = np.repeat(times, self.Nbls)
         self.lst_array = np.repeat(np.linspace(0.0, 1e-3, self.Ntimes, endpoint=False) if self.Ntimes > 1 else np.zeros(1), self.Nbls)
         self.integration_time = np.full(self.Nblts, 10.0)
-        self.freq_array = np.asarray(freqs, dtype=np.float64)[None, :]
-        self.Nfreqs = self.freq_array.shape[1]
+        # future_shapes: the array layout of pyuvdata >= 3 (no spw axis, 1-D freq_array); default: the layout the
+        # reference was written against
+        self.future_array_shapes = bool(future_shapes)
+        f1 = np.asarray(freqs, dtype=np.float64)
+        self.freq_array = f1.copy() if future_shapes else f1[None, :]
+        self.Nfreqs = len(f1)
         self.Nspws = 1
         self.spw_array = np.array([0])
-        self.channel_width = float(np.median(np.diff(self.freq_array[0]))) if self.Nfreqs > 1 else 1.0
+        self.channel_width = float(np.median(np.diff(f1))) if self.Nfreqs > 1 else 1.0
         self.polarization_array = np.asarray(pols, dtype=int)
         self.Npols = len(self.polarization_array)
         self.x_orientation = x_orientation
-        shape = (self.Nblts, 1, self.Nfreqs, self.Npols)
+        shape = (self.Nblts, self.Nfreqs, self.Npols) if future_shapes else (self.Nblts, 1, self.Nfreqs, self.Npols)
         self.data_array = np.zeros(shape, dtype=np.complex128) if data is None else np.asarray(data, dtype=np.complex128).reshape(shape)
         self.flag_array = np.zeros(shape, dtype=bool) if flags is None else np.asarray(flags, dtype=bool).reshape(shape)
         self.nsample_array = np.ones(shape, dtype=np.float64) if nsamples is None else np.asarray(nsamples, dtype=np.float64).reshape(shape)
@@ -121,14 +142,14 @@ class SimpleUVData:
     def get_data(self, key):
         i1, i2, (pi, pc) = self._key2inds(key)
         if len(i1):
-            return self.data_array[i1, 0, :, pi[0]]
-        return np.conj(self.data_array[i2, 0, :, pc[0]])
+            return vis3(self.data_array)[i1, :, pi[0]]
+        return np.conj(vis3(self.data_array)[i2, :, pc[0]])
 
     def get_flags(self, key):
         i1, i2, (pi, pc) = self._key2inds(key)
         if len(i1):
-            return self.flag_array[i1, 0, :, pi[0]]
-        return self.flag_array[i2, 0, :, pc[0]]
+            return vis3(self.flag_array)[i1, :, pi[0]]
+        return vis3(self.flag_array)[i2, :, pc[0]]
 
     def baseline_to_antnums(self, bl):
         return baseline_to_antnums(bl)
@@ -217,13 +238,14 @@ class SimpleUVCal:
 
     def __add__(self, other):
         out = copy.deepcopy(self)
+        tax = np.ndim(self.gain_array) - 2  # the time axis: 3 with the spw axis, 2 without
         for name in ("gain_array", "flag_array", "quality_array"):
-            setattr(out, name, np.concatenate([getattr(self, name), getattr(other, name)], axis=3))
+            setattr(out, name, np.concatenate([getattr(self, name), getattr(other, name)], axis=tax))
         out.time_array = np.concatenate([self.time_array, other.time_array])
         order = np.argsort(out.time_array)
         out.time_array = out.time_array[order]
         for name in ("gain_array", "flag_array", "quality_array"):
-            setattr(out, name, getattr(out, name)[:, :, :, order])
+            setattr(out, name, np.take(getattr(out, name), order, axis=tax))
         out.Ntimes = len(out.time_array)
         return out
 
@@ -251,28 +273,59 @@ class SimpleUVFlag:
         return self._ap_index.get((int(ap[0]), int(ap[1])), np.asarray([], dtype=int))
 
 
-def _write_pickle(obj, path, clobber):
+_KINDS = {}  # kind tag -> container class (filled below)
+
+
+def _write_container(obj, path, clobber, kind):
+    """Store a duck-typed container as an .npz archive (arrays as arrays, everything else as one JSON string) under
+    exactly the given name.  No pickle: reading one of these files can never execute code."""
+    import json
     import os
-    import pickle
 
     if os.path.exists(path) and not clobber:
         raise IOError(f"{path} exists; use clobber=True to overwrite")
-    with open(path, "wb") as f:
-        pickle.dump(obj, f, protocol=4)
+    arrays, meta = {}, {}
+    for k, v in obj.__dict__.items():
+        if k.startswith("_"):
+            continue  # derived (rebuilt on read)
+        if isinstance(v, np.ndarray):
+            arrays[k] = v
+        elif isinstance(v, (np.integer, np.floating, np.bool_)):
+            meta[k] = v.item()
+        elif isinstance(v, tuple):
+            meta[k] = [x.item() if isinstance(x, np.generic) else x for x in v]
+        else:
+            meta[k] = v
+    with open(path, "wb") as f:  # a file object: np.savez would append ".npz" to a bare name
+        np.savez(f, __kind__=np.asarray(kind), __meta__=np.asarray(json.dumps(meta)), **arrays)
 
 
 def read_container(path):
-    """Read a container written by ``SimpleUVData.write_uvh5`` / ``SimpleUVCal.write_calfits``."""
-    import pickle
+    """Read a container written by ``SimpleUVData.write_uvh5`` / ``SimpleUVCal.write_calfits`` (an .npz archive whatever
+    its name; real uvh5 / calfits files need pyuvdata and are rejected here with a clear message)."""
+    import json
 
-    with open(path, "rb") as f:
-        return pickle.load(f)
+    try:
+        z = np.load(path, allow_pickle=False)
+        kind = str(z["__kind__"])
+    except Exception as e:  # not one of our archives (e.g. a real HDF5 / FITS file)
+        raise IOError(f"{path} is not a calamity_amd container archive; reading uvh5 / calfits files needs pyuvdata ({e})")
+    obj = object.__new__(_KINDS[kind])
+    for k, v in json.loads(str(z["__meta__"])).items():
+        setattr(obj, k, v)
+    for k in z.files:
+        if not k.startswith("__"):
+            setattr(obj, k, z[k])
+    if hasattr(obj, "_refresh"):
+        obj._refresh()
+    return obj
 
 
 # The file driver (calibration.py:1659-1817) writes its outputs with these method names.  The duck-typed containers
-# store themselves as pickles under whatever name they are given; real uvh5 / calfits I/O needs pyuvdata objects.
-SimpleUVData.write_uvh5 = lambda self, path, clobber=False: _write_pickle(self, path, clobber)
-SimpleUVCal.write_calfits = lambda self, path, clobber=False: _write_pickle(self, path, clobber)
+# store themselves as .npz archives under whatever name they are given; real uvh5 / calfits I/O needs pyuvdata objects.
+SimpleUVData.write_uvh5 = lambda self, path, clobber=False: _write_container(self, path, clobber, "uvdata")
+SimpleUVCal.write_calfits = lambda self, path, clobber=False: _write_container(self, path, clobber, "uvcal")
+_KINDS.update(uvdata=SimpleUVData, uvcal=SimpleUVCal)
 
 
 def is_uvdata(obj):

@@ -13,9 +13,10 @@ from calamity_amd import _lib, cal_utils, calibration, modeling, problem, synthe
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def sets():
-    uvd, sky, vecs = synthetic.make_uvdata(nants=6, nfreqs=48, ntimes=2, seed=1)
+@pytest.fixture(scope="module", params=[False, True], ids=["spw_axis", "future_shapes"])
+def sets(request):
+    """Both pyuvdata array vintages: with the length-1 spw axis and without (pyuvdata >= 3)."""
+    uvd, sky, vecs = synthetic.make_uvdata(nants=6, nfreqs=48, ntimes=2, seed=1, future_shapes=request.param)
     return uvd, sky, vecs
 
 
@@ -121,7 +122,7 @@ def test_tensorize_gains(gains):
     for i, ant in enumerate(gains.ant_array):
         assert np.allclose(g_r[ant], ant + 1) and np.allclose(g_i[ant], 0.0)
     calibration.insert_gains_into_uvcal(gains, gains.time_array[1], "xx", 2 * g_r, g_i + 1)
-    assert np.allclose(gains.gain_array[:, 0, :, 1, 0], 2 * g_r + 1j * (g_i + 1))
+    assert np.allclose(uvcompat.gain4(gains.gain_array)[:, :, 1, 0], 2 * g_r + 1j * (g_i + 1))
 
 
 def test_tensorize_data_weights_and_conjugation(sets, gains):
@@ -129,7 +130,7 @@ def test_tensorize_data_weights_and_conjugation(sets, gains):
     ants_map = {ant: i for i, ant in enumerate(gains.ant_array)}
     comps, corr_inds = calibration.tensorize_fg_model_comps_dict(vecs, ants_map, nfreqs=sky.Nfreqs)
     sky = copy.deepcopy(sky)
-    sky.flag_array[3, 0, 5:9, 0] = True
+    uvcompat.vis3(sky.flag_array)[3, 5:9, 0] = True
     sky.nsample_array[:] = 2.0
     t0 = np.unique(sky.time_array)[0]
     d_r, d_i, w = calibration.tensorize_data(sky, corr_inds, ants_map, "xx", t0, data_scale_factor=3.0, dtype=np.float64)
@@ -144,15 +145,15 @@ def test_tensorize_data_weights_and_conjugation(sets, gains):
         inds = sky.antpair2ind((a, b))
         rev_order = len(inds) == 0  # the redundancy finder orients pairs east-positive; the data may hold (b, a)
         n = calibration._time_ind(sky.time_array, sky.antpair2ind((b, a)) if rev_order else inds, t0)
-        row = np.conj(sky.data_array[n, 0, :, 0]) if rev_order else sky.data_array[n, 0, :, 0]
+        row = np.conj(uvcompat.vis3(sky.data_array)[n, :, 0]) if rev_order else uvcompat.vis3(sky.data_array)[n, :, 0]
         assert np.allclose(d_r[0][g, 0] + 1j * d_i[0][g, 0], row / 3.0)
-        assert np.all((w[0][g, 0] == 0) == sky.flag_array[n, 0, :, 0])
+        assert np.all((w[0][g, 0] == 0) == uvcompat.vis3(sky.flag_array)[n, :, 0])
     # nsamples weights: the same after normalisation when nsamples is uniform
     _, _, w2 = calibration.tensorize_data(sky, corr_inds, ants_map, "xx", t0, nsamples_in_weights=True, dtype=np.float64)
     assert np.allclose(w2[0], w[0])
     # a pair stored in reversed order is conjugated (calibration.py:263-278)
-    rev = uvcompat.SimpleUVData(sky.antenna_positions, [ap[::-1] for ap in sky.get_antpairs()], sky.freq_array[0], np.unique(sky.time_array),
-                                data=np.conj(sky.data_array), flags=sky.flag_array)
+    rev = uvcompat.SimpleUVData(sky.antenna_positions, [ap[::-1] for ap in sky.get_antpairs()], uvcompat.freqs_1d(sky), np.unique(sky.time_array),
+                                data=np.conj(sky.data_array), flags=sky.flag_array, future_shapes=sky.future_array_shapes)
     r_r, r_i, _ = calibration.tensorize_data(rev, corr_inds, ants_map, "xx", t0, data_scale_factor=3.0, dtype=np.float64)
     assert np.allclose(r_r[0], d_r[0]) and np.allclose(r_i[0], d_i[0])
     # UVFlag-style weights
@@ -177,7 +178,7 @@ def test_insert_model_round_trip(sets, gains):
             inds = sky.antpair2ind(ap)
             conj = len(inds) == 0
             n = calibration._time_ind(sky.time_array, sky.antpair2ind(ap[::-1]) if conj else inds, t0)
-            row = np.conj(sky.data_array[n, 0, :, 0]) if conj else sky.data_array[n, 0, :, 0]
+            row = np.conj(uvcompat.vis3(sky.data_array)[n, :, 0]) if conj else uvcompat.vis3(sky.data_array)[n, :, 0]
             model_r[i, j], model_i[i, j] = row.real / 7.0, row.imag / 7.0
     inserted = copy.deepcopy(sky)
     rng = np.random.default_rng(0)
@@ -208,8 +209,8 @@ def test_flag_poltime(sets, gains):
     sel = np.isclose(uvd.time_array, t, rtol=0.0, atol=1e-7)
     assert np.all(uvd.flag_array[sel]) and not np.any(uvd.flag_array[~sel]) and np.all(uvd.data_array[sel] == 0)
     calibration.flag_poltime(gains, time=t, polarization="xx")
-    assert np.all(gains.flag_array[:, :, :, 1]) and not np.any(gains.flag_array[:, :, :, 0])
-    assert np.all(gains.gain_array[:, :, :, 1] == 1.0)
+    assert np.all(uvcompat.gain4(gains.flag_array)[:, :, 1]) and not np.any(uvcompat.gain4(gains.flag_array)[:, :, 0])
+    assert np.all(uvcompat.gain4(gains.gain_array)[:, :, 1] == 1.0)
     with pytest.raises(ValueError):
         calibration.flag_poltime(np.zeros(3), time=t, polarization="xx")
 
@@ -223,13 +224,13 @@ def test_apply_gains_round_trip(sets, gains):
     assert np.allclose(back.data_array, uvd.data_array) and not np.allclose(cal.data_array, uvd.data_array)
     n = 4
     a0, a1 = uvd.ant_1_array[n], uvd.ant_2_array[n]
-    expect = uvd.data_array[n, 0, :, 0] / (gains.gain_array[a0, 0, :, 0, 0] * np.conj(gains.gain_array[a1, 0, :, 0, 0]))
-    assert np.allclose(cal.data_array[n, 0, :, 0], expect)
-    gains.flag_array[2, 0, 7, 0, 0] = True
-    fl = cal_utils.apply_gains(uvd, gains).flag_array
+    expect = uvcompat.vis3(uvd.data_array)[n, :, 0] / (uvcompat.gain4(gains.gain_array)[a0, :, 0, 0] * np.conj(uvcompat.gain4(gains.gain_array)[a1, :, 0, 0]))
+    assert np.allclose(uvcompat.vis3(cal.data_array)[n, :, 0], expect)
+    uvcompat.gain4(gains.flag_array)[2, 7, 0, 0] = True
+    fl = uvcompat.vis3(cal_utils.apply_gains(uvd, gains).flag_array)
     touched = (uvd.ant_1_array == 2) | (uvd.ant_2_array == 2)
     t0 = np.isclose(uvd.time_array, gains.time_array[0], rtol=0.0, atol=1e-7)
-    assert np.all(fl[touched & t0, 0, 7, 0]) and not np.any(fl[~touched, 0, 7, 0])
+    assert np.all(fl[touched & t0, 7, 0]) and not np.any(fl[~touched, 7, 0])
 
 
 def test_unknown_optimizer_is_a_keyerror():
