@@ -63,7 +63,23 @@ def host_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return dict(cpu_model=model, cpu_count=os.cpu_count(), usable_cores=usable)
+    # the CPU time this process is actually allowed: the cgroup quota (a GPU box hands one GPU's job 16 of the host's cores
+    # while nproc still shows all of them; 256 OpenMP threads on such a share ran 13x slower than 16)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(float(q) / float(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(round(q / per)))
+        except (OSError, ValueError):
+            pass
+    share = quota if quota is not None else min(usable, 16)  # no quota visible: the documented share of a one-GPU box
+    return dict(cpu_model=model, cpu_count=os.cpu_count(), affinity_cores=usable, cgroup_quota_cores=quota, usable_cores=min(usable, share))
 
 
 def kernel_source_hash():
@@ -303,7 +319,7 @@ def main():
         shared = {
             "steps_per_s": args.steps / dt2,
             "ms_per_step": dt2 / args.steps * 1e3,
-            "kernel": "fused_mfma_ws_kernel<GRAD> (v_mfma_f32_32x32x2_f32)",
+            "kernel": "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)",
             "kernel_ms": k2,
             "roofline_mfma": {"bound": "mfma", "achieved": flops / (k2 * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": flops / (k2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_launch": flops},
