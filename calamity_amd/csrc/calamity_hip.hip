@@ -695,6 +695,7 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipMemsetAsync(coef_v.p, 0, coef_v.bytes, stream));
     // a new fit begins: loop state of calibration.py:573-574
     h_state->t = 0;
+    h_state->b1t = h_state->b2t = 1.0;
     h_state->min_loss = 9e99;
     h_state->prev_loss = 0;
     h_state->n_recorded_total = 0;
@@ -769,6 +770,8 @@ struct SolverT final : cal_solver {
     if (cv_r) HIP_TRY(hipMemcpy(coef_v.as<T>(), cv_r, cb, hipMemcpyHostToDevice));
     if (cv_i) HIP_TRY(hipMemcpy(coef_v.as<T>() + ncoef, cv_i, cb, hipMemcpyHostToDevice));
     h_state->t = t;
+    h_state->b1t = std::pow(opt.beta_1, (double)t);
+    h_state->b2t = std::pow(opt.beta_2, (double)t);
     return CAL_OK;
   }
 
@@ -901,7 +904,7 @@ struct SolverT final : cal_solver {
     T2* r0 = comm.as<T2>();
     T2* r1 = r0 + gn;
     T2* r2 = r1 + gn;
-    const bool fused_tail = apply_update && !Rk;  // loop bookkeeping + update (+ partial-gradient sums) in ONE launch: enqueue_update
+    const bool fused_tail = apply_update && !Rk && tail_fits_one_launch();  // loop bookkeeping + update (+ partial-gradient sums) in ONE launch: enqueue_update
     if (grads) {
       if (!gc_direct && !use_mfma && !fused_tail) {
         hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
@@ -948,6 +951,10 @@ struct SolverT final : cal_solver {
     return CAL_OK;
   }
 
+  // Small problems (a step of tens of microseconds: HERA-37, the tutorial) gain from one launch instead of three for the
+  // tail of a step; with millions of parameters the per-block decision prologue of the fused kernel costs more than the two
+  // kernel boundaries it saves (HERA-350: 105 us against 5 + 56 us), so those keep finalize_kernel + adam2_kernel.
+  bool tail_fits_one_launch() const { return 2LL * nants * fpad + 2LL * ncoef <= (1LL << 20); }
   int enqueue_update(bool freeze_model, int losses_cap) {
     DevState* st = st_cur();
     const long long gn = 2LL * nants * fpad;
@@ -957,18 +964,18 @@ struct SolverT final : cal_solver {
     const AdamSet<T> ca{coef.as<T>(), grad_c0(), coef_m.as<T>(), coef_v.as<T>(), csnap, freeze_model ? 0LL : 2LL * ncoef};
     const int nblk_a = (int)((ga.n + 255) / 256), nblk_b = (int)((ca.n + 255) / 256);
     const bool Rk = reg == CAL_REG_SUM && !mf_ok;
-    if (!Rk) {
+    if (!Rk && tail_fits_one_launch()) {
       // the common path: finalize + update (+ the partial coefficient-gradient sums of split groups) as one launch
       PartialSum<T> ps{};
       if (!gc_direct && !mf_ok && !freeze_model)
         ps = PartialSum<T>{gcp0.as<T>(), gcp0.as<T>() + gcp_len, coef_grp.as<int>(), grp_coff.as<int>(), grp_item_ptr.as<int>(),
                            item_goff.as<int>(), ncoef};
-      const unsigned nb = (unsigned)std::max(1, nblk_a + nblk_b);
+      const unsigned nb = (unsigned)std::max(1, std::min(nblk_a + nblk_b, 16384));
       if (opt.optimizer == CAL_OPT_ADAM)
-        hipLaunchKernelGGL((step_update_kernel<T, 0>), dim3(nb), dim3(256), 0, stream, ga, ca, nblk_a, ps, st, st_nxt(), scal.as<double>(),
+        hipLaunchKernelGGL((step_update_kernel<T, 0>), dim3(nb), dim3(256), 0, stream, ga, ca, ps, st, st_nxt(), scal.as<double>(),
                            losses.as<double>(), losses_cap);
       else
-        hipLaunchKernelGGL((step_update_kernel<T, 1>), dim3(nb), dim3(256), 0, stream, ga, ca, nblk_a, ps, st, st_nxt(), scal.as<double>(),
+        hipLaunchKernelGGL((step_update_kernel<T, 1>), dim3(nb), dim3(256), 0, stream, ga, ca, ps, st, st_nxt(), scal.as<double>(),
                            losses.as<double>(), losses_cap);
       st_par ^= 1;
       HIP_TRY(hipGetLastError());

@@ -106,6 +106,9 @@ __device__ long long g_dense_stamps[4096][4][4];  // diagnostic build only: [pan
 #else
 #define STAMP_T(var)
 #endif
+#ifndef CAL_DENSE_ROT
+#define CAL_DENSE_ROT 1
+#endif
 #ifndef CAL_DENSE_WPS
 #define CAL_DENSE_WPS(NTMAX) 2
 #endif
@@ -170,15 +173,24 @@ __global__ __launch_bounds__(kDenseThreads, CAL_DENSE_WPS(NTMAX)) void fused_den
   // positions, then (GRAD) the 4 NT adjoint positions -- both contiguous in the packed blocks.  A request cursor runs kRing
   // positions ahead of the consumer through phases and channel blocks alike; past the last block it re-requests the last.
   const int nb_pos = GRAD ? 4 * NT : 0;
-  const int last_cb = wave + 4 * ((ncb - 1 - wave) / 4);
-  int rq_cb = wave, rq_o = 0;
+  // the wave's channel blocks, in the order it walks them: cb_of(n) = wave + 4 ((n + rot) mod nper), n = 0 .. nper - 1.
+  // The start offset differs from panel to panel: panels of one basis block start together on many CUs and would otherwise
+  // request the same operand lines at the same moment.
+  const int nper = ncb / 4;  // the row padding makes ncb a multiple of 4
+#if CAL_DENSE_ROT
+  const int rot = (int)(blockIdx.x % (unsigned)nper);
+#else
+  const int rot = 0;
+#endif
+  auto cb_of = [&](int n) { int m = n + rot; m = m >= nper ? m - nper : m; return wave + 4 * m; };
+  int rq_n = 0, rq_o = 0;
   auto req_off = [&]() {
-    const int cbv = rq_cb < last_cb ? rq_cb : last_cb;
+    const int cbv = cb_of(rq_n < nper ? rq_n : nper - 1);
     return rq_o < ngk ? fblk + (unsigned)(cbv * ngk + rq_o) * 1024u : bblk + (unsigned)(cbv * nb_pos + (rq_o - ngk)) * 1024u;
   };
   auto req_advance = [&]() {
     ++rq_o;
-    if (rq_o == ngk + nb_pos) { rq_o = 0; rq_cb += 4; }
+    if (rq_o == ngk + nb_pos) { rq_o = 0; ++rq_n; }
   };
   int cons = 0;  // stream index of the position the next step consumes; its slot is cons % kRing
   f32x4 r_cur, r_nxt;
@@ -234,13 +246,14 @@ __global__ __launch_bounds__(kDenseThreads, CAL_DENSE_WPS(NTMAX)) void fused_den
     }
   };
   Samples S_cur, S_nxt;
-  load_samples(wave, S_nxt);
+  load_samples(cb_of(0), S_nxt);
 
 #ifdef CAL_STAMP
   long long cyc_f = 0, cyc_e = 0, cyc_b = 0;
   const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
 #endif
-  for (int cb = wave; cb < ncb; cb += 4) {
+  for (int nb = 0; nb < nper; ++nb) {
+    const int cb = cb_of(nb);
     STAMP_T(t0);
     // ---- F: rows = this block's 32 channels, cols = (slot, re | im), K = vectors; position = k-group (4 MFMAs)
     f32x16 acc;  // one chain: a dependent 32x32x2 may issue as soon as the pipe is free again (64 cycles either way)
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(kDenseThreads, CAL_DENSE_WPS(NTMAX)) void fused_den
     // retire in order, so the only place such a request does not park the operand stream behind it is in front of this
     // arithmetic
     S_cur = S_nxt;
-    if (cb + 4 < ncb) load_samples(cb + 4, S_nxt);
+    if (nb + 1 < nper) load_samples(cb_of(nb + 1), S_nxt);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (GA == 2 && g < 3) {

@@ -46,6 +46,8 @@ struct DevState {
   double tol;
   double lr, beta1, beta2, eps;
   double lr_t, lr_u, bc1;   // bias-corrected step sizes of the current step (Adam, Adamax)
+  double b1t, b2t;          // beta1^t, beta2^t as running products (a pow() per step and per block of the update kernel is
+                            // what the tail of a small step consists of)
   long long t;        // optimizer iterations
   int n_recorded;     // recorded losses written so far in this run
   int n_recorded_total;  // recorded steps since the loop began ("step" of :699)
@@ -992,9 +994,10 @@ __global__ void finalize_kernel(DevState* st, const double* __restrict__ scal, d
   }
   st->t += 1;
   st->nupdates += 1;
-  const double t = (double)st->t;
-  st->bc1 = 1.0 - pow(st->beta1, t);
-  st->lr_t = st->lr * sqrt(1.0 - pow(st->beta2, t)) / st->bc1;
+  st->b1t *= st->beta1;
+  st->b2t *= st->beta2;
+  st->bc1 = 1.0 - st->b1t;
+  st->lr_t = st->lr * sqrt(1.0 - st->b2t) / st->bc1;
   st->lr_u = st->lr / st->bc1;
   if (st->record) {
     if (st->n_recorded < losses_cap) losses[st->n_recorded] = loss;
@@ -1094,7 +1097,7 @@ struct PartialSum {          // gradient of coefficient n = sum over the items q
   int ncoef;                 // 0: the gradient is read from AdamSet::g as it stands
 };
 template <typename T, int OPT>
-__global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, const AdamSet<T> b, int nblk_a, const PartialSum<T> ps,
+__global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, const AdamSet<T> b, const PartialSum<T> ps,
                                                          const DevState* __restrict__ in, DevState* __restrict__ out,
                                                          const double* __restrict__ scal, double* __restrict__ losses, int losses_cap) {
   // ---- the step's decisions: thread 0 of every block derives them (identically), block 0 records them
@@ -1127,9 +1130,10 @@ __global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, co
       update = true;
       s.t += 1;
       s.nupdates += 1;
-      const double t = (double)s.t;
-      s.bc1 = 1.0 - pow(s.beta1, t);
-      s.lr_t = s.lr * sqrt(1.0 - pow(s.beta2, t)) / s.bc1;
+      s.b1t *= s.beta1;
+      s.b2t *= s.beta2;
+      s.bc1 = 1.0 - s.b1t;
+      s.lr_t = s.lr * sqrt(1.0 - s.b2t) / s.bc1;
       s.lr_u = s.lr / s.bc1;
       if (s.record) {
         if (writer && s.n_recorded < losses_cap) losses[s.n_recorded] = loss;
@@ -1152,38 +1156,43 @@ __global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, co
   }
   __syncthreads();
   if (!sh_update) return;
-  // ---- the update
-  const bool first = (int)blockIdx.x < nblk_a;
-  const AdamSet<T>& S = first ? a : b;
-  const long long i = (long long)(first ? blockIdx.x : blockIdx.x - nblk_a) * blockDim.x + threadIdx.x;
-  if (i >= S.n) return;
-  T gi;
-  if (!first && ps.ncoef > 0) {
-    const int plane = i >= ps.ncoef ? 1 : 0;
-    const int n = (int)(i - (long long)plane * ps.ncoef);
-    const int g = ps.coef_grp[n];
-    const int k = n - ps.grp_coff[g];
-    const T* src = plane ? ps.gcp_i : ps.gcp_r;
-    gi = 0;
-    for (int q = ps.grp_item_ptr[g]; q < ps.grp_item_ptr[g + 1]; ++q) gi += src[ps.item_goff[q] + k];
-  } else {
-    gi = S.g[i];
-  }
+  // ---- the update: sets a (gains) and b (coefficients) as one index space, grid-stride (the decisions above are taken
+  // once per block, so a big problem runs a few thousand blocks, not one per 256 elements)
   const T b1 = (T)sh_b1, b2 = (T)sh_b2, eps = (T)sh_eps;
-  const T mi = b1 * S.m[i] + ((T)1 - b1) * gi;
-  T pi = S.p[i];
-  if (OPT == 0) {
-    const T vi = b2 * S.v[i] + ((T)1 - b2) * gi * gi;
-    S.v[i] = vi;
-    pi -= (T)sh_lr_t * mi / (sqrt(vi) + eps);
-  } else {
-    const T ui = fmax(b2 * S.v[i], fabs(gi));
-    S.v[i] = ui;
-    pi -= (T)sh_lr_u * mi / (ui + eps);
+  const T lr_t = (T)sh_lr_t, lr_u = (T)sh_lr_u;
+  const bool improved = sh_improved != 0;
+  const long long total = a.n + b.n;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const bool first = e < a.n;
+    const AdamSet<T>& S = first ? a : b;
+    const long long i = first ? e : e - a.n;
+    T gi;
+    if (!first && ps.ncoef > 0) {
+      const int plane = i >= ps.ncoef ? 1 : 0;
+      const int n = (int)(i - (long long)plane * ps.ncoef);
+      const int g = ps.coef_grp[n];
+      const int k = n - ps.grp_coff[g];
+      const T* src = plane ? ps.gcp_i : ps.gcp_r;
+      gi = 0;
+      for (int q = ps.grp_item_ptr[g]; q < ps.grp_item_ptr[g + 1]; ++q) gi += src[ps.item_goff[q] + k];
+    } else {
+      gi = S.g[i];
+    }
+    const T mi = b1 * S.m[i] + ((T)1 - b1) * gi;
+    T pi = S.p[i];
+    if (OPT == 0) {
+      const T vi = b2 * S.v[i] + ((T)1 - b2) * gi * gi;
+      S.v[i] = vi;
+      pi -= lr_t * mi / (sqrt(vi) + eps);
+    } else {
+      const T ui = fmax(b2 * S.v[i], fabs(gi));
+      S.v[i] = ui;
+      pi -= lr_u * mi / (ui + eps);
+    }
+    S.m[i] = mi;
+    S.p[i] = pi;
+    if (improved) S.snap[i] = pi;
   }
-  S.m[i] = mi;
-  S.p[i] = pi;
-  if (sh_improved) S.snap[i] = pi;
 }
 
 // ---- setup kernels -------------------------------------------------------------------------------------------
