@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+MFMA_F64_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate (128 FLOP/clk/CU x 256 CUs x 2.4 GHz)
 
 
 def parse():
@@ -87,7 +88,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("fit_kernels.hpp", "dense_kernels.hpp", "calamity_hip.hip"):
+    for name in ("fit_kernels.hpp", "dense_kernels.hpp", "dense64_kernels.hpp", "calamity_hip.hip"):
         with open(os.path.join(ROOT, "calamity_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -201,6 +202,25 @@ def torch_sum_float(dist, vals):
     return t.numpy()
 
 
+def dense_rooflines(prob, tim, kernel_ms, dtype):
+    """Both bounds of the dense (shared-layout) kernel from its measured launch duration: the matrix pipe for
+    8 F sum nvec flops, and HBM for the algorithmic bytes with every DISTINCT basis block counted once."""
+    f32 = dtype == np.float32
+    peak = MFMA_F32_PEAK_TFLOPS if f32 else MFMA_F64_PEAK_TFLOPS
+    flops = tim["flops_per_launch"]
+    tf = flops / (kernel_ms * 1e-3) / 1e12
+    uniq_bytes = float(sum(b.size for b in prob.basis)) * np.dtype(dtype).itemsize
+    bytes_unique = tim["algorithmic_bytes_per_launch"] - tim["basis_bytes_per_launch"] + uniq_bytes
+    gbs = bytes_unique / (kernel_ms * 1e-3) / 1e9
+    return {
+        "kernel": "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)" if f32 else "fused_dense64_kernel<GRAD> (v_mfma_f64_16x16x4_f64)",
+        "kernel_ms": kernel_ms,
+        "roofline_mfma": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "flops_per_launch": flops},
+        "roofline_hbm_unique_basis": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_launch": bytes_unique},
+    }
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -296,10 +316,10 @@ def main():
     sync()
     chi2_rate = nev * ntimes / (time.perf_counter() - t1)
 
-    # the SHARED layout of the same workload (baselines of one delay alias ONE basis block; fp32 MFMA GEMM path): measured
+    # the SHARED layout of the same workload (baselines of one delay alias ONE basis block; dense MFMA path): measured
     # in the same run and reported beside the headline, against its own bounds
     shared = None
-    if not sharded and args.layout == "stream" and not args.no_shared and dtype == np.float32 and args.reg == "none":
+    if not sharded and args.layout == "stream" and not args.no_shared and args.reg == "none":
         s2 = HipFitSolver(dtype=dtype, device=0)
         s2.set_problem(prob, layout="shared")
         s2.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
@@ -313,20 +333,8 @@ def main():
         dt2 = time.perf_counter() - t2
         tim2 = s2.timing_get()
         k2 = tim2["total_ms"] / max(tim2["launches"], 1)
-        flops = 8.0 * prob.nfreqs * prob.ncoeffs  # forward A c and adjoint A^T gbar_v, complex x real
-        uniq_bytes = float(sum(b.size for b in prob.basis)) * np.dtype(dtype).itemsize
-        bytes_unique = tim2["algorithmic_bytes_per_launch"] - tim2["basis_bytes_per_launch"] + uniq_bytes
-        shared = {
-            "steps_per_s": args.steps / dt2,
-            "ms_per_step": dt2 / args.steps * 1e3,
-            "kernel": "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)",
-            "kernel_ms": k2,
-            "roofline_mfma": {"bound": "mfma", "achieved": flops / (k2 * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": flops / (k2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flops_per_launch": flops},
-            "roofline_hbm_unique_basis": {"bound": "hbm", "achieved": bytes_unique / (k2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": bytes_unique / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_unique},
-            "device_memory_GB": s2.memory_bytes() / 1e9,
-        }
+        shared = dense_rooflines(prob, tim2, k2, dtype)
+        shared.update(steps_per_s=args.steps / dt2, ms_per_step=dt2 / args.steps * 1e3, device_memory_GB=s2.memory_bytes() / 1e9)
         s2.close()
 
     # measured streaming peaks of this box and, for orientation, the only configuration the
@@ -390,6 +398,27 @@ def main():
                         traffic, traffic_src = v["hbm_bytes"], os.path.relpath(pmc_path, ROOT)
             else:
                 traffic_src = f"{os.path.relpath(pmc_path, ROOT)} is stale (measured on other kernel sources): not reported"
+        hbm_roofline = {
+            "bound": "hbm",
+            "kernel": "fused_basis_kernel<MODE_GRAD>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "kernel_ms": kern_ms,
+            "algorithmic_bytes_per_launch": tim["algorithmic_bytes_per_launch"],
+            "peak_measured": peaks,
+            "frac_of_measured_read_peak": (achieved / peaks["read_GBps"]) if peaks and "read_GBps" in peaks else None,
+        }
+        if tim["kernel_path"] == "dense":
+            # the shared layout's dense kernel is bound by the matrix pipe, not by HBM: lead with that roofline
+            d = dense_rooflines(prob, tim, kern_ms, dtype)
+            roofline = dict(d["roofline_mfma"], kernel=d["kernel"], kernel_ms=kern_ms, traffic=None, peak_measured=peaks,
+                            hbm_unique_basis=d["roofline_hbm_unique_basis"])
+        else:
+            roofline = hbm_roofline
         out = {
             "metric": "Adam steps/sec (chi2 eval/sec in extra), " + {"hera350": "HERA-350", "hera37": "HERA-37", "tutorial": "tutorial-scale"}.get(args.config, args.config)
                       + f" {prob.nfreqs}ch DPSS; %HBM roofline",
@@ -412,20 +441,7 @@ def main():
                 "parallelism": (f"every slice's baselines sharded over {world} GPUs (one process each), one RCCL all-reduce of the gain gradients + loss scalars per step"
                                 + (" [one-rank rehearsal of the multi-rank path]" if world == 1 else "")) if sharded else "single GPU",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "fused_basis_kernel<MODE_GRAD>",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel_ms": kern_ms,
-                "algorithmic_bytes_per_launch": tim["algorithmic_bytes_per_launch"],
-                "peak_measured": peaks,
-                "frac_of_measured_read_peak": (achieved / peaks["read_GBps"]) if peaks and "read_GBps" in peaks else None,
-            },
+            "roofline": roofline,
             "extra": {
                 "chi2_evals_per_s": chi2_rate,
                 # recorded (pre-update) losses of the timed steps: the steps did optimise; summed over the job's slices

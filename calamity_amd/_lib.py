@@ -69,6 +69,9 @@ class KernelTiming(C.Structure):
         ("total_ms", C.c_double),
         ("algorithmic_bytes_per_launch", C.c_double),
         ("basis_bytes_per_launch", C.c_double),
+        ("flops_per_launch", C.c_double),
+        ("kernel_path", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

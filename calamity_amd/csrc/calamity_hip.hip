@@ -17,6 +17,7 @@
 
 #include "fit_kernels.hpp"
 #include "dense_kernels.hpp"
+#include "dense64_kernels.hpp"
 #include <cstdlib>
 #include <type_traits>
 
@@ -255,9 +256,11 @@ struct SolverT final : cal_solver {
     if ((long long)(nbls + 2) * fpad * 2 * (long long)sizeof(T) >= (1LL << 32)) dense_ok = false;
     // ... and its packed operands (two MFMA-native copies of every unique block) with 32-bit byte offsets from one base
     long long dense_op_elems = 0;
-    for (int u = 0; u < nbasis && dense_ok; ++u)
-      dense_op_elems += (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256 + (long long)(fpad / 8) * ((d->basis_nvec[u] + 31) / 32) * 256;
-    if (dense_op_elems * 4 >= (1LL << 32)) dense_ok = false;
+    for (int u = 0; u < nbasis && dense_ok; ++u)  // kilobyte positions: forward + adjoint (the same count for both dtypes' layouts up to padding)
+      dense_op_elems += std::is_same<T, float>::value
+                            ? (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256 + (long long)(fpad / 32) * ((d->basis_nvec[u] + 31) / 32) * 4 * 256
+                            : (long long)(fpad / 16) * ((d->basis_nvec[u] + 7) / 8) * 128 + (long long)(fpad / 16) * ((d->basis_nvec[u] + 15) / 16) * 2 * 128;
+    if (dense_op_elems * (long long)sizeof(T) >= (1LL << 32)) dense_ok = false;
     if (d->kernel_path == CAL_PATH_DENSE && !dense_ok)
       return fail(CAL_ERR_UNSUPPORTED, "set_problem: CAL_PATH_DENSE needs the SHARED layout, one baseline per fitting group, "
                   "basis_nvec <= %d and nfreqs > 64", DenseCfg<T>::max_nvec);
@@ -409,6 +412,61 @@ struct SolverT final : cal_solver {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
+        mf_ok = true;
+      } else {
+        // ---- double precision: v_mfma_f64_16x16x4_f64 (dense64_kernels.hpp).  Two launch classes: blocks of more than 128
+        // vectors with panels of 8 baselines (one column tile, 16 gradient tiles), the rest with panels of 16 (two column tiles)
+        std::vector<long long> okf(nbasis + 1, 0), ofk(nbasis + 1, 0);
+        int nvec_a = 0, nvec_b = 0;
+        for (int u = 0; u < nbasis; ++u) {
+          const int nv = d->basis_nvec[u];
+          (nv > 128 ? nvec_a : nvec_b) = std::max(nv > 128 ? nvec_a : nvec_b, nv);
+          okf[u + 1] = okf[u] + (long long)(fpad / kCB64) * ((nv + 7) / 8) * 128;
+          ofk[u + 1] = ofk[u] + (long long)(fpad / kCB64) * ((nv + kVT64 - 1) / kVT64) * 2 * 128;
+        }
+        for (int u = 0; u <= nbasis; ++u) ofk[u] += okf[nbasis];
+        CAL_TRY(mf_ops.alloc((size_t)ofk[nbasis] * sizeof(double), false));
+        for (int u = 0; u < nbasis; ++u)
+          hipLaunchKernelGGL(mfma_pack64_kernel, dim3(grid_for(okf[u + 1] - okf[u] + ofk[u + 1] - ofk[u])), dim3(256), 0, stream,
+                             raw.as<double>() + d->basis_offset[u], mf_ops.as<double>() + okf[u], mf_ops.as<double>() + ofk[u], nfreqs, fpad,
+                             d->basis_nvec[u]);
+        HIP_TRY(hipGetLastError());
+        std::vector<std::vector<int>> by_u(nbasis);
+        for (int b = 0; b < nbls; ++b) by_u[d->grp_basis[grp_of_bl[b]]].push_back(b);
+        std::vector<int> uorder(nbasis);
+        std::iota(uorder.begin(), uorder.end(), 0);
+        std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
+        std::vector<PanelItem> h_panels;
+        mf_split = 0;
+        for (int cls = 0; cls < 2; ++cls) {
+          const int width = cls == 0 ? 8 : 16;
+          for (int u : uorder) {
+            if ((d->basis_nvec[u] > 128) != (cls == 0)) continue;
+            for (size_t i = 0; i < by_u[u].size(); i += width) {
+              PanelItem pi{};
+              for (int k = 0; k < kPanel; ++k) pi.bl[k] = k < width && i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+              pi.a_kf4 = okf[u];
+              pi.a_fk4 = ofk[u];
+              pi.nvec = d->basis_nvec[u];
+              h_panels.push_back(pi);
+            }
+          }
+          if (cls == 0) mf_split = (int)h_panels.size();
+        }
+        mf_npanels = (int)h_panels.size();
+        CAL_TRY(mf_panels.alloc(h_panels.size() * sizeof(PanelItem), false));
+        HIP_TRY(hipMemcpyAsync(mf_panels.p, h_panels.data(), h_panels.size() * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
+        std::vector<int> h_bl_coff(nbls);
+        for (int b = 0; b < nbls; ++b) h_bl_coff[b] = h_grp_coff[grp_of_bl[b]];
+        CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
+        HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        mf_lds_grad = std::max(dense64_lds_bytes(nvec_a, 1, true), dense64_lds_bytes(nvec_b, 2, true));
+        mf_lds_loss = std::max(dense64_lds_bytes(nvec_a, 1, false), dense64_lds_bytes(nvec_b, 2, false));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
         mf_ok = true;
       }
     }
@@ -826,6 +884,17 @@ struct SolverT final : cal_solver {
     }
   }
   // the dense pass: panels with more than four vector tiles (kernel instance with eight accumulator tiles per wave), then the rest
+  template <bool GRAD> void launch_dense(Dense64Args m) {
+    const size_t lds = GRAD ? mf_lds_grad : mf_lds_loss;
+    if (mf_split > 0) {
+      m.panel_base = 0;
+      hipLaunchKernelGGL((fused_dense64_kernel<GRAD, 1, 16>), dim3(mf_split), dim3(kDenseThreads), lds, stream, m);
+    }
+    if (mf_npanels > mf_split) {
+      m.panel_base = mf_split;
+      hipLaunchKernelGGL((fused_dense64_kernel<GRAD, 2, 8>), dim3(mf_npanels - mf_split), dim3(kDenseThreads), lds, stream, m);
+    }
+  }
   template <bool GRAD> void launch_dense(MfmaArgs m) {
     const size_t lds = GRAD ? mf_lds_grad : mf_lds_loss;
     if (mf_split > 0) {
@@ -864,21 +933,21 @@ struct SolverT final : cal_solver {
     const bool Rk = R && !use_mfma;  // the general kernel's two-adjoint-set form of the regulariser
     const bool two_pass = use_mfma && R && grads;
     if (use_mfma) {
-      if constexpr (std::is_same<T, float>::value) {
-        MfmaArgs m{};
-        m.ops = mf_ops.as<float>();
+      {
+        typename std::conditional<std::is_same<T, float>::value, MfmaArgs, Dense64Args>::type m{};
+        m.ops = mf_ops.as<T>();
         m.panels = mf_panels.as<PanelItem>();
         m.bl_ant = bl_ant.as<int2>();
         m.bl_coff = mf_bl_coff.as<int>();
-        m.data_r = data_r.as<float>();
-        m.data_i = data_i.as<float>();
-        m.wgts = wgts.as<float>();
-        m.gains = gains.as<float2>();
-        m.c_r = coef.as<float>();
-        m.c_i = coef.as<float>() + ncoef;
-        m.q0 = q0.as<float2>();
-        m.gc_r = reinterpret_cast<float*>(grad_c0());
-        m.gc_i = reinterpret_cast<float*>(grad_c0()) + ncoef;
+        m.data_r = data_r.as<T>();
+        m.data_i = data_i.as<T>();
+        m.wgts = wgts.as<T>();
+        m.gains = gains.as<T2>();
+        m.c_r = coef.as<T>();
+        m.c_i = coef.as<T>() + ncoef;
+        m.q0 = q0.as<T2>();
+        m.gc_r = grad_c0();
+        m.gc_i = grad_c0() + ncoef;
         m.part = part.as<double>();
         m.state = st;
         m.fpad = fpad;
@@ -1156,13 +1225,17 @@ struct SolverT final : cal_solver {
     out->basis_bytes_per_launch = basis_bytes;
     out->algorithmic_bytes_per_launch =
         basis_bytes + s * (3.0 * nfreqs * nbls + 2.0 * ncoef + 2.0 * nants * nfreqs) + s * (10.0 * ncoef + 10.0 * nants * nfreqs);
+    out->flops_per_launch = 8.0 * nfreqs * (double)ncoef;
+    out->kernel_path = mf_ok ? CAL_PATH_DENSE : CAL_PATH_GENERAL;
+    out->reserved = 0;
     return CAL_OK;
   }
   int memory_bytes(int64_t* b) override {
     if (!b) return fail(CAL_ERR_INVALID, "memory_bytes: null");
     const DevBuf* all[] = {&tiles, &bl_tile, &bl_ant, &items, &ant_ptr, &ant_ent, &coef_grp, &grp_coff, &grp_item_ptr, &item_goff,
                            &data_r, &data_i, &wgts, &gains, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
-                           &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf};
+                           &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf,
+                           &mf_ops, &mf_panels, &mf_bl_coff};
     int64_t n = 0;
     for (auto* d : all) n += (int64_t)d->bytes;
     *b = n;

@@ -1,0 +1,346 @@
+// dense64_kernels.hpp -- the dense (matrix-core) formulation of dense_kernels.hpp in double precision, on
+// v_mfma_f64_16x16x4_f64 (--precision 64 of the reference, /root/reference/calamity/calibration.py:1857, :1795).
+//
+// Same structure as the fp32 kernel -- one 4-wave workgroup per panel, two workgroups per CU, each wave owns channel blocks
+// and runs forward MFMA, element-wise stage in the accumulator registers and the adjoint MFMA that takes those registers as
+// its B operand, coefficient gradients in registers for the whole panel, operand stream through a per-wave LDS-DMA ring --
+// with the tile shapes of the f64 instruction:
+//   * one MFMA = 16 x 16 x 4; a channel block = 16 channels; a column tile = 16 columns = 8 baselines x (re | im);
+//   * accumulator of lane l: column j = l & 15, rows (l >> 4) + 4 r, r = 0..3: as the B operand of the adjoint MFMA register
+//     r carries k = l >> 4 <-> channel (l >> 4) + 4 r, which is how the packed adjoint operand is ordered;
+//   * re and im of a slot sit 8 lanes apart inside a row of 16 lanes and are exchanged with a DPP row rotation by 8; of the
+//     four channels a lane holds per block the re lane takes the first two, the im lane the last two.
+// One kilobyte of packed basis feeds only TWO f64 MFMAs per column tile (eight bytes per operand), so a panel of NC = 2
+// column tiles (16 baselines) is used wherever the registers allow it (at most 128 vectors: 2 x 8 gradient tiles); wider
+// blocks run with NC = 1.
+#pragma once
+#include "dense_kernels.hpp"
+
+namespace calk {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <> struct DenseCfg<double> { static constexpr int max_nvec = 256; };
+constexpr int kCB64 = 16;    // channels per block
+constexpr int kVT64 = 16;    // vectors per gradient tile
+
+struct Dense64Args {
+  const double* ops;           // packed operands of every basis block
+  const PanelItem* panels;     // bl[0 .. 8 NC)
+  const int2* bl_ant;
+  const int* bl_coff;
+  const double* data_r;        // [nbls + 1][fpad]
+  const double* data_i;
+  const double* wgts;
+  const double2* gains;        // [nants][fpad]
+  const double* c_r;
+  const double* c_i;
+  double2* q0;                 // [nbls + 1][fpad]
+  double* gc_r;
+  double* gc_i;
+  double* part;                // [npanels][4]
+  const DevState* state;
+  int fpad;
+  int use_alpha;
+  int nbls;
+  int panel_base;
+};
+
+__device__ __forceinline__ double swap8(double x) {  // the value of lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
+  const long long b = __builtin_bit_cast(long long, x);
+  int lo = (int)b, hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+template <bool GRAD, int NC, int NTMAX>
+__global__ __launch_bounds__(kDenseThreads, 2) void fused_dense64_kernel(const Dense64Args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int kRing = GRAD ? 8 : 4;
+  if (A.state->done | A.state->done_after) return;
+  const int panel_idx = A.panel_base + (int)blockIdx.x;
+  const PanelItem& P = A.panels[panel_idx];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15;       // MFMA column of a tile: (slot, re | im)
+  const int kq = lane >> 4;        // the k of a 16x16x4 step this lane feeds / the channel sub-offset it holds
+  const bool im_lane = (col & 8) != 0;
+  const int nvec = P.nvec;
+  const int NT = (nvec + kVT64 - 1) / kVT64;
+  const int ngk = (nvec + 7) / 8;  // forward positions: 8 vectors (two k-steps of 4) per kilobyte
+  const int ncb = A.fpad / kCB64;
+
+  unsigned char* s_ring = smem_raw;                                                // [4 waves][kRing][1 KB]
+  double* s_red = reinterpret_cast<double*>(smem_raw + 4 * kRing * 1024);          // [4 waves][3]
+  double* s_c = reinterpret_cast<double*>(smem_raw + 4 * kRing * 1024 + 128);      // [NC][ngk][64 lanes][2]
+  {
+    // coefficient operand of column tile c: s_c[((c * ngk + p) * 64 + lane) * 2 + u] = C[col = lane & 15][vector 8 p + 4 u + (lane >> 4)]
+    const int n = NC * ngk * 128;
+    for (int i = tid; i < n; i += kDenseThreads) {
+      const int u = i & 1, l = (i >> 1) & 63, r = i >> 7;
+      const int p = r % ngk, c = r / ngk;
+      const int cj = l & 15, k = 8 * p + 4 * u + (l >> 4);
+      const int b = P.bl[c * 8 + (cj & 7)];
+      double v = 0.0;
+      if (b >= 0 && k < nvec) v = (cj < 8 ? A.c_r : A.c_i)[A.bl_coff[b] + k];
+      s_c[i] = v;
+    }
+  }
+  // this lane's slots (one per column tile): sample row and antenna pair as 32-bit BYTE offsets from the kernel-argument bases
+  // (+ kq channels: the lane holds channels kq + 4 r of a block)
+  const unsigned pl = im_lane ? 2u : 0u;  // the re lane works on r = 0, 1, the im lane on r = 2, 3
+  int my_bl[NC];
+  unsigned ob[NC], og0[NC], og1[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    my_bl[c] = P.bl[c * 8 + (col & 7)];
+    const int2 ant = my_bl[c] >= 0 ? A.bl_ant[my_bl[c]] : make_int2(0, 0);
+    const unsigned row = (unsigned)(my_bl[c] >= 0 ? my_bl[c] : A.nbls);
+    ob[c] = (row * (unsigned)A.fpad + (unsigned)kq + 4u * pl) * 8u;              // double arrays
+    og0[c] = ((unsigned)ant.x * (unsigned)A.fpad + (unsigned)kq + 4u * pl) * 16u;  // double2 arrays
+    og1[c] = ((unsigned)ant.y * (unsigned)A.fpad + (unsigned)kq + 4u * pl) * 16u;
+  }
+  __syncthreads();
+
+  const f32x4_t* ops = reinterpret_cast<const f32x4_t*>(A.ops);
+  const unsigned fblk = (unsigned)P.a_kf4 * 8u, bblk = (unsigned)P.a_fk4 * 8u;  // byte offsets of this panel's two packed blocks
+  const f64x2* sc2 = reinterpret_cast<const f64x2*>(s_c) + lane;
+  const unsigned voff = (unsigned)lane * 16u;
+  const unsigned ring_lds = (unsigned)reinterpret_cast<unsigned long long>(s_ring + wave * kRing * 1024);
+  const f64x2* ring_rd = reinterpret_cast<const f64x2*>(s_ring + wave * kRing * 1024) + lane;
+
+  // the wave's operand stream (see dense_kernels.hpp): per channel block ngk forward positions, then 2 NT adjoint positions
+  const int nb_pos = GRAD ? 2 * NT : 0;
+  const int nper = ncb / 4;  // the row padding (a multiple of 128 channels) makes ncb a multiple of 4
+  auto cb_of = [&](int n) { return wave + 4 * n; };
+  int rq_n = 0, rq_o = 0;
+  auto req_off = [&]() {
+    const int cbv = cb_of(rq_n < nper ? rq_n : nper - 1);
+    return rq_o < ngk ? fblk + (unsigned)(cbv * ngk + rq_o) * 1024u : bblk + (unsigned)(cbv * nb_pos + (rq_o - ngk)) * 1024u;
+  };
+  auto req_advance = [&]() {
+    ++rq_o;
+    if (rq_o == ngk + nb_pos) { rq_o = 0; ++rq_n; }
+  };
+  int cons = 0;
+  f64x2 r_cur, r_nxt;
+  for (int j = 0; j < kRing; ++j) {
+    ring_issue(ring_lds + (unsigned)j * 1024u, ops, voff, req_off());
+    req_advance();
+  }
+  RING_WAIT(kRing - 1);
+  r_cur = ring_rd[0];
+#define STREAM_NEXT()                                      \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  RING_WAIT(kRing - 2);                                    \
+  r_nxt = ring_rd[((cons + 1) & (kRing - 1)) * 64];        \
+  __builtin_amdgcn_sched_barrier(0);
+#define STREAM_REQ()                                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  ring_issue(ring_lds + (unsigned)(cons & (kRing - 1)) * 1024u, ops, voff, req_off());           \
+  req_advance();                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+#define STREAM_ADVANCE() \
+  r_cur = r_nxt;         \
+  ++cons;
+
+  f64x4 dC[NC][NTMAX];  // gradient tiles: lane (col, kq), element r -> vector 16 t + kq + 4 r
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int t = 0; t < NTMAX; ++t) dC[c][t] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
+  const double al_r = A.use_alpha ? A.state->alpha_r : 0.0, al_i = A.use_alpha ? A.state->alpha_i : 0.0;
+  const char* p_dr = reinterpret_cast<const char*>(A.data_r);
+  const char* p_di = reinterpret_cast<const char*>(A.data_i);
+  const char* p_w = reinterpret_cast<const char*>(A.wgts);
+  const char* p_g = reinterpret_cast<const char*>(A.gains);
+  char* p_q = reinterpret_cast<char*>(A.q0);
+  struct Samples { double dr[NC][2], di[NC][2], w[NC][2]; };  // one channel block: [column tile][this lane's two channels]
+  auto load_samples = [&](int cbn, Samples& S) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned o = ob[c] + (unsigned)cbn * (kCB64 * 8u) + 32u * i;  // channel 16 cb + kq + 4 (pl + i)
+        S.dr[c][i] = *reinterpret_cast<const double*>(p_dr + o);
+        S.di[c][i] = *reinterpret_cast<const double*>(p_di + o);
+        S.w[c][i] = *reinterpret_cast<const double*>(p_w + o);
+      }
+  };
+  Samples S_cur, S_nxt;
+  load_samples(cb_of(0), S_nxt);
+
+  for (int nb = 0; nb < nper; ++nb) {
+    const int cb = cb_of(nb);
+    // ---- F: rows = this block's 16 channels, cols = (slot, re | im), K = vectors; position = 8 vectors (2 MFMAs per column tile)
+    f64x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+    f64x2 c_cur[NC], c_nxt[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) c_cur[c] = sc2[(c * ngk) * 64];
+    for (int g = 0; g < ngk; ++g) {
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[0], c_cur[0][0], acc[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) c_nxt[c] = sc2[(c * ngk + (g + 1 < ngk ? g + 1 : ngk - 1)) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[1], c_cur[0][1], acc[0], 0, 0, 0);
+      STREAM_NEXT()
+      if (NC > 1) acc[NC - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[0], c_cur[NC - 1][0], acc[NC - 1], 0, 0, 0);
+      STREAM_REQ()
+      if (NC > 1) acc[NC - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[1], c_cur[NC - 1][1], acc[NC - 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      STREAM_ADVANCE()
+#pragma unroll
+      for (int c = 0; c < NC; ++c) c_cur[c] = c_nxt[c];
+    }
+    // acc[c][r] of lane (col, kq) = v(channel 16 cb + kq + 4 r) of column col of tile c
+
+    // ---- E: element-wise; per column tile the re lane evaluates channels r = 0, 1 and the im lane r = 2, 3 (see the header)
+    const unsigned cb16 = (unsigned)cb * (kCB64 * 16u);
+    S_cur = S_nxt;
+    if (nb + 1 < nper) load_samples(cb_of(nb + 1), S_nxt);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const double2 g0 = *reinterpret_cast<const double2*>(p_g + (og0[c] + cb16 + 64u * i));
+        const double2 g1 = *reinterpret_cast<const double2*>(p_g + (og1[c] + cb16 + 64u * i));
+        // the re lane gets the imaginary part of channel i from its partner, the im lane the real part of channel i + 2
+        const double mine_re = acc[c][i], mine_im = acc[c][i + 2];
+        const double got = swap8(im_lane ? mine_re : mine_im);
+        const double vr = im_lane ? got : mine_re, vi = im_lane ? mine_im : got;
+        const double d_r = S_cur.dr[c][i], d_i = S_cur.di[c][i], w = S_cur.w[c][i];
+        // G = g0 conj(g1)   (calibration.py:1598-1601: grgr + gigi, gigr - grgi)
+        const double G_r = g0.x * g1.x + g0.y * g1.y;
+        const double G_i = g0.y * g1.x - g0.x * g1.y;
+        const double m_r = G_r * vr - G_i * vi;
+        const double m_i = G_i * vr + G_r * vi;
+        const double r_r = d_r - m_r, r_i = d_i - m_i;
+        loss_acc += w * (r_r * r_r + r_i * r_i);
+        sr_acc += w * m_r;  // S = sum w m of the "sum" regulariser (calibration.py:1648-1649)
+        si_acc += w * m_i;
+        if (GRAD) {
+          const double e_r = -2.0 * w * r_r + al_r * w, e_i = -2.0 * w * r_i + al_i * w;
+          // gbar_v = conj(G) e: the re lane keeps the real part of its channel and needs the real part of the im lane's
+          // channel; the im lane keeps the imaginary part of its channel and needs the imaginary part of the re lane's
+          const double gv_r = G_r * e_r + G_i * e_i, gv_i = G_r * e_i - G_i * e_r;
+          const double back = swap8(im_lane ? gv_r : gv_i);
+          acc[c][i] = im_lane ? back : gv_r;      // channel i:     re lane: own real part;       im lane: re lane's imaginary part
+          acc[c][i + 2] = im_lane ? gv_i : back;  // channel i + 2: re lane: im lane's real part; im lane: own imaginary part
+          // gbar_G = conj(v) e
+          double2 q;
+          q.x = vr * e_r + vi * e_i;
+          q.y = vr * e_i - vi * e_r;
+          *reinterpret_cast<double2*>(p_q + (2u * ob[c] + cb16 + 64u * i)) = q;
+        }
+      }
+    }
+
+    // ---- B: rows = vectors of tile t, cols = (slot, re | im), K = this block's channels; position = (tile, half v): r = 2 v, 2 v + 1
+    if (GRAD) {
+#define B_POS64(T, V)                                                                                                 \
+  dC[0][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[0], acc[0][2 * (V) + 0], dC[0][T], 0, 0, 0);                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  dC[0][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[1], acc[0][2 * (V) + 1], dC[0][T], 0, 0, 0);                    \
+  STREAM_NEXT()                                                                                                       \
+  if (NC > 1) dC[NC - 1][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[0], acc[NC - 1][2 * (V) + 0], dC[NC - 1][T], 0, 0, 0); \
+  STREAM_REQ()                                                                                                        \
+  if (NC > 1) dC[NC - 1][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[1], acc[NC - 1][2 * (V) + 1], dC[NC - 1][T], 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  STREAM_ADVANCE()
+#pragma unroll
+      for (int t = 0; t < NTMAX; ++t) {
+        if (t < NT) {  // wave-uniform
+          B_POS64(t, 0)
+          B_POS64(t, 1)
+        }
+      }
+#undef B_POS64
+    }
+  }
+#undef STREAM_NEXT
+#undef STREAM_REQ
+#undef STREAM_ADVANCE
+  RING_WAIT(0);
+
+  // ---- panel epilogue: loss partials (fixed order), then the coefficient gradients
+  {
+    const double l = ldsum(loss_acc), sr = ldsum(sr_acc), si = ldsum(si_acc);
+    if (lane == 0) {
+      s_red[wave * 3 + 0] = l;
+      s_red[wave * 3 + 1] = sr;
+      s_red[wave * 3 + 2] = si;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const size_t pi = (size_t)panel_idx * 4;
+    A.part[pi + 0] = s_red[0] + s_red[3] + s_red[6] + s_red[9];
+    A.part[pi + 1] = s_red[1] + s_red[4] + s_red[7] + s_red[10];
+    A.part[pi + 2] = s_red[2] + s_red[5] + s_red[8] + s_red[11];
+  }
+  if (!GRAD) return;
+  // each wave holds the sums over ITS channel blocks; tile by tile the four parts meet in the (now idle) ring area and one
+  // wave adds them in wave order and stores the tile
+  double* s_x = reinterpret_cast<double*>(s_ring);  // [4 waves][4 elements][64 lanes] = 8 KB
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int coff = my_bl[c] >= 0 ? A.bl_coff[my_bl[c]] : 0;
+    double* gc = im_lane ? A.gc_i : A.gc_r;
+#pragma unroll
+    for (int t = 0; t < NTMAX; ++t) {
+      if (t < NT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_x[(wave * 4 + j) * 64 + lane] = dC[c][t][j];
+        __syncthreads();
+        if (wave == (t & 3) && my_bl[c] >= 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int n = kVT64 * t + kq + 4 * j;
+            const double v = ((s_x[(0 * 4 + j) * 64 + lane] + s_x[(1 * 4 + j) * 64 + lane]) + s_x[(2 * 4 + j) * 64 + lane]) + s_x[(3 * 4 + j) * 64 + lane];
+            if (n < nvec) gc[coff + n] = v;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+inline size_t dense64_lds_bytes(int nvec_max, int nc, bool grad) {
+  return 4 * (size_t)(grad ? 8 : 4) * 1024 + 128 + (size_t)nc * ((nvec_max + 7) / 8) * 1024;
+}
+
+// packed operands of the f64 kernel:
+//   forward [F/16][ceil(nvec/8)][64 lanes][2]: lane (i, kq), u -> A[16 cb + i][8 p + 4 u + kq]
+//   adjoint [F/16][NT][2][64 lanes][2]:        lane (i, kq), u -> A[16 cb + kq + 4 (2 v + u)][16 t + i]
+__global__ void mfma_pack64_kernel(const double* __restrict__ src, double* __restrict__ a_kf, double* __restrict__ a_fk, int nfreqs, int fpad, int nvec) {
+  const int ngk = (nvec + 7) / 8, NT = (nvec + kVT64 - 1) / kVT64;
+  const long long n1 = (long long)(fpad / kCB64) * ngk * 128, n2 = (long long)(fpad / kCB64) * NT * 2 * 128;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * blockDim.x) {
+    if (i < n1) {
+      const int u = (int)(i & 1), l = (int)((i >> 1) & 63);
+      const long long r = i >> 7;
+      const int p = (int)(r % ngk), cb = (int)(r / ngk);
+      const int f = cb * kCB64 + (l & 15), k = 8 * p + 4 * u + (l >> 4);
+      a_kf[i] = (f < nfreqs && k < nvec) ? src[(long long)f * nvec + k] : 0.0;
+    } else {
+      const long long q = i - n1;
+      const int u = (int)(q & 1), l = (int)((q >> 1) & 63);
+      long long r = q >> 7;
+      const int v = (int)(r & 1);
+      r >>= 1;
+      const int t = (int)(r % NT), cb = (int)(r / NT);
+      const int f = kCB64 * cb + (l >> 4) + 4 * (2 * v + u), n = kVT64 * t + (l & 15);
+      a_fk[q] = (f < nfreqs && n < nvec) ? src[(long long)f * nvec + n] : 0.0;
+    }
+  }
+}
+
+}  // namespace calk

@@ -106,14 +106,8 @@ __device__ long long g_dense_stamps[4096][4][4];  // diagnostic build only: [pan
 #else
 #define STAMP_T(var)
 #endif
-#ifndef CAL_DENSE_ROT
-#define CAL_DENSE_ROT 1
-#endif
-#ifndef CAL_DENSE_WPS
-#define CAL_DENSE_WPS(NTMAX) 2
-#endif
 template <bool GRAD, int NTMAX>
-__global__ __launch_bounds__(kDenseThreads, CAL_DENSE_WPS(NTMAX)) void fused_dense_kernel(const MfmaArgs A) {
+__global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const MfmaArgs A) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // measured at HERA-350: 8 slots 0.955 ms / 4 slots 1.00 ms for the gradient pass (a third to a half of the operand
@@ -173,16 +167,10 @@ __global__ __launch_bounds__(kDenseThreads, CAL_DENSE_WPS(NTMAX)) void fused_den
   // positions, then (GRAD) the 4 NT adjoint positions -- both contiguous in the packed blocks.  A request cursor runs kRing
   // positions ahead of the consumer through phases and channel blocks alike; past the last block it re-requests the last.
   const int nb_pos = GRAD ? 4 * NT : 0;
-  // the wave's channel blocks, in the order it walks them: cb_of(n) = wave + 4 ((n + rot) mod nper), n = 0 .. nper - 1.
-  // The start offset differs from panel to panel: panels of one basis block start together on many CUs and would otherwise
-  // request the same operand lines at the same moment.
+  // the wave's channel blocks: cb_of(n) = wave + 4 n, n = 0 .. nper - 1.  (Starting every panel at a different block, so
+  // that panels of one basis block do not request the same operand lines at the same moment, measured no difference.)
   const int nper = ncb / 4;  // the row padding makes ncb a multiple of 4
-#if CAL_DENSE_ROT
-  const int rot = (int)(blockIdx.x % (unsigned)nper);
-#else
-  const int rot = 0;
-#endif
-  auto cb_of = [&](int n) { int m = n + rot; m = m >= nper ? m - nper : m; return wave + 4 * m; };
+  auto cb_of = [&](int n) { return wave + 4 * n; };
   int rq_n = 0, rq_o = 0;
   auto req_off = [&]() {
     const int cbv = cb_of(rq_n < nper ? rq_n : nper - 1);

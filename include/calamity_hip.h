@@ -113,6 +113,9 @@ typedef struct cal_kernel_timing { /* HIP-event timing of the fused basis-stream
   double total_ms;
   double algorithmic_bytes_per_launch; /* SURVEY.md 8(d) B_step figure restated for this problem */
   double basis_bytes_per_launch;
+  double flops_per_launch;             /* 8 F sum nvec: forward A c and adjoint A^T gbar_v, complex x real */
+  int32_t kernel_path;                 /* CAL_PATH_GENERAL or CAL_PATH_DENSE: the family the timed launches belong to */
+  int32_t reserved;
 } cal_kernel_timing;
 
 const char* cal_last_error(void);

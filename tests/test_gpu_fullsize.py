@@ -20,11 +20,11 @@ def relnorm(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def solver_for(p, start, dtype, layout):
+def solver_for(p, start, dtype, layout, kernel_path="auto"):
     from calamity_amd.solver import HipFitSolver
 
     s = HipFitSolver(dtype=dtype)
-    s.set_problem(p, layout=layout)
+    s.set_problem(p, layout=layout, kernel_path=kernel_path)
     s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
     return s
 
@@ -70,12 +70,19 @@ def hera350():
 
 
 def test_hera350_kernel_families_and_layouts_agree(hera350):
-    """BASELINE config 2 at full size (61 075 baselines x 1024 channels): fp32 MFMA path (shared layout), fp32 streaming
-    kernel (per-baseline tiles) and the fp64 general kernel give the same loss and gradients."""
+    """BASELINE config 2 at full size (61 075 baselines x 1024 channels): the fp64 general kernel is the reference; the fp64
+    dense kernel (shared layout, v_mfma_f64_16x16x4) must agree with it to 1e-10, the fp32 dense kernel (v_mfma_f32_32x32x2)
+    and the fp32 streaming kernel (per-baseline tiles) to fp32 accuracy."""
     p, start = hera350
-    ref = solver_for(p, start, np.float64, "shared")
+    ref = solver_for(p, start, np.float64, "shared", kernel_path="general")
     l64, g64_r, g64_i, c64_r, c64_i = ref.eval_grads()
     ref.close()
+    s = solver_for(p, start, np.float64, "shared", kernel_path="dense")
+    assert abs(s.eval_loss() - l64) <= 1e-10 * abs(l64)
+    ld, g_r, g_i, c_r, c_i = s.eval_grads()
+    assert abs(ld - l64) <= 1e-10 * abs(l64)
+    assert relnorm(g_r, g64_r) <= 1e-10 and relnorm(g_i, g64_i) <= 1e-10 and relnorm(c_r, c64_r) <= 1e-10 and relnorm(c_i, c64_i) <= 1e-10
+    s.close()
     for layout in ("shared", "stream"):
         s = solver_for(p, start, np.float32, layout)
         assert abs(s.eval_loss() - l64) <= 1e-5 * abs(l64)
@@ -195,7 +202,7 @@ def test_hera350_results_are_bitwise_reproducible(hera350):
     against synchronisation slips, which show up as run-to-run differences at this size first."""
     p, start = hera350
     truth = {"antpos": synthetic.hex_positions(p.nants)}
-    cases = [(p, start, np.float32, "stream"), (p, start, np.float32, "shared"), (p, start, np.float64, "stream")]
+    cases = [(p, start, np.float32, "stream"), (p, start, np.float32, "shared"), (p, start, np.float64, "stream"), (p, start, np.float64, "shared")]
     pr, sr = synthetic.merge_redundant_groups(p, truth, start)
     cases.append((pr, sr, np.float32, "shared"))
     for prob, st, dtype, layout in cases:

@@ -100,10 +100,11 @@ def test_short_trajectory(dtype, optimizer, reg):
     assert relnorm(c_i, problem.coeffs_from_chunks(p, out[3])) <= tol["traj"]
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("reg", [False, True])
-def test_short_trajectory_dense_path(reg):
-    """fp32 + SHARED layout + one baseline per group -> the MFMA path (two passes per step with the "sum" regulariser).
-    Problems this small normally take the general kernel; kernel_path="dense" asks for the dense one."""
+def test_short_trajectory_dense_path(reg, dtype):
+    """SHARED layout + one baseline per group -> the dense (matrix-core) path, fp32 and fp64 (two passes per step with the
+    "sum" regulariser).  Problems this small normally take the general kernel; kernel_path="dense" asks for the dense one."""
     p, start = make_case(seed=6, nants=12, nfreqs=200, with_sky=reg, perturb=False)
     ch, fg_r, fg_i = oracle_inputs(p, start)
     out = R.fit_gains_and_foregrounds(
@@ -111,11 +112,11 @@ def test_short_trajectory_dense_path(reg):
         maxsteps=30, optimizer="Adam", learning_rate=1e-2, sky_model_r=ch["sky_model_r"], sky_model_i=ch["sky_model_i"],
         model_regularization="sum" if reg else None,
     )
-    s = make_solver(p, start, np.float32, "shared", reg, kernel_path="dense")
+    s = make_solver(p, start, dtype, "shared", reg, kernel_path="dense")
     s.set_optimizer("Adam", learning_rate=1e-2)
     s.run(1, record=False)
     losses, stopped, nupd = s.run(30, record=True, tol=1e-14)
-    tol = TOL[np.float32]
+    tol = TOL[dtype]
     np.testing.assert_allclose(losses, np.asarray(out[4]["loss"], dtype=np.float64), rtol=tol["traj"])
     g_r, g_i, c_r, c_i = s.get_params()
     assert relnorm(g_r.astype(np.float64) + 1j * g_i, out[0] + 1j * out[1]) <= tol["traj"]

@@ -72,15 +72,16 @@ def test_row_blocks_inside_groups():
 
 
 def test_dense_path_vector_counts():
-    """One baseline per group, nvec <= 256: fp32 + shared layout takes the MFMA kernel (nvec padded to 8 / 32 inside);
-    requested explicitly, problems below ~2000 baselines normally take the general kernel."""
+    """One baseline per group, nvec <= 256, shared layout: the dense (matrix-core) kernels -- v_mfma_f32_32x32x2 in fp32
+    (vector tiles of 32, panels of 16 baselines), v_mfma_f64_16x16x4 in fp64 (tiles of 16, panels of 8 or 16) -- across
+    every tile-count class and tail; requested explicitly, problems below ~2000 baselines normally take the general kernel."""
     nvecs = [1, 7, 8, 9, 31, 32, 33, 64, 100, 129, 224, 255, 256] * 3
     p, start = random_problem(nvecs, [1] * len(nvecs), nants=12, nfreqs=1024, seed=3)
     # make same-shape groups share one basis block, as the operator cache does: panels of several baselines
     first = {}
     for g, n in enumerate(nvecs):
         p.grp_basis[g] = first.setdefault(n, g)
-    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense")
+    check(p, start, dtypes=(np.float32, np.float64), layouts=("shared",), kernel_path="dense")
 
 
 def test_many_channels_few_groups_split_items():

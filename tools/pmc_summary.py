@@ -8,7 +8,10 @@ usage: pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv 
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -22,7 +25,9 @@ def per_kernel(path, counter):
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"units": "bytes per launch", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read undercount)", "kernels": {}}
+    import bench
+
+    out = {"kernel_source_hash": bench.kernel_source_hash(), "units": "bytes per launch", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read undercount)", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("void calk::") and "calk::" not in k:
             continue

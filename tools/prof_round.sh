@@ -16,4 +16,5 @@ rocprofv3 --pmc WRITE_SIZE -d $out/pmc -o write --output-format csv -- python3 b
 echo "write done"
 python3 bench.py --steps 20 --warmup 3 > $out/bench.log 2>&1
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --extras > $out/bench_extras.log 2>&1
+python3 tools/pmc_summary.py $out/pmc/fetch_counter_collection.csv $out/pmc/write_counter_collection.csv $out/pmc_hera350_f32_stream.json > $out/pmc_summary.log 2>&1
 tail -1 $out/bench.log | cut -c1-400
