@@ -140,10 +140,10 @@ struct SolverT final : cal_solver {
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
-  DevBuf mf_ops, mf_panels, mf_bl_coff;        // mf_ops: every block's packed forward operand, then every block's packed adjoint operand
+  DevBuf mf_ops, mf_panels, mf_bl_coff;        // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
   int mf_split = 0;                            // panels [0, mf_split) have more than 4 vector tiles (kernel instance with 8 accumulator tiles)
-  size_t mf_lds_grad = 0, mf_lds_loss = 0;
+  size_t mf_lds_grad[2] = {0, 0}, mf_lds_loss[2] = {0, 0};  // per launch class
   bool mf_ok = false;
   int steps_per_sync = 1;                      // train steps enqueued between two host synchronisations of run()
   DevBuf agree_buf;
@@ -359,15 +359,12 @@ struct SolverT final : cal_solver {
           nvp2[u] = (d->basis_nvec[u] + 15) / 16 * 16;
           nvp32[u] = (d->basis_nvec[u] + 31) / 32 * 32;
           nvec_max = std::max(nvec_max, d->basis_nvec[u]);
-          okf4[u + 1] = okf4[u] + (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256;
-          ofk4[u + 1] = ofk4[u] + (long long)(fpad / 32) * (nvp32[u] / 32) * 4 * 256;
+          okf4[u + 1] = okf4[u] + (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8 + nvp32[u] / 32 * 4) * 256;
         }
-        for (int u = 0; u <= nbasis; ++u) ofk4[u] += okf4[nbasis];  // adjoint operands behind the forward ones, one buffer
-        CAL_TRY(mf_ops.alloc((size_t)ofk4[nbasis] * sizeof(float), false));
+        CAL_TRY(mf_ops.alloc((size_t)okf4[nbasis] * sizeof(float), false));
         for (int u = 0; u < nbasis; ++u)
-          hipLaunchKernelGGL(mfma_pack_kernel, dim3(grid_for(okf4[u + 1] - okf4[u] + ofk4[u + 1] - ofk4[u])), dim3(256), 0, stream,
-                             raw.as<float>() + d->basis_offset[u], mf_ops.as<float>() + okf4[u], mf_ops.as<float>() + ofk4[u], nfreqs, fpad,
-                             d->basis_nvec[u], nvp32[u]);
+          hipLaunchKernelGGL(mfma_pack_kernel, dim3(grid_for(okf4[u + 1] - okf4[u])), dim3(256), 0, stream,
+                             raw.as<float>() + d->basis_offset[u], mf_ops.as<float>() + okf4[u], nfreqs, fpad, d->basis_nvec[u], nvp32[u]);
         HIP_TRY(hipGetLastError());
         // panels of kPanel baselines with the same basis, heaviest first
         std::vector<std::vector<int>> by_u(nbasis);
@@ -387,9 +384,14 @@ struct SolverT final : cal_solver {
             if ((nvp32[u] > 128) != (cls == 0)) continue;
             for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
               PanelItem pi{};
-              for (int k = 0; k < kPanel; ++k) pi.bl[k] = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+              for (int k = 0; k < kPanel; ++k) {
+                const int b = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+                pi.bl[k] = b;
+                pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
+                pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
+              }
               pi.a_kf4 = okf4[u];
-              pi.a_fk4 = ofk4[u];
+              pi.a_fk4 = 0;
               pi.nvec = d->basis_nvec[u];
               pi.nvp2 = nvp2[u];
               pi.nvp32 = nvp32[u];
@@ -406,12 +408,14 @@ struct SolverT final : cal_solver {
         CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
         HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        mf_lds_grad = dense_lds_bytes(nvec_max, true);
-        mf_lds_loss = dense_lds_bytes(nvec_max, false);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
+        mf_lds_grad[0] = dense_lds_bytes(nvec_max, true, 8);
+        mf_lds_loss[0] = dense_lds_bytes(nvec_max, false, 8);
+        mf_lds_grad[1] = dense_lds_bytes(std::min(nvec_max, 128), true, 4);
+        mf_lds_loss[1] = dense_lds_bytes(std::min(nvec_max, 128), false, 4);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[1]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[1]));
         mf_ok = true;
       } else {
         // ---- double precision: v_mfma_f64_16x16x4_f64 (dense64_kernels.hpp).  Two launch classes: blocks of more than 128
@@ -444,7 +448,12 @@ struct SolverT final : cal_solver {
             if ((d->basis_nvec[u] > 128) != (cls == 0)) continue;
             for (size_t i = 0; i < by_u[u].size(); i += width) {
               PanelItem pi{};
-              for (int k = 0; k < kPanel; ++k) pi.bl[k] = k < width && i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+              for (int k = 0; k < kPanel; ++k) {
+                const int b = k < width && i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+                pi.bl[k] = b;
+                pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
+                pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
+              }
               pi.a_kf4 = okf[u];
               pi.a_fk4 = ofk[u];
               pi.nvec = d->basis_nvec[u];
@@ -461,12 +470,14 @@ struct SolverT final : cal_solver {
         CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
         HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        mf_lds_grad = std::max(dense64_lds_bytes(nvec_a, 1, true), dense64_lds_bytes(nvec_b, 2, true));
-        mf_lds_loss = std::max(dense64_lds_bytes(nvec_a, 1, false), dense64_lds_bytes(nvec_b, 2, false));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss));
+        mf_lds_grad[0] = dense64_lds_bytes(nvec_a, 1, true);
+        mf_lds_loss[0] = dense64_lds_bytes(nvec_a, 1, false);
+        mf_lds_grad[1] = dense64_lds_bytes(nvec_b, 2, true);
+        mf_lds_loss[1] = dense64_lds_bytes(nvec_b, 2, false);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[1]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[1]));
         mf_ok = true;
       }
     }
@@ -885,25 +896,25 @@ struct SolverT final : cal_solver {
   }
   // the dense pass: panels with more than four vector tiles (kernel instance with eight accumulator tiles per wave), then the rest
   template <bool GRAD> void launch_dense(Dense64Args m) {
-    const size_t lds = GRAD ? mf_lds_grad : mf_lds_loss;
+    const size_t* lds = GRAD ? mf_lds_grad : mf_lds_loss;
     if (mf_split > 0) {
       m.panel_base = 0;
-      hipLaunchKernelGGL((fused_dense64_kernel<GRAD, 1, 16>), dim3(mf_split), dim3(kDenseThreads), lds, stream, m);
+      hipLaunchKernelGGL((fused_dense64_kernel<GRAD, 1, 16>), dim3(mf_split), dim3(kDenseThreads), lds[0], stream, m);
     }
     if (mf_npanels > mf_split) {
       m.panel_base = mf_split;
-      hipLaunchKernelGGL((fused_dense64_kernel<GRAD, 2, 8>), dim3(mf_npanels - mf_split), dim3(kDenseThreads), lds, stream, m);
+      hipLaunchKernelGGL((fused_dense64_kernel<GRAD, 2, 8>), dim3(mf_npanels - mf_split), dim3(kDenseThreads), lds[1], stream, m);
     }
   }
   template <bool GRAD> void launch_dense(MfmaArgs m) {
-    const size_t lds = GRAD ? mf_lds_grad : mf_lds_loss;
+    const size_t* lds = GRAD ? mf_lds_grad : mf_lds_loss;
     if (mf_split > 0) {
       m.panel_base = 0;
-      hipLaunchKernelGGL((fused_dense_kernel<GRAD, 8>), dim3(mf_split), dim3(kDenseThreads), lds, stream, m);
+      hipLaunchKernelGGL((fused_dense_kernel<GRAD, 8>), dim3(mf_split), dim3(kDenseThreads), lds[0], stream, m);
     }
     if (mf_npanels > mf_split) {
       m.panel_base = mf_split;
-      hipLaunchKernelGGL((fused_dense_kernel<GRAD, 4>), dim3(mf_npanels - mf_split), dim3(kDenseThreads), lds, stream, m);
+      hipLaunchKernelGGL((fused_dense_kernel<GRAD, 4>), dim3(mf_npanels - mf_split), dim3(kDenseThreads), lds[1], stream, m);
     }
   }
   T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
@@ -937,8 +948,10 @@ struct SolverT final : cal_solver {
         typename std::conditional<std::is_same<T, float>::value, MfmaArgs, Dense64Args>::type m{};
         m.ops = mf_ops.as<T>();
         m.panels = mf_panels.as<PanelItem>();
-        m.bl_ant = bl_ant.as<int2>();
-        m.bl_coff = mf_bl_coff.as<int>();
+        if constexpr (!std::is_same<T, float>::value) {
+          m.bl_ant = bl_ant.as<int2>();
+          m.bl_coff = mf_bl_coff.as<int>();
+        }
         m.data_r = data_r.as<T>();
         m.data_i = data_i.as<T>();
         m.wgts = wgts.as<T>();

@@ -29,6 +29,7 @@ constexpr int kChunk = 128;       // the row padding the dense path needs: 4 wav
 constexpr int kCB = 32;           // channels per block = one MFMA tile edge
 constexpr int kMaxNT = 8;         // vector tiles of 32 (nvec <= 256)
 constexpr int kDenseThreads = 256;
+constexpr int kSmpBytes = 6 * 1024;  // one channel block's samples of a wave's 16 baselines: 3 arrays x 32 channels x 16 x 4 B
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -40,16 +41,18 @@ struct PanelItem {
   int bl[kPanel];     // baseline ids (-1: padding slot)
   int nvec, nvp2, nvp32;
   int pad;
+  int coff[kPanel];   // coefficient offset of each slot's group (0 for padding slots)
+  int2 ant[kPanel];   // antenna pair of each slot (0, 0 for padding slots)
   // element offsets into MfmaArgs::ops (the whole buffer stays below 4 GB: the kernel adds 32-bit byte offsets to ONE base)
-  long long a_kf4;    // packed forward operand  [F/32][ceil(nvec/8)][64 lanes][4]: lane (c, half), u -> A[32 cb + c][8 g + 2 u + half]
-  long long a_fk4;    // packed adjoint operand  [F/32][nvp32/32][4][64 lanes][4]: lane (i, half), u -> A[32 cb + 8 q + 4 half + u][32 t + i]
+  long long a_kf4;    // the basis block's packed operands (mfma_pack_kernel): per channel block, forward positions
+                      //   [ceil(nvec/8)][64 lanes][4]: lane (c, half), u -> A[32 cb + c][8 g + 2 u + half], then adjoint positions
+                      //   [nvp32/32][4][64 lanes][4]: lane (i, half), u -> A[32 cb + 8 q + 4 half + u][32 t + i]
+  long long a_fk4;    // (double precision: the adjoint operands are a separate run)
 };
 
 struct MfmaArgs {
   const float* ops;            // packed operands of every basis block
   const PanelItem* panels;
-  const int2* bl_ant;
-  const int* bl_coff;          // coefficient offset of each baseline's group
   const float* data_r;         // [nbls + 1][fpad]
   const float* data_i;
   const float* wgts;
@@ -76,7 +79,7 @@ struct MfmaArgs {
 // nothing guarantees that (a register ring worked for one shape of the loops and silently broke -- renamed slots, moves of
 // registers with a load in flight -- when they were restructured).  With the data in LDS every register the compiler sees
 // is written by an instruction it tracks (ds_read_b128 of the slot, behind the counted wait).
-constexpr int kRingMax = 8;                 // operand-ring slots (1 KB each) per wave: 8 in the gradient pass, 4 in the loss-only pass
+constexpr int dense_ring_slots(bool grad, int ntmax) { return grad ? (ntmax > 4 ? 6 : 8) : 4; }  // operand-ring slots (1 KB each) per wave
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ const f32x4_t* uniform_ptr(const f32x4_t* p) {  // tell the compiler the pointer is wave-uniform ("s" operands)
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
@@ -101,7 +104,7 @@ __device__ __forceinline__ void ring_issue(unsigned lds_slot, const f32x4_t* sba
   } while (0)
 
 #ifdef CAL_STAMP
-__device__ long long g_dense_stamps[4096][4][4];  // diagnostic build only: [panel][wave][F, E, B, total] cycles
+__device__ long long g_dense_stamps[4096][4][8];  // diagnostic build only: [panel][wave][F, E, B, loop, prologue, epilogue cycles, entry time, exit time]
 #define STAMP_T(var) const long long var = (long long)__builtin_amdgcn_s_memtime()
 #else
 #define STAMP_T(var)
@@ -110,11 +113,10 @@ template <bool GRAD, int NTMAX>
 __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const MfmaArgs A) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // measured at HERA-350: 8 slots 0.955 ms / 4 slots 1.00 ms for the gradient pass (a third to a half of the operand
-  // requests miss L2: more of them in flight), 0.53 / 0.50 ms for the loss-only pass (whose smaller LDS footprint buys a
-  // third workgroup per CU)
-  constexpr int kRing = GRAD ? 8 : 4;
-  if (A.state->done | A.state->done_after) return;
+  // ring depth: as deep as two workgroups per CU allow (measured at HERA-350, gradient pass: 8 slots 0.955 ms, 4 slots
+  // 1.00 ms); the class with more than four vector tiles has the larger coefficient panel and gets 6
+  constexpr int kRing = dense_ring_slots(GRAD, NTMAX);
+  STAMP_T(t_entry);
   const int panel_idx = A.panel_base + (int)blockIdx.x;
   const PanelItem& P = A.panels[panel_idx];
   const int tid = threadIdx.x;
@@ -125,67 +127,108 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
   const int half = lane >> 5;      // the k of a 32x32x2 step this lane feeds / the channel sub-group (+4) it holds
   const int slot = col & 15;
   const bool im_lane = (col & 16) != 0;
+  // this lane's slot: sample row (padding slots use the all-zero spare row: weight 0), antenna pair, coefficient offset.
+  // The panel's whole prologue is three dependent round trips (panel record -> samples + operands + coefficients -> LDS);
+  // nothing in it sits behind a branch (a load behind a branch costs a round trip of its own)
+  const int my_bl = P.bl[slot];
+  const int2 my_ant = P.ant[slot];
+  const int my_coff = P.coff[slot];
+  const int fill_bl = P.bl[(tid >> 2) & 15];     // the column this thread fills of the coefficient panel (below)
+  const int fill_coff = P.coff[(tid >> 2) & 15];
   const int nvec = P.nvec, NT = P.nvp32 / 32;
   const int ngk = (nvec + 7) / 8;  // forward k-groups of 8 vectors (4 k-steps)
   const int ncb = A.fpad / kCB;
+  const int stopped = A.state->done | A.state->done_after;
 
-  unsigned char* s_ring = smem_raw;                                                // [4 waves][kRing][1 KB] operand rings, lowest LDS addresses
-  double* s_red = reinterpret_cast<double*>(smem_raw + 4 * kRing * 1024);          // [4 waves][3]: loss, S_r, S_i partials
-  float* s_c = reinterpret_cast<float*>(smem_raw + 4 * kRing * 1024 + 128);        // [ngk][64 lanes][4] packed coefficient operand
-  {
-    // coefficient panel in the packed operand layout: s_c[(g * 64 + lane) * 4 + u] = c_part[col = lane & 31][k = 8 g + 2 u + (lane >> 5)],
-    // cols 0-15 re, 16-31 im of the panel slots; zero beyond nvec and for padding slots
-    const int n = ngk * 256;
-    for (int i = tid; i < n; i += kDenseThreads) {
-      const int u = i & 3, l = (i >> 2) & 63, g = i >> 8;
-      const int c = l & 31, k = 8 * g + 2 * u + (l >> 5);
-      const int b = P.bl[c & 15];
-      float v = 0.f;
-      if (b >= 0 && k < nvec) v = (c < 16 ? A.c_r : A.c_i)[A.bl_coff[b] + k];
-      s_c[i] = v;
-    }
-  }
-  // this lane's slot: sample row (padding slots use the all-zero spare row: weight 0) and antenna pair, as 32-bit BYTE offsets
-  // from the kernel-argument bases (scalar base + unsigned 32-bit offset is the form hipcc turns into `global_load v, v_off,
-  // s[base]`; with element offsets it builds a 64-bit address pair per load)
-  const int my_bl = P.bl[slot];
-  const int2 my_ant = my_bl >= 0 ? A.bl_ant[my_bl] : make_int2(0, 0);
-  const unsigned row = (unsigned)(my_bl >= 0 ? my_bl : A.nbls);
-  const unsigned ob = (row * (unsigned)A.fpad + 4u * half) * 4u;            // float arrays
-  const unsigned og0 = ((unsigned)my_ant.x * (unsigned)A.fpad + 4u * half) * 8u;  // float2 arrays
-  const unsigned og1 = ((unsigned)my_ant.y * (unsigned)A.fpad + 4u * half) * 8u;
-  __syncthreads();
+  unsigned char* s_ring = smem_raw;                                                // [4 waves][kRing][1 KB] operand rings
+  unsigned char* s_smp = smem_raw + 4 * kRing * 1024;                              // [4 waves][6 KB]: one channel block's samples
+  double* s_red = reinterpret_cast<double*>(s_smp + 4 * kSmpBytes);                // [4 waves][3]: loss, S_r, S_i partials
+  float* s_c = reinterpret_cast<float*>(s_smp + 4 * kSmpBytes + 128);              // [ngk][64 lanes][4] packed coefficient operand
 
   const f32x4* ops = reinterpret_cast<const f32x4*>(A.ops);  // ONE scalar base for every operand request
-  const unsigned fblk = (unsigned)P.a_kf4 * 4u, bblk = (unsigned)P.a_fk4 * 4u;  // byte offsets of this panel's two packed blocks
   const f32x4* sc4 = reinterpret_cast<const f32x4*>(s_c) + lane;
   const unsigned voff = (unsigned)lane * 16u;
   const unsigned ring_lds = (unsigned)reinterpret_cast<unsigned long long>(s_ring + wave * kRing * 1024);
   const f32x4* ring_rd = reinterpret_cast<const f32x4*>(s_ring + wave * kRing * 1024) + lane;
 
   // The wave's operand stream, position by position (1 KB = 4 MFMAs each): for each of its channel blocks the ngk forward
-  // positions, then (GRAD) the 4 NT adjoint positions -- both contiguous in the packed blocks.  A request cursor runs kRing
-  // positions ahead of the consumer through phases and channel blocks alike; past the last block it re-requests the last.
-  const int nb_pos = GRAD ? 4 * NT : 0;
+  // positions, then the 4 NT adjoint positions.  The packed block stores them in exactly that order, wave after wave
+  // (mfma_pack_kernel), so the gradient pass requests ONE contiguous run; the loss-only pass skips the adjoint positions.
+  // A request cursor runs kRing positions ahead of the consumer through phases and channel blocks alike; past the end it
+  // re-requests the last position.
+  const int nb_pos = 4 * NT;
   // the wave's channel blocks: cb_of(n) = wave + 4 n, n = 0 .. nper - 1.  (Starting every panel at a different block, so
   // that panels of one basis block do not request the same operand lines at the same moment, measured no difference.)
   const int nper = ncb / 4;  // the row padding makes ncb a multiple of 4
   auto cb_of = [&](int n) { return wave + 4 * n; };
-  int rq_n = 0, rq_o = 0;
-  auto req_off = [&]() {
-    const int cbv = cb_of(rq_n < nper ? rq_n : nper - 1);
-    return rq_o < ngk ? fblk + (unsigned)(cbv * ngk + rq_o) * 1024u : bblk + (unsigned)(cbv * nb_pos + (rq_o - ngk)) * 1024u;
-  };
+  const unsigned wblk = (unsigned)P.a_kf4 * 4u + (unsigned)(wave * nper * (ngk + nb_pos)) * 1024u;  // byte offset of this wave's run
+  unsigned rq_off = wblk;
+  const unsigned rq_last = wblk + (unsigned)(nper * (ngk + nb_pos) - (GRAD ? 1 : nb_pos + 1)) * 1024u;
+  int rq_o = 0;
   auto req_advance = [&]() {
-    ++rq_o;
-    if (rq_o == ngk + nb_pos) { rq_o = 0; ++rq_n; }
+    if (GRAD) {
+      rq_off = rq_off < rq_last ? rq_off + 1024u : rq_last;
+    } else {
+      ++rq_o;
+      unsigned nxt = rq_off + 1024u;
+      if (rq_o == ngk) { rq_o = 0; nxt += (unsigned)nb_pos * 1024u; }
+      if (rq_off < rq_last) rq_off = nxt; else rq_o = 0;
+    }
   };
-  int cons = 0;  // stream index of the position the next step consumes; its slot is cons % kRing
+  // ---- samples (d_r, d_i, w) of one channel block: they stream from HBM, so they are requested a whole block ahead -- by
+  // LDS-DMA into a 6-KB area of the wave, not into registers: a register double buffer carried around the block loop makes
+  // hipcc copy it at the loop edge and wait for the loads there.  Request k (0..5) fetches array k / 2, register groups
+  // 2 (k & 1) + (lane >> 5): lane L brings the 16 bytes (4 channels) of slot L & 15, channel sub-group (L >> 4) & 1; the re and
+  // im lane of a slot each read back their 8 bytes of it.
+  const unsigned row = (unsigned)(my_bl >= 0 ? my_bl : A.nbls);
+  const unsigned smp_lds = (unsigned)reinterpret_cast<unsigned long long>(s_smp + wave * kSmpBytes);
+  const unsigned smp_voff = (row * (unsigned)A.fpad + 4u * ((unsigned)(lane >> 4) & 1u)) * 4u + (unsigned)(lane >> 5) * 32u;
+  const unsigned char* smp_rd = s_smp + wave * kSmpBytes + (slot + 16 * half) * 16 + (im_lane ? 8 : 0);
+  auto smp_issue = [&](int cbn) {
+    const unsigned o = (unsigned)cbn * (kCB * 4u);
+    ring_issue(smp_lds + 0u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o);
+    ring_issue(smp_lds + 1u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o + 64u);
+    ring_issue(smp_lds + 2u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o);
+    ring_issue(smp_lds + 3u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o + 64u);
+    ring_issue(smp_lds + 4u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o);
+    ring_issue(smp_lds + 5u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o + 64u);
+  };
+  constexpr int kSmpReq = 6;
+  if (stopped) return;
+  smp_issue(cb_of(0));  // older than every operand request: RING_WAIT(kRing - 1) in front of the first element stage covers them
+  int cslot = 0;  // ring slot of the position the next step consumes
   f32x4 r_cur, r_nxt;
   for (int j = 0; j < kRing; ++j) {
-    ring_issue(ring_lds + (unsigned)j * 1024u, ops, voff, req_off());
+    ring_issue(ring_lds + (unsigned)j * 1024u, ops, voff, rq_off);
     req_advance();
   }
+  const unsigned ob = (row * (unsigned)A.fpad + 4u * half) * 4u;                  // float arrays
+  const unsigned og0 = ((unsigned)my_ant.x * (unsigned)A.fpad + 4u * half) * 8u;  // float2 arrays
+  const unsigned og1 = ((unsigned)my_ant.y * (unsigned)A.fpad + 4u * half) * 8u;
+  {
+    // coefficient panel in the packed operand layout: s_c[(g * 64 + l) * 4 + u] = c_part[col = l & 31][k = 8 g + 2 u + (l >> 5)],
+    // cols 0-15 re, 16-31 im of the panel slots; zero beyond nvec and for padding slots.  Thread tid fills (l, u) =
+    // ((tid >> 2) & 63, tid & 3) of every k-group: its column is fixed, and the loads of eight k-groups go out together,
+    // unconditionally (clamped index)
+    const int u = tid & 3, l = (tid >> 2) & 63;
+    const float* src = ((l & 16) ? A.c_i : A.c_r) + fill_coff;
+    const int k0 = 2 * u + (l >> 5);
+    const int klast = nvec - 1;
+    for (int g0 = 0; g0 < ngk; g0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * (g0 + j) + k0;
+        v[j] = src[k < klast ? k : klast];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * (g0 + j) + k0;
+        if (g0 + j < ngk) s_c[(g0 + j) * 256 + tid] = (fill_bl >= 0 && k < nvec) ? v[j] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
   RING_WAIT(kRing - 1);
   r_cur = ring_rd[0];
   // One position = 4 MFMAs (256 cycles of the SIMD's matrix pipe) + what feeds the next ones.  A wave issues in order and
@@ -193,19 +236,28 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
   // therefore sits BETWEEN the MFMAs, a piece per 64-cycle gap, pinned with scheduling barriers:
   //   MFMA 1 | next position's operand has landed (all but the kRing - 2 youngest requests) -> read it back  (STREAM_NEXT)
   //   MFMA 2 | this position's slot is free (read one step ago) -> request position + kRing into it          (STREAM_REQ)
+  // A wave's vector-memory operations retire in issue order and s_waitcnt counts them together.  The kSmpReq sample
+  // requests of the element stage are YOUNGER than the kRing - 1 operand requests in flight at that moment, so the next
+  // kRing - 1 STREAM_NEXT waits leave them out of the count (`relax`); after that they are older than anything awaited.
+  int relax = 0;
 #define STREAM_NEXT()                                      \
   __builtin_amdgcn_sched_barrier(0);                       \
-  RING_WAIT(kRing - 2);                                    \
-  r_nxt = ring_rd[((cons + 1) & (kRing - 1)) * 64];        \
+  if (relax > 0) {                                         \
+    RING_WAIT(kRing - 2 + kSmpReq);                        \
+    --relax;                                               \
+  } else {                                                 \
+    RING_WAIT(kRing - 2);                                  \
+  }                                                        \
+  r_nxt = ring_rd[(cslot + 1 == kRing ? 0 : cslot + 1) * 64]; \
   __builtin_amdgcn_sched_barrier(0);
 #define STREAM_REQ()                                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                             \
-  ring_issue(ring_lds + (unsigned)(cons & (kRing - 1)) * 1024u, ops, voff, req_off());           \
+  ring_issue(ring_lds + (unsigned)cslot * 1024u, ops, voff, rq_off);                             \
   req_advance();                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
 #define STREAM_ADVANCE() \
   r_cur = r_nxt;         \
-  ++cons;
+  cslot = cslot + 1 == kRing ? 0 : cslot + 1;
 
   f32x16 dC[NTMAX];  // coefficient-gradient tiles: lane (col, half), reg r -> vector 32 t + (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
@@ -214,27 +266,12 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
     for (int j = 0; j < 16; ++j) dC[t][j] = 0.f;
   double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
   const float al_r = A.use_alpha ? (float)A.state->alpha_r : 0.f, al_i = A.use_alpha ? (float)A.state->alpha_i : 0.f;
-  const char* p_dr = reinterpret_cast<const char*>(A.data_r);
-  const char* p_di = reinterpret_cast<const char*>(A.data_i);
-  const char* p_w = reinterpret_cast<const char*>(A.wgts);
   const char* p_g = reinterpret_cast<const char*>(A.gains);
   char* p_q = reinterpret_cast<char*>(A.q0);
   // this lane's two channels of every register group: + 0, 1 on the re lane, + 2, 3 on the im lane
   const unsigned pl = im_lane ? 2u : 0u;
   const unsigned obp = ob + 4u * pl, og0p = og0 + 8u * pl, og1p = og1 + 8u * pl;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  struct Samples { f32x2 dr[4], di[4], w[4]; };  // one channel block: [register group][this lane's two channels]
-  auto load_samples = [&](int cbn, Samples& S) {
-    const unsigned o = obp + (unsigned)cbn * (kCB * 4u);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      S.dr[g] = *reinterpret_cast<const f32x2*>(p_dr + (o + 32u * g));
-      S.di[g] = *reinterpret_cast<const f32x2*>(p_di + (o + 32u * g));
-      S.w[g] = *reinterpret_cast<const f32x2*>(p_w + (o + 32u * g));
-    }
-  };
-  Samples S_cur, S_nxt;
-  load_samples(cb_of(0), S_nxt);
 
 #ifdef CAL_STAMP
   long long cyc_f = 0, cyc_e = 0, cyc_b = 0;
@@ -271,6 +308,17 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
     // returns the halves of gbar_v the other lane needs, so that acc[] ends up as gbar_v in the layout v had.
     const unsigned cb8 = (unsigned)cb * (kCB * 8u);
     float lt = 0.f, st_r = 0.f, st_i = 0.f;
+    // this block's samples were requested one block ago and are older than the kRing - 1 youngest operand requests
+    // (at least 7 positions -- 3 forward, 4 adjoint -- lie between)
+    RING_WAIT(kRing - 1);
+    f32x2 s_dr[4], s_di[4], s_w[4];  // [register group][this lane's two channels]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int o = ((g >> 1) * 64 + 32 * (g & 1)) * 16;
+      s_dr[g] = *reinterpret_cast<const f32x2*>(smp_rd + o);
+      s_di[g] = *reinterpret_cast<const f32x2*>(smp_rd + 2048 + o);
+      s_w[g] = *reinterpret_cast<const f32x2*>(smp_rd + 4096 + o);
+    }
     // the two antennas' gains (they come from L2): all four register groups at once where the registers allow it (one
     // round trip instead of four), else one group ahead
     constexpr int GA = NTMAX <= 4 ? 4 : 2;  // gain quads per antenna in flight
@@ -280,12 +328,6 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
       ga4[g] = *reinterpret_cast<const f32x4*>(p_g + (og0p + cb8 + 64u * g));
       gb4[g] = *reinterpret_cast<const f32x4*>(p_g + (og1p + cb8 + 64u * g));
     }
-    // this block's samples were requested one block ago (the copy waits for them HERE, where they are needed, not where
-    // they were requested); the NEXT block's are requested now: they stream from HBM, and a wave's memory operations
-    // retire in order, so the only place such a request does not park the operand stream behind it is in front of this
-    // arithmetic
-    S_cur = S_nxt;
-    if (nb + 1 < nper) load_samples(cb_of(nb + 1), S_nxt);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (GA == 2 && g < 3) {
@@ -302,7 +344,7 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
         const u2 pr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, xb), false, false);
         const unsigned p0 = pr[0], p1 = pr[1];
         const float vr = __builtin_bit_cast(float, p0), vi = __builtin_bit_cast(float, p1);  // channel i (re lane) / i + 2 (im lane)
-        const float d_r = S_cur.dr[g][i], d_i = S_cur.di[g][i], w = S_cur.w[g][i];
+        const float d_r = s_dr[g][i], d_i = s_di[g][i], w = s_w[g][i];
         const float g0x = ga[2 * i], g0y = ga[2 * i + 1], g1x = gb[2 * i], g1y = gb[2 * i + 1];
         // G = g0 conj(g1)   (calibration.py:1598-1601: grgr + gigi, gigr - grgi)
         const float G_r = g0x * g1x + g0y * g1y;
@@ -335,6 +377,12 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
     loss_acc += (double)lt;
     sr_acc += (double)st_r;
     si_acc += (double)st_i;
+    // the next block's samples (the last block requests itself again: the count of requests in flight stays what the
+    // waits assume)
+    __builtin_amdgcn_sched_barrier(0);
+    smp_issue(cb_of(nb + 1 < nper ? nb + 1 : nb));
+    relax = kRing - 1;
+    __builtin_amdgcn_sched_barrier(0);
 
     STAMP_T(t2);
     // ---- B: rows = vectors of tile t, cols = (slot, re | im), K = this block's channels; position = (tile, register group q)
@@ -371,7 +419,16 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
   if (lane == 0 && panel_idx < 4096) {
     long long* o = g_dense_stamps[panel_idx][wave];
     o[0] = cyc_f; o[1] = cyc_e; o[2] = cyc_b; o[3] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+    o[4] = t_begin - t_entry; o[6] = t_entry;
   }
+  const long long t_loop_end = (long long)__builtin_amdgcn_s_memtime();
+#define STAMP_EXIT()                                                              \
+  if (lane == 0 && panel_idx < 4096) {                                            \
+    long long* o = g_dense_stamps[panel_idx][wave];                               \
+    o[7] = (long long)__builtin_amdgcn_s_memtime(); o[5] = o[7] - t_loop_end;     \
+  }
+#else
+#define STAMP_EXIT()
 #endif
 #undef STREAM_NEXT
 #undef STREAM_REQ
@@ -394,55 +451,70 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
     A.part[pi + 1] = s_red[1] + s_red[4] + s_red[7] + s_red[10];
     A.part[pi + 2] = s_red[2] + s_red[5] + s_red[8] + s_red[11];
   }
-  if (!GRAD) return;
-  // each wave holds the sums over ITS channel blocks; tile by tile the four parts meet in the (now idle) ring area and
-  // wave t % 4 adds them in wave order and stores the tile
-  float* s_x = reinterpret_cast<float*>(s_ring);  // [4 waves][16 regs][64 lanes] = 16 KB
-  const int coff = my_bl >= 0 ? A.bl_coff[my_bl] : 0;
-  float* gc = im_lane ? A.gc_i : A.gc_r;
+  if (!GRAD) { STAMP_EXIT() return; }
+  // each wave holds the sums over ITS channel blocks; two tiles at a time the four parts meet in the (now idle) ring and
+  // sample areas ([2 tiles][4 waves][16 regs][64 lanes] = 32 KB of their 40 KB or more) and ALL 256 threads add them, in wave order: thread (tile tid >> 7,
+  // vector octet (tid >> 5) & 3, column tid & 31) owns 8 consecutive vectors of its column -- registers 4 o .. 4 o + 3 of the
+  // two lane halves -- and stores them as one contiguous run
+  float* s_x = reinterpret_cast<float*>(s_ring);
+  const int e_tile = tid >> 7, e_oct = (tid >> 5) & 3;
+  float* gc = (im_lane ? A.gc_i : A.gc_r) + my_coff;  // the thread's column is its MFMA column: tid & 31 == lane & 31
 #pragma unroll
-  for (int t = 0; t < NTMAX; ++t) {
-    if (t < NT) {
+  for (int t0 = 0; t0 < NTMAX; t0 += 2) {
+    if (t0 < NT) {  // wave-uniform
 #pragma unroll
-      for (int j = 0; j < 16; ++j) s_x[(wave * 16 + j) * 64 + lane] = dC[t][j];
-      __syncthreads();
-      if (wave == (t & 3) && my_bl >= 0) {
+      for (int tt = 0; tt < 2; ++tt)
+        if (t0 + tt < NTMAX && t0 + tt < NT) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int n = 32 * t + (j & 3) + 8 * (j >> 2) + 4 * half;
-          const float v = ((s_x[(0 * 16 + j) * 64 + lane] + s_x[(1 * 16 + j) * 64 + lane]) + s_x[(2 * 16 + j) * 64 + lane]) + s_x[(3 * 16 + j) * 64 + lane];
-          if (n < nvec) gc[coff + n] = v;
+          for (int j = 0; j < 16; ++j) s_x[((tt * 4 + wave) * 16 + j) * 64 + lane] = dC[t0 + tt][j];
         }
+      __syncthreads();
+      const int t = t0 + e_tile;
+      if (t < NT && my_bl >= 0) {
+        const int nbase = 32 * t + 8 * e_oct;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float* px = s_x + ((e_tile * 4) * 16 + 4 * e_oct + jj) * 64 + col + 32 * hf;
+            const float v = ((px[0] + px[16 * 64]) + px[2 * 16 * 64]) + px[3 * 16 * 64];
+            const int n = nbase + 4 * hf + jj;
+            if (n < nvec) gc[n] = v;
+          }
       }
       __syncthreads();
     }
   }
+  STAMP_EXIT()
 }
 
-inline size_t dense_lds_bytes(int nvec_max, bool grad) { return 4 * (size_t)(grad ? 8 : 4) * 1024 + 128 + (size_t)((nvec_max + 7) / 8) * 1024; }
+inline size_t dense_lds_bytes(int nvec_max, bool grad, int ntmax) {
+  return 4 * (size_t)dense_ring_slots(grad, ntmax) * 1024 + 128 + 4 * (size_t)kSmpBytes + (size_t)((nvec_max + 7) / 8) * 1024;
+}
 
-// packed MFMA-native operand layouts of the dense kernel (see PanelItem)
-__global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ a_kf4, float* __restrict__ a_fk4, int nfreqs, int fpad,
-                                 int nvec, int nvp32) {
+// packed MFMA-native operand layout of the dense kernel (see PanelItem): per basis block, wave after wave (w = 0..3), the
+// wave's channel blocks cb = w + 4 n in order, each as [ngk forward KB][4 NT adjoint KB] -- the order the kernel consumes
+__global__ void mfma_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int nfreqs, int fpad, int nvec, int nvp32) {
   const int ngk = (nvec + 7) / 8, NT = nvp32 / 32;
-  const long long n1 = (long long)(fpad / 32) * ngk * 256, n2 = (long long)(fpad / 32) * NT * 4 * 256;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * blockDim.x) {
-    if (i < n1) {
-      const int u = (int)(i & 3), l = (int)((i >> 2) & 63);
-      const long long r = i >> 8;
-      const int g = (int)(r % ngk), cb = (int)(r / ngk);
+  const int nper = fpad / 128;
+  const long long per_cb = (long long)(ngk + 4 * NT) * 256, total = per_cb * (fpad / 32);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cbp = (int)(i / per_cb);
+    const int r = (int)(i % per_cb);
+    const int cb = cbp / nper + 4 * (cbp % nper);
+    const int u = r & 3, l = (r >> 2) & 63;
+    float v = 0.f;
+    if (r < ngk * 256) {
+      const int g = r >> 8;
       const int f = cb * 32 + (l & 31), k = 8 * g + 2 * u + (l >> 5);
-      a_kf4[i] = (f < nfreqs && k < nvec) ? src[(long long)f * nvec + k] : 0.f;
+      if (f < nfreqs && k < nvec) v = src[(long long)f * nvec + k];
     } else {
-      const long long q = i - n1;
-      const int u = (int)(q & 3), l = (int)((q >> 2) & 63);
-      long long r = q >> 8;
-      const int qd = (int)(r & 3);
-      r >>= 2;
-      const int t = (int)(r % NT), cb = (int)(r / NT);
+      const int pos = (r >> 8) - ngk;
+      const int qd = pos & 3, t = pos >> 2;
       const int f = 32 * cb + 8 * qd + 4 * (l >> 5) + u, n = 32 * t + (l & 31);
-      a_fk4[q] = (f < nfreqs && n < nvec) ? src[(long long)f * nvec + n] : 0.f;
+      if (f < nfreqs && n < nvec) v = src[(long long)f * nvec + n];
     }
+    dst[i] = v;
   }
 }
 
