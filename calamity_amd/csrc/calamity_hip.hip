@@ -408,14 +408,11 @@ struct SolverT final : cal_solver {
         CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
         HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        mf_lds_grad[0] = dense_lds_bytes(nvec_max, true, 8);
-        mf_lds_loss[0] = dense_lds_bytes(nvec_max, false, 8);
-        mf_lds_grad[1] = dense_lds_bytes(std::min(nvec_max, 128), true, 4);
-        mf_lds_loss[1] = dense_lds_bytes(std::min(nvec_max, 128), false, 4);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[1]));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[1]));
+        // one launch serves both panel classes (up to 4 / up to 8 vector tiles): the larger of their LDS footprints
+        mf_lds_grad[0] = std::max(dense_lds_bytes(nvec_max, true, nvec_max > 128 ? 8 : 4), dense_lds_bytes(std::min(nvec_max, 128), true, 4));
+        mf_lds_loss[0] = std::max(dense_lds_bytes(nvec_max, false, nvec_max > 128 ? 8 : 4), dense_lds_bytes(std::min(nvec_max, 128), false, 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
         mf_ok = true;
       } else {
         // ---- double precision: v_mfma_f64_16x16x4_f64 (dense64_kernels.hpp).  Two launch classes: blocks of more than 128
@@ -907,15 +904,8 @@ struct SolverT final : cal_solver {
     }
   }
   template <bool GRAD> void launch_dense(MfmaArgs m) {
-    const size_t* lds = GRAD ? mf_lds_grad : mf_lds_loss;
-    if (mf_split > 0) {
-      m.panel_base = 0;
-      hipLaunchKernelGGL((fused_dense_kernel<GRAD, 8>), dim3(mf_split), dim3(kDenseThreads), lds[0], stream, m);
-    }
-    if (mf_npanels > mf_split) {
-      m.panel_base = mf_split;
-      hipLaunchKernelGGL((fused_dense_kernel<GRAD, 4>), dim3(mf_npanels - mf_split), dim3(kDenseThreads), lds[1], stream, m);
-    }
+    m.panel_base = 0;
+    hipLaunchKernelGGL((fused_dense_kernel<GRAD>), dim3(mf_npanels), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
   }
   T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
   T* grad_c1() { return gc_direct ? gcp1.as<T>() : gc1.as<T>(); }

@@ -110,9 +110,8 @@ __device__ long long g_dense_stamps[4096][4][8];  // diagnostic build only: [pan
 #define STAMP_T(var)
 #endif
 template <bool GRAD, int NTMAX>
-__global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const MfmaArgs A) {
+__device__ __forceinline__ void dense_panel(const MfmaArgs& A, unsigned char* smem_raw) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // ring depth: as deep as two workgroups per CU allow (measured at HERA-350, gradient pass: 8 slots 0.955 ms, 4 slots
   // 1.00 ms); the class with more than four vector tiles has the larger coefficient panel and gets 6
   constexpr int kRing = dense_ring_slots(GRAD, NTMAX);
@@ -194,6 +193,7 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
     ring_issue(smp_lds + 5u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o + 64u);
   };
   constexpr int kSmpReq = 6;
+  const bool few_positions = (GRAD ? ngk + nb_pos : ngk) < kRing - 1;
   if (stopped) return;
   smp_issue(cb_of(0));  // older than every operand request: RING_WAIT(kRing - 1) in front of the first element stage covers them
   int cslot = 0;  // ring slot of the position the next step consumes
@@ -239,25 +239,26 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
   // A wave's vector-memory operations retire in issue order and s_waitcnt counts them together.  The kSmpReq sample
   // requests of the element stage are YOUNGER than the kRing - 1 operand requests in flight at that moment, so the next
   // kRing - 1 STREAM_NEXT waits leave them out of the count (`relax`); after that they are older than anything awaited.
+  // In the gradient pass those kRing - 1 waits are the first adjoint positions (compile-time); in the loss-only pass the
+  // next block's forward positions (a counter).
   int relax = 0;
-#define STREAM_NEXT()                                      \
-  __builtin_amdgcn_sched_barrier(0);                       \
-  if (relax > 0) {                                         \
+#define RING_WAIT_NEXT(RELAXED)                            \
+  if (RELAXED) {                                           \
     RING_WAIT(kRing - 2 + kSmpReq);                        \
-    --relax;                                               \
   } else {                                                 \
     RING_WAIT(kRing - 2);                                  \
-  }                                                        \
-  r_nxt = ring_rd[(cslot + 1 == kRing ? 0 : cslot + 1) * 64]; \
+  }
+#define STREAM_NEXT_INTO(R, RELAXED)                       \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  RING_WAIT_NEXT(RELAXED)                                  \
+  R = ring_rd[(cslot + 1 == kRing ? 0 : cslot + 1) * 64];  \
   __builtin_amdgcn_sched_barrier(0);
 #define STREAM_REQ()                                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                             \
   ring_issue(ring_lds + (unsigned)cslot * 1024u, ops, voff, rq_off);                             \
   req_advance();                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
-#define STREAM_ADVANCE() \
-  r_cur = r_nxt;         \
-  cslot = cslot + 1 == kRing ? 0 : cslot + 1;
+#define STREAM_STEP() cslot = cslot + 1 == kRing ? 0 : cslot + 1;
 
   f32x16 dC[NTMAX];  // coefficient-gradient tiles: lane (col, half), reg r -> vector 32 t + (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
@@ -284,21 +285,36 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
     f32x16 acc;  // one chain: a dependent 32x32x2 may issue as soon as the pipe is free again (64 cycles either way)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    // two positions per trip, the operand registers alternating roles (a copy per position otherwise); the coefficient
+    // panel has a spare position behind its last, so the read-ahead needs no clamp
     f32x4 c_cur = sc4[0], c_nxt;
-    for (int g = 0; g < ngk; ++g) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r_cur[0], c_cur[0], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      c_nxt = sc4[(g + 1 < ngk ? g + 1 : ngk - 1) * 64];
-      __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r_cur[1], c_cur[1], acc, 0, 0, 0);
-      STREAM_NEXT()
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r_cur[2], c_cur[2], acc, 0, 0, 0);
-      STREAM_REQ()
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r_cur[3], c_cur[3], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      STREAM_ADVANCE()
-      c_cur = c_nxt;
+    int gq = 0;
+#define F_POS(RC, RN, CC, CN)                                                     \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(RC[0], CC[0], acc, 0, 0, 0);         \
+  __builtin_amdgcn_sched_barrier(0);                                              \
+  ++gq;                                                                           \
+  CN = sc4[gq * 64];                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                              \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(RC[1], CC[1], acc, 0, 0, 0);         \
+  {                                                                               \
+    const bool rlx = !GRAD && relax > 0;                                          \
+    STREAM_NEXT_INTO(RN, rlx)                                                     \
+    if (!GRAD && rlx) --relax;                                                    \
+  }                                                                               \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(RC[2], CC[2], acc, 0, 0, 0);         \
+  STREAM_REQ()                                                                    \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(RC[3], CC[3], acc, 0, 0, 0);         \
+  __builtin_amdgcn_sched_barrier(0);                                              \
+  STREAM_STEP()
+    for (int g = 0; g + 2 <= ngk; g += 2) {
+      F_POS(r_cur, r_nxt, c_cur, c_nxt)
+      F_POS(r_nxt, r_cur, c_nxt, c_cur)
     }
+    if (ngk & 1) {
+      F_POS(r_cur, r_nxt, c_cur, c_nxt)
+      r_cur = r_nxt;
+    }
+#undef F_POS
     // acc[r] of lane (col, half) = v(channel 32 cb + (r & 3) + 8 (r >> 2) + 4 half) of column col
 
     STAMP_T(t1);
@@ -308,9 +324,13 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
     // returns the halves of gbar_v the other lane needs, so that acc[] ends up as gbar_v in the layout v had.
     const unsigned cb8 = (unsigned)cb * (kCB * 8u);
     float lt = 0.f, st_r = 0.f, st_i = 0.f;
-    // this block's samples were requested one block ago and are older than the kRing - 1 youngest operand requests
-    // (at least 7 positions -- 3 forward, 4 adjoint -- lie between)
-    RING_WAIT(kRing - 1);
+    // this block's samples were requested one block ago: they are older than the kRing - 1 youngest operand requests when
+    // at least that many positions lie between (a block of fewer -- 16 vectors or less -- drains the queue instead)
+    if (few_positions) {
+      RING_WAIT(0);
+    } else {
+      RING_WAIT(kRing - 1);
+    }
     f32x2 s_dr[4], s_di[4], s_w[4];  // [register group][this lane's two channels]
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
     // waits assume)
     __builtin_amdgcn_sched_barrier(0);
     smp_issue(cb_of(nb + 1 < nper ? nb + 1 : nb));
-    relax = kRing - 1;
+    if (!GRAD) relax = kRing - 1;
     __builtin_amdgcn_sched_barrier(0);
 
     STAMP_T(t2);
@@ -391,12 +411,13 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
   dC[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(r_cur[0], acc[4 * (Q) + 0], dC[T], 0, 0, 0);      \
   __builtin_amdgcn_sched_barrier(0);                                                             \
   dC[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(r_cur[1], acc[4 * (Q) + 1], dC[T], 0, 0, 0);      \
-  STREAM_NEXT()                                                                                  \
+  STREAM_NEXT_INTO(r_nxt, 4 * (T) + (Q) < kRing - 1)                                             \
   dC[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(r_cur[2], acc[4 * (Q) + 2], dC[T], 0, 0, 0);      \
   STREAM_REQ()                                                                                   \
   dC[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(r_cur[3], acc[4 * (Q) + 3], dC[T], 0, 0, 0);      \
   __builtin_amdgcn_sched_barrier(0);                                                             \
-  STREAM_ADVANCE()
+  r_cur = r_nxt;                                                                                 \
+  STREAM_STEP()
 #pragma unroll
       for (int t = 0; t < NTMAX; ++t) {
         if (t < NT) {  // wave-uniform
@@ -430,9 +451,10 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
 #else
 #define STAMP_EXIT()
 #endif
-#undef STREAM_NEXT
+#undef STREAM_NEXT_INTO
+#undef RING_WAIT_NEXT
 #undef STREAM_REQ
-#undef STREAM_ADVANCE
+#undef STREAM_STEP
   RING_WAIT(0);  // retire the trailing requests: the epilogue reuses the ring area
 
   // ---- panel epilogue: loss partials (double, fixed order), then the coefficient gradients
@@ -488,8 +510,19 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const Mfm
   STAMP_EXIT()
 }
 
+// One launch for all panels, heaviest first: the body is instantiated for panels of up to 4 and of up to 8 vector tiles
+// (registers for 64 / 128 gradient accumulators; two launches, one per class, leave the CUs idle while the first drains)
+template <bool GRAD>
+__global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const MfmaArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (A.panels[A.panel_base + (int)blockIdx.x].nvp32 > 128)
+    dense_panel<GRAD, 8>(A, smem_raw);
+  else
+    dense_panel<GRAD, 4>(A, smem_raw);
+}
+
 inline size_t dense_lds_bytes(int nvec_max, bool grad, int ntmax) {
-  return 4 * (size_t)dense_ring_slots(grad, ntmax) * 1024 + 128 + 4 * (size_t)kSmpBytes + (size_t)((nvec_max + 7) / 8) * 1024;
+  return 4 * (size_t)dense_ring_slots(grad, ntmax) * 1024 + 128 + 4 * (size_t)kSmpBytes + (size_t)((nvec_max + 7) / 8 + 1) * 1024;  // + the spare coefficient position
 }
 
 // packed MFMA-native operand layout of the dense kernel (see PanelItem): per basis block, wave after wave (w = 0..3), the
