@@ -544,6 +544,8 @@ struct SolverT final : cal_solver {
           it.bl0 = d->grp_bl_start[g];
           it.tile0 = (int)(nt * p / nparts);
           it.tile1 = (int)(nt * (p + 1) / nparts);
+          it.tile_first = h_bl_tile[it.bl0];
+          it.ant_first = make_int2(d->bl_ant0[it.bl0], d->bl_ant1[it.bl0]);
           h_items.push_back(it);
           h_item_cost.push_back((long long)(it.tile1 - it.tile0) * it.nvec * fb_u[u]);
           h_item_multi.push_back(0);

@@ -70,6 +70,10 @@ struct Item {        // one workgroup's share of a fitting group
   int goff;          // offset of this item's partial coefficient gradient
   int fb_log2;       // log2 of the channel-block width of this group's tiles
   int pad;
+  // single-baseline groups: tile offset and antenna pair of the baseline the item starts with (bl_tile / bl_ant of it), so
+  // that the item's first tile loads do not wait for a lookup of their own
+  long long tile_first;
+  int2 ant_first;
 };
 
 template <typename T>
@@ -242,19 +246,10 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     q_count = 0;
   };
 
-  // Per-baseline metadata (tile offset, antenna pair) is fetched one tile ahead of its use, so that the chain
-  // bl -> bl_tile[bl] -> tile loads and bl_ant[bl] -> gains never waits inside a tile.  The index goes through an
-  // empty asm: left alone the compiler moves the loaded values to scalar registers right behind the load, which is a
-  // wait for every older load of the wave.
-  long long m_tile = 0;
-  int2 m_ant = make_int2(0, 0);
-  auto load_meta = [&](int tau) {
-    int bl = it.bl0 + tau / ntpb;
-    asm volatile("" : "+v"(bl));
-    m_tile = A.bl_tile[bl];
-    m_ant = A.bl_ant[bl];
-  };
-  load_meta(it.tile0);
+  // The items of this kernel belong to single-baseline groups: tile offset and antenna pair are those of the item record
+  // (wave-uniform, no lookup behind the item's own load).
+  const long long t_off = it.tile_first;
+  const int2 ant = it.ant_first;
 
   for (int tau = it.tile0; tau < it.tile1; ++tau) {
     const int blrel = tau / ntpb;
@@ -263,10 +258,6 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     const long long o_row = (long long)bl * A.fpad + fbk * FB;  // this tile's channels in the [nbls][fpad] arrays
     if (MODE == MODE_GRAD && q_count == C::QT) flush_q();       // s_q was last written before the previous barrier
 
-    const long long t_off = ((long long)__builtin_amdgcn_readfirstlane((int)(m_tile >> 32)) << 32) |
-                            (unsigned)__builtin_amdgcn_readfirstlane((int)m_tile);
-    const int2 ant = make_int2(__builtin_amdgcn_readfirstlane(m_ant.x), __builtin_amdgcn_readfirstlane(m_ant.y));
-    if (tau + 1 < it.tile1) load_meta(tau + 1);
 
     // ---- issue everything the tile needs: per-channel operands first (threads < FB), then the tile
     T d_r = 0, d_i = 0, w = 0;
@@ -790,9 +781,9 @@ template <typename T, int MODE, bool REG>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && !REG) ? CAL_WAVES_EU : 1)))
 void fused_basis_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (A.state->done | A.state->done_after) return;
   const int idx = A.item_base + blockIdx.x;
-  const Item it = A.items[idx];
+  const Item it = A.items[idx];  // requested together with the stop flags: one round trip, not two
+  if (A.state->done | A.state->done_after) return;
   constexpr int FBM = FbSet<T>::fb_max;
   const int fb = 1 << it.fb_log2;
   if (fb == FBM) process_item<T, FBM, MODE, REG>(A, it, smem, idx);
