@@ -140,9 +140,9 @@ struct SolverT final : cal_solver {
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
-  DevBuf mf_ops, mf_panels, mf_bl_coff;        // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
+  DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
-  int mf_split = 0;                            // panels [0, mf_split) have more than 4 vector tiles (kernel instance with 8 accumulator tiles)
+  int mf_split = 0;                            // panels [0, mf_split) are of the wide class (more vector tiles: the kernel body with more accumulators)
   size_t mf_lds_grad[2] = {0, 0}, mf_lds_loss[2] = {0, 0};  // per launch class
   bool mf_ok = false;
   int steps_per_sync = 1;                      // train steps enqueued between two host synchronisations of run()
@@ -403,10 +403,6 @@ struct SolverT final : cal_solver {
         mf_npanels = (int)h_panels.size();
         CAL_TRY(mf_panels.alloc(h_panels.size() * sizeof(PanelItem), false));
         HIP_TRY(hipMemcpyAsync(mf_panels.p, h_panels.data(), h_panels.size() * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
-        std::vector<int> h_bl_coff(nbls);
-        for (int b = 0; b < nbls; ++b) h_bl_coff[b] = h_grp_coff[grp_of_bl[b]];
-        CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
-        HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         // one launch serves both panel classes (up to 4 / up to 8 vector tiles): the larger of their LDS footprints
         mf_lds_grad[0] = std::max(dense_lds_bytes(nvec_max, true, nvec_max > 128 ? 8 : 4), dense_lds_bytes(std::min(nvec_max, 128), true, 4));
@@ -462,19 +458,11 @@ struct SolverT final : cal_solver {
         mf_npanels = (int)h_panels.size();
         CAL_TRY(mf_panels.alloc(h_panels.size() * sizeof(PanelItem), false));
         HIP_TRY(hipMemcpyAsync(mf_panels.p, h_panels.data(), h_panels.size() * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
-        std::vector<int> h_bl_coff(nbls);
-        for (int b = 0; b < nbls; ++b) h_bl_coff[b] = h_grp_coff[grp_of_bl[b]];
-        CAL_TRY(mf_bl_coff.alloc(nbls * sizeof(int), false));
-        HIP_TRY(hipMemcpyAsync(mf_bl_coff.p, h_bl_coff.data(), nbls * sizeof(int), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        mf_lds_grad[0] = dense64_lds_bytes(nvec_a, 1, true);
-        mf_lds_loss[0] = dense64_lds_bytes(nvec_a, 1, false);
-        mf_lds_grad[1] = dense64_lds_bytes(nvec_b, 2, true);
-        mf_lds_loss[1] = dense64_lds_bytes(nvec_b, 2, false);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[1]));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[1]));
+        mf_lds_grad[0] = std::max(dense64_lds_bytes(nvec_a, 1, true), dense64_lds_bytes(nvec_b, 2, true));
+        mf_lds_loss[0] = std::max(dense64_lds_bytes(nvec_a, 1, false), dense64_lds_bytes(nvec_b, 2, false));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
         mf_ok = true;
       }
     }
@@ -895,15 +883,8 @@ struct SolverT final : cal_solver {
   }
   // the dense pass: panels with more than four vector tiles (kernel instance with eight accumulator tiles per wave), then the rest
   template <bool GRAD> void launch_dense(Dense64Args m) {
-    const size_t* lds = GRAD ? mf_lds_grad : mf_lds_loss;
-    if (mf_split > 0) {
-      m.panel_base = 0;
-      hipLaunchKernelGGL((fused_dense64_kernel<GRAD, 1, 16>), dim3(mf_split), dim3(kDenseThreads), lds[0], stream, m);
-    }
-    if (mf_npanels > mf_split) {
-      m.panel_base = mf_split;
-      hipLaunchKernelGGL((fused_dense64_kernel<GRAD, 2, 8>), dim3(mf_npanels - mf_split), dim3(kDenseThreads), lds[1], stream, m);
-    }
+    m.panel_base = 0;
+    hipLaunchKernelGGL((fused_dense64_kernel<GRAD>), dim3(mf_npanels), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
   }
   template <bool GRAD> void launch_dense(MfmaArgs m) {
     m.panel_base = 0;
@@ -940,10 +921,6 @@ struct SolverT final : cal_solver {
         typename std::conditional<std::is_same<T, float>::value, MfmaArgs, Dense64Args>::type m{};
         m.ops = mf_ops.as<T>();
         m.panels = mf_panels.as<PanelItem>();
-        if constexpr (!std::is_same<T, float>::value) {
-          m.bl_ant = bl_ant.as<int2>();
-          m.bl_coff = mf_bl_coff.as<int>();
-        }
         m.data_r = data_r.as<T>();
         m.data_i = data_i.as<T>();
         m.wgts = wgts.as<T>();
@@ -1240,7 +1217,7 @@ struct SolverT final : cal_solver {
     const DevBuf* all[] = {&tiles, &bl_tile, &bl_ant, &items, &ant_ptr, &ant_ent, &coef_grp, &grp_coff, &grp_item_ptr, &item_goff,
                            &data_r, &data_i, &wgts, &gains, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
                            &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf,
-                           &mf_ops, &mf_panels, &mf_bl_coff};
+                           &mf_ops, &mf_panels};
     int64_t n = 0;
     for (auto* d : all) n += (int64_t)d->bytes;
     *b = n;

@@ -28,8 +28,6 @@ constexpr int kVT64 = 16;    // vectors per gradient tile
 struct Dense64Args {
   const double* ops;           // packed operands of every basis block
   const PanelItem* panels;     // bl[0 .. 8 NC)
-  const int2* bl_ant;
-  const int* bl_coff;
   const double* data_r;        // [nbls + 1][fpad]
   const double* data_i;
   const double* wgts;
@@ -56,12 +54,11 @@ __device__ __forceinline__ double swap8(double x) {  // the value of lane l ^ 8 
 }
 
 template <bool GRAD, int NC, int NTMAX>
-__global__ __launch_bounds__(kDenseThreads, 2) void fused_dense64_kernel(const Dense64Args A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned char* smem_raw) {
   constexpr int kRing = GRAD ? 8 : 4;
-  if (A.state->done | A.state->done_after) return;
   const int panel_idx = A.panel_base + (int)blockIdx.x;
   const PanelItem& P = A.panels[panel_idx];
+  const int stopped = A.state->done | A.state->done_after;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,17 +73,32 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense64_kernel(const D
   unsigned char* s_ring = smem_raw;                                                // [4 waves][kRing][1 KB]
   double* s_red = reinterpret_cast<double*>(smem_raw + 4 * kRing * 1024);          // [4 waves][3]
   double* s_c = reinterpret_cast<double*>(smem_raw + 4 * kRing * 1024 + 128);      // [NC][ngk][64 lanes][2]
+  if (stopped) return;
   {
-    // coefficient operand of column tile c: s_c[((c * ngk + p) * 64 + lane) * 2 + u] = C[col = lane & 15][vector 8 p + 4 u + (lane >> 4)]
-    const int n = NC * ngk * 128;
-    for (int i = tid; i < n; i += kDenseThreads) {
-      const int u = i & 1, l = (i >> 1) & 63, r = i >> 7;
-      const int p = r % ngk, c = r / ngk;
-      const int cj = l & 15, k = 8 * p + 4 * u + (l >> 4);
-      const int b = P.bl[c * 8 + (cj & 7)];
-      double v = 0.0;
-      if (b >= 0 && k < nvec) v = (cj < 8 ? A.c_r : A.c_i)[A.bl_coff[b] + k];
-      s_c[i] = v;
+    // coefficient operand of column tile c: s_c[((c * ngk + p) * 64 + lane) * 2 + u] = C[col = lane & 15][vector 8 p + 4 u + (lane >> 4)].
+    // Thread tid fills (u, lane) = (tid & 1, (tid >> 1) & 63) of the positions p = (tid >> 7) + 2 j of every tile: its column
+    // is fixed per tile, the slot table is read once, and the loads of a tile's positions go out in batches of eight,
+    // unconditionally (clamped index; a load behind a branch costs a round trip each)
+    const int u = tid & 1, l = (tid >> 1) & 63, cj = l & 15;
+    const int k0 = 4 * u + (l >> 4);
+    const int klast = nvec - 1;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int fb = P.bl[c * 8 + (cj & 7)];
+      const double* src = (cj < 8 ? A.c_r : A.c_i) + P.coff[c * 8 + (cj & 7)];
+      for (int p0 = tid >> 7; p0 < ngk; p0 += 16) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 8 * (p0 + 2 * j) + k0;
+          v[j] = src[k < klast ? k : klast];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int p = p0 + 2 * j, k = 8 * p + k0;
+          if (p < ngk) s_c[((c * ngk + p) * 64 + l) * 2 + u] = (fb >= 0 && k < nvec) ? v[j] : 0.0;
+        }
+      }
     }
   }
   // this lane's slots (one per column tile): sample row and antenna pair as 32-bit BYTE offsets from the kernel-argument bases
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense64_kernel(const D
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     my_bl[c] = P.bl[c * 8 + (col & 7)];
-    const int2 ant = my_bl[c] >= 0 ? A.bl_ant[my_bl[c]] : make_int2(0, 0);
+    const int2 ant = P.ant[c * 8 + (col & 7)];
     const unsigned row = (unsigned)(my_bl[c] >= 0 ? my_bl[c] : A.nbls);
     ob[c] = (row * (unsigned)A.fpad + (unsigned)kq + 4u * pl) * 8u;              // double arrays
     og0[c] = ((unsigned)ant.x * (unsigned)A.fpad + (unsigned)kq + 4u * pl) * 16u;  // double2 arrays
@@ -286,31 +298,50 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense64_kernel(const D
     A.part[pi + 2] = s_red[2] + s_red[5] + s_red[8] + s_red[11];
   }
   if (!GRAD) return;
-  // each wave holds the sums over ITS channel blocks; tile by tile the four parts meet in the (now idle) ring area and one
-  // wave adds them in wave order and stores the tile
-  double* s_x = reinterpret_cast<double*>(s_ring);  // [4 waves][4 elements][64 lanes] = 8 KB
+  // each wave holds the sums over ITS channel blocks; eight tiles at a time the four parts meet in the (now idle) ring area
+  // ([8 tiles][4 waves][4 elements][64 lanes] doubles = 64 KB would not fit: [4 tiles] = 32 KB does) and ALL 256 threads add
+  // them, in wave order: thread (tile tid >> 6, column tid & 15, quarter (tid >> 4) & 3) owns the 4 consecutive vectors
+  // 4 quarter .. + 3 of its column -- element `quarter` of the four lanes kq = 0..3 -- and stores them as one run
+  double* s_x = reinterpret_cast<double*>(s_ring);
+  const int e_tile = tid >> 6, e_q = (tid >> 4) & 3;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    const int coff = my_bl[c] >= 0 ? A.bl_coff[my_bl[c]] : 0;
-    double* gc = im_lane ? A.gc_i : A.gc_r;
+    double* gc = (im_lane ? A.gc_i : A.gc_r) + P.coff[c * 8 + (col & 7)];  // the thread's column is its MFMA column: tid & 15 == lane & 15
 #pragma unroll
-    for (int t = 0; t < NTMAX; ++t) {
-      if (t < NT) {
+    for (int t0 = 0; t0 < NTMAX; t0 += 4) {
+      if (t0 < NT) {  // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_x[(wave * 4 + j) * 64 + lane] = dC[c][t][j];
+        for (int tt = 0; tt < 4; ++tt)
+          if (t0 + tt < NTMAX && t0 + tt < NT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_x[((tt * 4 + wave) * 4 + j) * 64 + lane] = dC[c][t0 + tt][j];
+          }
         __syncthreads();
-        if (wave == (t & 3) && my_bl[c] >= 0) {
+        const int t = t0 + e_tile;
+        if (t < NT && my_bl[c] >= 0) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int n = kVT64 * t + kq + 4 * j;
-            const double v = ((s_x[(0 * 4 + j) * 64 + lane] + s_x[(1 * 4 + j) * 64 + lane]) + s_x[(2 * 4 + j) * 64 + lane]) + s_x[(3 * 4 + j) * 64 + lane];
-            if (n < nvec) gc[coff + n] = v;
+          for (int kk = 0; kk < 4; ++kk) {
+            const double* px = s_x + ((e_tile * 4) * 4 + e_q) * 64 + col + 16 * kk;
+            const double v = ((px[0] + px[4 * 64]) + px[2 * 4 * 64]) + px[3 * 4 * 64];
+            const int n = kVT64 * t + 4 * e_q + kk;
+            if (n < nvec) gc[n] = v;
           }
         }
         __syncthreads();
       }
     }
   }
+}
+
+// One launch for all panels, heaviest first: blocks of more than 128 vectors with one column tile (8 baselines, 16
+// gradient tiles), the others with two (16 baselines, 8 tiles) -- see dense_kernels.hpp
+template <bool GRAD>
+__global__ __launch_bounds__(kDenseThreads, 2) void fused_dense64_kernel(const Dense64Args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (A.panels[A.panel_base + (int)blockIdx.x].nvec > 128)
+    dense64_panel<GRAD, 1, 16>(A, smem_raw);
+  else
+    dense64_panel<GRAD, 2, 8>(A, smem_raw);
 }
 
 inline size_t dense64_lds_bytes(int nvec_max, int nc, bool grad) {
