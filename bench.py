@@ -202,10 +202,23 @@ def torch_sum_float(dist, vals):
     return t.numpy()
 
 
-def dense_rooflines(prob, tim, kernel_ms, dtype):
+def dense_traffic(config, dtype):
+    """HBM bytes per gradient launch of the dense kernel from the committed counter summary (tools/prof_dense.sh +
+    tools/dense_pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes) -- only if it was measured on these kernel sources."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{config}_{'f32' if dtype == np.float32 else 'f64'}_shared.json")
+    if not os.path.exists(path):
+        return None, None
+    pmc = json.load(open(path))
+    if pmc.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"{os.path.relpath(path, ROOT)} is stale (measured on other kernel sources): not reported"
+    return pmc.get("gradient_pass", {}).get("hbm_bytes"), os.path.relpath(path, ROOT)
+
+
+def dense_rooflines(prob, tim, kernel_ms, dtype, config=None):
     """Both bounds of the dense (shared-layout) kernel from its measured launch duration: the matrix pipe for
     8 F sum nvec flops, and HBM for the algorithmic bytes with every DISTINCT basis block counted once."""
     f32 = dtype == np.float32
+    traffic, traffic_src = dense_traffic(config, dtype) if config else (None, None)
     peak = MFMA_F32_PEAK_TFLOPS if f32 else MFMA_F64_PEAK_TFLOPS
     flops = tim["flops_per_launch"]
     tf = flops / (kernel_ms * 1e-3) / 1e12
@@ -215,7 +228,8 @@ def dense_rooflines(prob, tim, kernel_ms, dtype):
     return {
         "kernel": "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)" if f32 else "fused_dense64_kernel<GRAD> (v_mfma_f64_16x16x4_f64)",
         "kernel_ms": kernel_ms,
-        "roofline_mfma": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "flops_per_launch": flops},
+        "roofline_mfma": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "flops_per_launch": flops,
+                          "traffic": traffic, "traffic_source": traffic_src},
         "roofline_hbm_unique_basis": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_launch": bytes_unique},
     }
@@ -333,7 +347,7 @@ def main():
         dt2 = time.perf_counter() - t2
         tim2 = s2.timing_get()
         k2 = tim2["total_ms"] / max(tim2["launches"], 1)
-        shared = dense_rooflines(prob, tim2, k2, dtype)
+        shared = dense_rooflines(prob, tim2, k2, dtype, args.config if args.max_bls is None else None)
         shared.update(steps_per_s=args.steps / dt2, ms_per_step=dt2 / args.steps * 1e3, device_memory_GB=s2.memory_bytes() / 1e9)
         s2.close()
 
@@ -414,8 +428,8 @@ def main():
         }
         if tim["kernel_path"] == "dense":
             # the shared layout's dense kernel is bound by the matrix pipe, not by HBM: lead with that roofline
-            d = dense_rooflines(prob, tim, kern_ms, dtype)
-            roofline = dict(d["roofline_mfma"], kernel=d["kernel"], kernel_ms=kern_ms, traffic=None, peak_measured=peaks,
+            d = dense_rooflines(prob, tim, kern_ms, dtype, args.config if (not sharded and args.max_bls is None and args.reg == "none") else None)
+            roofline = dict(d["roofline_mfma"], kernel=d["kernel"], kernel_ms=kern_ms, peak_measured=peaks,
                             hbm_unique_basis=d["roofline_hbm_unique_basis"])
         else:
             roofline = hbm_roofline
