@@ -875,8 +875,12 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
     return;
   }
   __shared__ T s_part[3][3][64][2 * CPL];  // [segment 1..3][sum 0..2][lane][components]
-  const int a = blockIdx.x / cblocks;
-  const int cb = blockIdx.x - a * cblocks;
+  // channel-block-major grid: the two antennas of a baseline read the same piece of its gbar_G row, and with all the
+  // antennas of one channel block next to each other in dispatch order the second read finds it in the Infinity Cache
+  // (antenna-major, the two reads of a row are up to the whole array apart: they both came from HBM, 0.30 -> 0.2 ms
+  // behind the streaming kernel at HERA-350)
+  const int cb = blockIdx.x / nants;
+  const int a = blockIdx.x - cb * nants;
   const int lane = threadIdx.x & 63;
   const int seg = threadIdx.x >> 6;
   const int f = (cb * 64 + lane) * CPL;
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
   const int per = (e1 - e0 + 3) >> 2;
   const int eb = e0 + seg * per, ee = min(e1, eb + per);
   if (ok) {
-#pragma unroll 4
+#pragma unroll 8  // eight rows' loads in flight per wave (4: 25 us slower behind the streaming kernel at HERA-350; one channel per lane: 50 us slower)
     for (int e = eb; e < ee; ++e) {
       const int2 ent = ant_ent[e];  // (bl * 2 + role, other antenna): wave-uniform
       const int bl = ent.x >> 1;
