@@ -158,6 +158,32 @@ def test_loop_controls_tol_usemin_freeze():
     np.testing.assert_array_equal(c_r, start["c_r"])
 
 
+def test_fp32_fit_stops_on_stagnation():
+    """calibration.py:712 compares the float32 values loss.numpy() returns in a float32 fit: with the default tol = 1e-14
+    such a fit stops when two consecutive float32 losses are EQUAL (the reference's usual way out of the loop).  Noisy data
+    keep the loss of order one, where float32 resolves 1e-8: the double-accumulated losses the library records still
+    differ by far more than tol at the stopping step, and a float64 fit of the same problem keeps going."""
+    p, start = make_case(seed=11, perturb=True)
+    rng = np.random.default_rng(5)
+    p.data_r = p.data_r + 0.3 * rng.standard_normal(p.data_r.shape)
+    p.data_i = p.data_i + 0.3 * rng.standard_normal(p.data_i.shape)
+    s = make_solver(p, start, np.float32)
+    s.set_optimizer("Adam", learning_rate=1e-2)
+    s.run(1, record=False)
+    losses, stopped, nupd = s.run(20000, record=True, tol=1e-14)
+    assert stopped and 2 <= len(losses) < 20000 and nupd == len(losses)
+    l32 = np.float32(losses)
+    assert l32[-1] == l32[-2] and abs(losses[-1] - losses[-2]) > 1e-14
+    assert not np.any(l32[1:-1] == l32[:-2])  # ... and it is the FIRST such pair
+    s.close()
+    s = make_solver(p, start, np.float64)
+    s.set_optimizer("Adam", learning_rate=1e-2)
+    s.run(1, record=False)
+    l64, stopped64, _ = s.run(len(losses) + 50, record=True, tol=1e-14)
+    assert not stopped64 and len(l64) == len(losses) + 50
+    s.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_model_and_init_coeffs(dtype):
     p, start = make_case(seed=9, nants=8, nfreqs=52)
