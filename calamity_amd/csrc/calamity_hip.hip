@@ -504,10 +504,16 @@ struct SolverT final : cal_solver {
       if (d->grp_bl_start[g + 1] - d->grp_bl_start[g] == 1) total_tiles += fpad / fb_u[d->grp_basis[g]];
     // one item per group when the groups alone fill the chip (256 CUs x ~4 resident workgroups, several waves of them);
     // otherwise split groups along their tiles (partial coefficient gradients are summed by coeff_partial_reduce_kernel)
+    // With at least one group per CU an item is never smaller than 1024 channels of its group (8 tiles of the widest fp32
+    // shape, 16 of the widest fp64 one): a group of up to 56 vectors is then ONE item -- no partial coefficient gradients,
+    // no second launch to sum them -- and only wider groups (narrower tiles) are cut, which also evens the items out.
+    // Measured at HERA-37 (666 groups): fp64 76 -> 61 us per step, fp32 45 -> 42; cutting every group into 4-tile items
+    // (the earlier rule) bought parallelism the chip did not need and paid a prologue and a reduction for it.
     const long long target_items = 8192;
     const bool groups_fill_chip = nsimple_grps >= 2048;
+    const long long min_tiles = nsimple_grps >= 256 ? 1024 / FbSet<T>::fb_max : 4;
     const long long tiles_per_item = groups_fill_chip ? std::max<long long>(64, 4 * total_tiles / std::max(1, nsimple_grps))
-                                                      : std::max<long long>(4, total_tiles / target_items);
+                                                      : std::max<long long>(min_tiles, total_tiles / target_items);
     std::vector<Item> h_items;
     std::vector<int> h_grp_item_ptr(ngrps + 1, 0);
     gc_direct = true;
