@@ -372,8 +372,8 @@ struct SolverT final : cal_solver {
         std::vector<int> uorder(nbasis);
         std::iota(uorder.begin(), uorder.end(), 0);
         std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
-        // Two launch classes: panels with more than four vector tiles first, then the rest; inside a class the heaviest
-        // panels come first (the hardware dispatches workgroups in index order, so the tail is made of the lightest).
+        // Panels of more than four vector tiles first, then the rest (two bodies of ONE launch); inside a class the
+        // heaviest panels come first (the hardware dispatches workgroups in index order, so the tail is made of the lightest).
         // Per-XCD panel lists (all panels of a basis block on one XCD, its packed operands L2-resident there: the L2 hit
         // rate of the operand requests is only 55-65 % without them) measured 3-5 % SLOWER with every generation of this
         // kernel: panels of one block then walk the same lines in step.
@@ -411,22 +411,19 @@ struct SolverT final : cal_solver {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
         mf_ok = true;
       } else {
-        // ---- double precision: v_mfma_f64_16x16x4_f64 (dense64_kernels.hpp).  Two launch classes: blocks of more than 128
-        // vectors with panels of 8 baselines (one column tile, 16 gradient tiles), the rest with panels of 16 (two column tiles)
-        std::vector<long long> okf(nbasis + 1, 0), ofk(nbasis + 1, 0);
+        // ---- double precision: v_mfma_f64_16x16x4_f64 (dense64_kernels.hpp).  Two panel classes (bodies of one launch): blocks
+        // of more than 128 vectors with panels of 8 baselines (one column tile, 16 gradient tiles), the rest with panels of 16
+        std::vector<long long> okf(nbasis + 1, 0);
         int nvec_a = 0, nvec_b = 0;
         for (int u = 0; u < nbasis; ++u) {
           const int nv = d->basis_nvec[u];
           (nv > 128 ? nvec_a : nvec_b) = std::max(nv > 128 ? nvec_a : nvec_b, nv);
-          okf[u + 1] = okf[u] + (long long)(fpad / kCB64) * ((nv + 7) / 8) * 128;
-          ofk[u + 1] = ofk[u] + (long long)(fpad / kCB64) * ((nv + kVT64 - 1) / kVT64) * 2 * 128;
+          okf[u + 1] = okf[u] + (long long)(fpad / kCB64) * ((nv + 7) / 8 + (nv + kVT64 - 1) / kVT64 * 2) * 128;
         }
-        for (int u = 0; u <= nbasis; ++u) ofk[u] += okf[nbasis];
-        CAL_TRY(mf_ops.alloc((size_t)ofk[nbasis] * sizeof(double), false));
+        CAL_TRY(mf_ops.alloc((size_t)okf[nbasis] * sizeof(double), false));
         for (int u = 0; u < nbasis; ++u)
-          hipLaunchKernelGGL(mfma_pack64_kernel, dim3(grid_for(okf[u + 1] - okf[u] + ofk[u + 1] - ofk[u])), dim3(256), 0, stream,
-                             raw.as<double>() + d->basis_offset[u], mf_ops.as<double>() + okf[u], mf_ops.as<double>() + ofk[u], nfreqs, fpad,
-                             d->basis_nvec[u]);
+          hipLaunchKernelGGL(mfma_pack64_kernel, dim3(grid_for(okf[u + 1] - okf[u])), dim3(256), 0, stream,
+                             raw.as<double>() + d->basis_offset[u], mf_ops.as<double>() + okf[u], nfreqs, fpad, d->basis_nvec[u]);
         HIP_TRY(hipGetLastError());
         std::vector<std::vector<int>> by_u(nbasis);
         for (int b = 0; b < nbls; ++b) by_u[d->grp_basis[grp_of_bl[b]]].push_back(b);
@@ -448,7 +445,7 @@ struct SolverT final : cal_solver {
                 pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
               }
               pi.a_kf4 = okf[u];
-              pi.a_fk4 = ofk[u];
+              pi.a_fk4 = 0;
               pi.nvec = d->basis_nvec[u];
               h_panels.push_back(pi);
             }

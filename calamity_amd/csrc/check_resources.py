@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Build-time guard (called by the Makefile with hipcc's -Rpass-analysis=kernel-resource-usage remarks on stdin).
+
+The dense kernels consume their LDS-DMA operand ring behind COUNTED `s_waitcnt vmcnt(N)`: every vector-memory operation of
+a wave is in that count, and register spills are vector-memory operations (scratch).  A spilling build would therefore not
+just be slower, it would read ring slots before they have landed.  So: no scratch, no spills, in any kernel whose name
+contains `fused_dense`; and two waves per SIMD where the kernels are written for two."""
+import re
+import sys
+
+cur, bad, seen = None, [], 0
+for line in sys.stdin:
+    m = re.search(r"remark:\s+Function Name: (\S+)", line)
+    if m:
+        cur = m.group(1)
+        seen += "fused_dense" in cur
+        continue
+    if cur is None or "fused_dense" not in cur:
+        continue
+    m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|Occupancy \[waves/SIMD\]): (\d+)", line)
+    if not m:
+        continue
+    key, val = m.group(1), int(m.group(2))
+    if key.startswith("Occupancy"):
+        if val < 2:
+            bad.append(f"{cur}: occupancy {val} waves/SIMD (< 2)")
+    elif val != 0:
+        bad.append(f"{cur}: {key} = {val}")
+if seen == 0:
+    bad.append("no fused_dense kernel found in the compiler's resource remarks")
+if bad:
+    sys.stderr.write("check_resources: the dense kernels must not spill (scratch traffic breaks their counted waits):\n  " + "\n  ".join(bad) + "\n")
+    sys.exit(1)
+print(f"check_resources: {seen} dense kernels, no scratch, no spills")

@@ -55,7 +55,7 @@ __device__ __forceinline__ double swap8(double x) {  // the value of lane l ^ 8 
 
 template <bool GRAD, int NC, int NTMAX>
 __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned char* smem_raw) {
-  constexpr int kRing = GRAD ? 8 : 4;
+  constexpr int kRing = GRAD ? 8 : 4;  // powers of two (slot index by mask)
   const int panel_idx = A.panel_base + (int)blockIdx.x;
   const PanelItem& P = A.panels[panel_idx];
   const int stopped = A.state->done | A.state->done_after;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
 
   unsigned char* s_ring = smem_raw;                                                // [4 waves][kRing][1 KB]
   double* s_red = reinterpret_cast<double*>(smem_raw + 4 * kRing * 1024);          // [4 waves][3]
-  double* s_c = reinterpret_cast<double*>(smem_raw + 4 * kRing * 1024 + 128);      // [NC][ngk][64 lanes][2]
+  double* s_c = reinterpret_cast<double*>(smem_raw + 4 * kRing * 1024 + 128);      // [NC][ngk + 1][64 lanes][2] (one spare position per tile)
   if (stopped) return;
   {
     // coefficient operand of column tile c: s_c[((c * ngk + p) * 64 + lane) * 2 + u] = C[col = lane & 15][vector 8 p + 4 u + (lane >> 4)].
@@ -96,7 +96,7 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int p = p0 + 2 * j, k = 8 * p + k0;
-          if (p < ngk) s_c[((c * ngk + p) * 64 + l) * 2 + u] = (fb >= 0 && k < nvec) ? v[j] : 0.0;
+          if (p < ngk) s_c[((c * (ngk + 1) + p) * 64 + l) * 2 + u] = (fb >= 0 && k < nvec) ? v[j] : 0.0;
         }
       }
     }
@@ -118,46 +118,54 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
   __syncthreads();
 
   const f32x4_t* ops = reinterpret_cast<const f32x4_t*>(A.ops);
-  const unsigned fblk = (unsigned)P.a_kf4 * 8u, bblk = (unsigned)P.a_fk4 * 8u;  // byte offsets of this panel's two packed blocks
   const f64x2* sc2 = reinterpret_cast<const f64x2*>(s_c) + lane;
   const unsigned voff = (unsigned)lane * 16u;
   const unsigned ring_lds = (unsigned)reinterpret_cast<unsigned long long>(s_ring + wave * kRing * 1024);
   const f64x2* ring_rd = reinterpret_cast<const f64x2*>(s_ring + wave * kRing * 1024) + lane;
 
-  // the wave's operand stream (see dense_kernels.hpp): per channel block ngk forward positions, then 2 NT adjoint positions
-  const int nb_pos = GRAD ? 2 * NT : 0;
+  // the wave's operand stream (see dense_kernels.hpp): per channel block ngk forward positions, then 2 NT adjoint positions,
+  // stored in exactly that order, wave after wave (mfma_pack64_kernel): the gradient pass requests ONE contiguous run, the
+  // loss-only pass skips the adjoint positions; past the end the last position is requested again
+  const int nb_pos = 2 * NT;
   const int nper = ncb / 4;  // the row padding (a multiple of 128 channels) makes ncb a multiple of 4
   auto cb_of = [&](int n) { return wave + 4 * n; };
-  int rq_n = 0, rq_o = 0;
-  auto req_off = [&]() {
-    const int cbv = cb_of(rq_n < nper ? rq_n : nper - 1);
-    return rq_o < ngk ? fblk + (unsigned)(cbv * ngk + rq_o) * 1024u : bblk + (unsigned)(cbv * nb_pos + (rq_o - ngk)) * 1024u;
-  };
+  const unsigned wblk = (unsigned)P.a_kf4 * 8u + (unsigned)(wave * nper * (ngk + nb_pos)) * 1024u;  // byte offset of this wave's run
+  unsigned rq_off = wblk;
+  const unsigned rq_last = wblk + (unsigned)(nper * (ngk + nb_pos) - (GRAD ? 1 : nb_pos + 1)) * 1024u;
+  int rq_o = 0;
   auto req_advance = [&]() {
-    ++rq_o;
-    if (rq_o == ngk + nb_pos) { rq_o = 0; ++rq_n; }
+    if (GRAD) {
+      rq_off = rq_off < rq_last ? rq_off + 1024u : rq_last;
+    } else {
+      ++rq_o;
+      unsigned nxt = rq_off + 1024u;
+      if (rq_o == ngk) { rq_o = 0; nxt += (unsigned)nb_pos * 1024u; }
+      if (rq_off < rq_last) rq_off = nxt; else rq_o = 0;
+    }
   };
-  int cons = 0;
+  int cslot = 0;  // ring slot of the position the next step consumes
   f64x2 r_cur, r_nxt;
   for (int j = 0; j < kRing; ++j) {
-    ring_issue(ring_lds + (unsigned)j * 1024u, ops, voff, req_off());
+    ring_issue(ring_lds + (unsigned)j * 1024u, ops, voff, rq_off);
     req_advance();
   }
   RING_WAIT(kRing - 1);
   r_cur = ring_rd[0];
-#define STREAM_NEXT()                                      \
+#define STREAM_NEXT_INTO(R, RELAXED)                       \
   __builtin_amdgcn_sched_barrier(0);                       \
-  RING_WAIT(kRing - 2);                                    \
-  r_nxt = ring_rd[((cons + 1) & (kRing - 1)) * 64];        \
+  if (RELAXED) {                                           \
+    RING_WAIT(kRing - 2 + kSmpLoads);                      \
+  } else {                                                 \
+    RING_WAIT(kRing - 2);                                  \
+  }                                                        \
+  R = ring_rd[((cslot + 1) & (kRing - 1)) * 64];           \
   __builtin_amdgcn_sched_barrier(0);
 #define STREAM_REQ()                                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                             \
-  ring_issue(ring_lds + (unsigned)(cons & (kRing - 1)) * 1024u, ops, voff, req_off());           \
+  ring_issue(ring_lds + (unsigned)cslot * 1024u, ops, voff, rq_off);                             \
   req_advance();                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
-#define STREAM_ADVANCE() \
-  r_cur = r_nxt;         \
-  ++cons;
+#define STREAM_STEP() cslot = (cslot + 1) & (kRing - 1);
 
   f64x4 dC[NC][NTMAX];  // gradient tiles: lane (col, kq), element r -> vector 16 t + kq + 4 r
 #pragma unroll
@@ -183,8 +191,13 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
         S.w[c][i] = *reinterpret_cast<const double*>(p_w + o);
       }
   };
-  Samples S_cur, S_nxt;
-  load_samples(cb_of(0), S_nxt);
+  // ONE sample buffer, refilled behind the element stage that has just used it: a (current, next) pair carried around the
+  // block loop costs 24 more registers and is copied at the loop edge, behind a wait for the loads.  The refill (6 NC loads)
+  // is younger than the operand requests in flight, so the adjoint phase's first kRing - 1 waits leave it out of the count.
+  Samples S_cur;
+  load_samples(cb_of(0), S_cur);
+  constexpr int kSmpLoads = 6 * NC;
+  int relax = 0;
 
   for (int nb = 0; nb < nper; ++nb) {
     const int cb = cb_of(nb);
@@ -192,31 +205,38 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
     f64x4 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // the coefficient operand has a spare position behind its last, so the read-ahead needs no clamp
     f64x2 c_cur[NC], c_nxt[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) c_cur[c] = sc2[(c * ngk) * 64];
+    for (int c = 0; c < NC; ++c) c_cur[c] = sc2[(c * (ngk + 1)) * 64];
+    int gq = 0;
+#define F_POS64(RC, RN, CC, CN)                                                                                       \
+  acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(RC[0], CC[0][0], acc[0], 0, 0, 0);                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  ++gq;                                                                                                               \
+  _Pragma("unroll") for (int c = 0; c < NC; ++c) CN[c] = sc2[(c * (ngk + 1) + gq) * 64];                              \
+  __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(RC[1], CC[0][1], acc[0], 0, 0, 0);                                    \
+  STREAM_NEXT_INTO(RN, !GRAD && relax > 0)                                                                            \
+  if (!GRAD && relax > 0) --relax;                                                                                    \
+  if (NC > 1) acc[NC - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(RC[0], CC[NC - 1][0], acc[NC - 1], 0, 0, 0);         \
+  STREAM_REQ()                                                                                                        \
+  if (NC > 1) acc[NC - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(RC[1], CC[NC - 1][1], acc[NC - 1], 0, 0, 0);         \
+  __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  STREAM_STEP()
+    // (one position per trip: with the operand registers of two positions live the gradient pass spills, and scratch
+    // traffic is vector-memory traffic -- it would break the counted waits of the ring)
     for (int g = 0; g < ngk; ++g) {
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[0], c_cur[0][0], acc[0], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int c = 0; c < NC; ++c) c_nxt[c] = sc2[(c * ngk + (g + 1 < ngk ? g + 1 : ngk - 1)) * 64];
-      __builtin_amdgcn_sched_barrier(0);
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[1], c_cur[0][1], acc[0], 0, 0, 0);
-      STREAM_NEXT()
-      if (NC > 1) acc[NC - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[0], c_cur[NC - 1][0], acc[NC - 1], 0, 0, 0);
-      STREAM_REQ()
-      if (NC > 1) acc[NC - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[1], c_cur[NC - 1][1], acc[NC - 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      STREAM_ADVANCE()
+      F_POS64(r_cur, r_nxt, c_cur, c_nxt)
+      r_cur = r_nxt;
 #pragma unroll
       for (int c = 0; c < NC; ++c) c_cur[c] = c_nxt[c];
     }
+#undef F_POS64
     // acc[c][r] of lane (col, kq) = v(channel 16 cb + kq + 4 r) of column col of tile c
 
     // ---- E: element-wise; per column tile the re lane evaluates channels r = 0, 1 and the im lane r = 2, 3 (see the header)
     const unsigned cb16 = (unsigned)cb * (kCB64 * 16u);
-    S_cur = S_nxt;
-    if (nb + 1 < nper) load_samples(cb_of(nb + 1), S_nxt);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -254,18 +274,25 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
       }
     }
 
+    // the next block's samples (the last block loads itself again: the count of loads in flight stays what the waits assume)
+    __builtin_amdgcn_sched_barrier(0);
+    load_samples(cb_of(nb + 1 < nper ? nb + 1 : nb), S_cur);
+    if (!GRAD) relax = kRing - 1;  // loss-only pass: the waits that skip the refill are the next forward positions
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- B: rows = vectors of tile t, cols = (slot, re | im), K = this block's channels; position = (tile, half v): r = 2 v, 2 v + 1
     if (GRAD) {
 #define B_POS64(T, V)                                                                                                 \
   dC[0][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[0], acc[0][2 * (V) + 0], dC[0][T], 0, 0, 0);                    \
   __builtin_amdgcn_sched_barrier(0);                                                                                  \
   dC[0][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[1], acc[0][2 * (V) + 1], dC[0][T], 0, 0, 0);                    \
-  STREAM_NEXT()                                                                                                       \
+  STREAM_NEXT_INTO(r_nxt, 2 * (T) + (V) < kRing - 1)                                                                  \
   if (NC > 1) dC[NC - 1][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[0], acc[NC - 1][2 * (V) + 0], dC[NC - 1][T], 0, 0, 0); \
   STREAM_REQ()                                                                                                        \
   if (NC > 1) dC[NC - 1][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_cur[1], acc[NC - 1][2 * (V) + 1], dC[NC - 1][T], 0, 0, 0); \
   __builtin_amdgcn_sched_barrier(0);                                                                                  \
-  STREAM_ADVANCE()
+  r_cur = r_nxt;                                                                                                      \
+  STREAM_STEP()
 #pragma unroll
       for (int t = 0; t < NTMAX; ++t) {
         if (t < NT) {  // wave-uniform
@@ -276,9 +303,9 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
 #undef B_POS64
     }
   }
-#undef STREAM_NEXT
+#undef STREAM_NEXT_INTO
 #undef STREAM_REQ
-#undef STREAM_ADVANCE
+#undef STREAM_STEP
   RING_WAIT(0);
 
   // ---- panel epilogue: loss partials (fixed order), then the coefficient gradients
@@ -345,32 +372,34 @@ __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense64_kernel(const D
 }
 
 inline size_t dense64_lds_bytes(int nvec_max, int nc, bool grad) {
-  return 4 * (size_t)(grad ? 8 : 4) * 1024 + 128 + (size_t)nc * ((nvec_max + 7) / 8) * 1024;
+  return 4 * (size_t)(grad ? 8 : 4) * 1024 + 128 + (size_t)nc * ((nvec_max + 7) / 8 + 1) * 1024;  // + the spare coefficient position per tile
 }
 
-// packed operands of the f64 kernel:
-//   forward [F/16][ceil(nvec/8)][64 lanes][2]: lane (i, kq), u -> A[16 cb + i][8 p + 4 u + kq]
-//   adjoint [F/16][NT][2][64 lanes][2]:        lane (i, kq), u -> A[16 cb + kq + 4 (2 v + u)][16 t + i]
-__global__ void mfma_pack64_kernel(const double* __restrict__ src, double* __restrict__ a_kf, double* __restrict__ a_fk, int nfreqs, int fpad, int nvec) {
+// packed operands of the f64 kernel, per basis block: wave after wave (w = 0..3), the wave's channel blocks cb = w + 4 n in
+// order, each as [ngk forward KB][2 NT adjoint KB] -- the order the kernel consumes:
+//   forward position p  [64 lanes][2]: lane (i, kq), u -> A[16 cb + i][8 p + 4 u + kq]
+//   adjoint position (t, v) [64 lanes][2]: lane (i, kq), u -> A[16 cb + kq + 4 (2 v + u)][16 t + i]
+__global__ void mfma_pack64_kernel(const double* __restrict__ src, double* __restrict__ dst, int nfreqs, int fpad, int nvec) {
   const int ngk = (nvec + 7) / 8, NT = (nvec + kVT64 - 1) / kVT64;
-  const long long n1 = (long long)(fpad / kCB64) * ngk * 128, n2 = (long long)(fpad / kCB64) * NT * 2 * 128;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * blockDim.x) {
-    if (i < n1) {
-      const int u = (int)(i & 1), l = (int)((i >> 1) & 63);
-      const long long r = i >> 7;
-      const int p = (int)(r % ngk), cb = (int)(r / ngk);
+  const int nper = fpad / (4 * kCB64);
+  const long long per_cb = (long long)(ngk + 2 * NT) * 128, total = per_cb * (fpad / kCB64);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cbp = (int)(i / per_cb);
+    const int r = (int)(i % per_cb);
+    const int cb = cbp / nper + 4 * (cbp % nper);
+    const int u = r & 1, l = (r >> 1) & 63;
+    double val = 0.0;
+    if (r < ngk * 128) {
+      const int p = r >> 7;
       const int f = cb * kCB64 + (l & 15), k = 8 * p + 4 * u + (l >> 4);
-      a_kf[i] = (f < nfreqs && k < nvec) ? src[(long long)f * nvec + k] : 0.0;
+      if (f < nfreqs && k < nvec) val = src[(long long)f * nvec + k];
     } else {
-      const long long q = i - n1;
-      const int u = (int)(q & 1), l = (int)((q >> 1) & 63);
-      long long r = q >> 7;
-      const int v = (int)(r & 1);
-      r >>= 1;
-      const int t = (int)(r % NT), cb = (int)(r / NT);
+      const int pos = (r >> 7) - ngk;
+      const int v = pos & 1, t = pos >> 1;
       const int f = kCB64 * cb + (l >> 4) + 4 * (2 * v + u), n = kVT64 * t + (l & 15);
-      a_fk[q] = (f < nfreqs && n < nvec) ? src[(long long)f * nvec + n] : 0.0;
+      if (f < nfreqs && n < nvec) val = src[(long long)f * nvec + n];
     }
+    dst[i] = val;
   }
 }
 
