@@ -239,10 +239,16 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
     const unsigned cb16 = (unsigned)cb * (kCB64 * 16u);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+      // the tile's four gain loads go out together (they come from L2: one round trip per tile, not one per channel pair)
+      double2 g0s[2], g1s[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const double2 g0 = *reinterpret_cast<const double2*>(p_g + (og0[c] + cb16 + 64u * i));
-        const double2 g1 = *reinterpret_cast<const double2*>(p_g + (og1[c] + cb16 + 64u * i));
+        g0s[i] = *reinterpret_cast<const double2*>(p_g + (og0[c] + cb16 + 64u * i));
+        g1s[i] = *reinterpret_cast<const double2*>(p_g + (og1[c] + cb16 + 64u * i));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const double2 g0 = g0s[i], g1 = g1s[i];
         // the re lane gets the imaginary part of channel i from its partner, the im lane the real part of channel i + 2
         const double mine_re = acc[c][i], mine_im = acc[c][i + 2];
         const double got = swap8(im_lane ? mine_re : mine_im);
