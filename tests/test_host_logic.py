@@ -239,3 +239,31 @@ def test_unknown_optimizer_is_a_keyerror():
     with pytest.raises(KeyError):
         OPTIMIZERS["Ftrl"]
     assert set(OPTIMIZERS) == {"Adam", "Adamax"}
+
+
+def test_build_guard_rejects_a_spilling_dense_kernel():
+    """calamity_amd/csrc/check_resources.py reads hipcc's -Rpass-analysis=kernel-resource-usage remarks in every build: a
+    dense kernel that uses scratch must fail it (scratch traffic would break the counted waits of its operand ring); other
+    kernels may spill."""
+    import subprocess
+    import sys
+
+    script = os.path.join(ROOT, "calamity_amd", "csrc", "check_resources.py")
+
+    def remarks(name, scratch, vspill, occ=2):
+        return (f"./x.hpp:1:1: remark: Function Name: {name} [-Rpass-analysis=kernel-resource-usage]\n"
+                f"./x.hpp:1:1: remark:     VGPRs: 250 [-Rpass-analysis=kernel-resource-usage]\n"
+                f"./x.hpp:1:1: remark:     ScratchSize [bytes/lane]: {scratch} [-Rpass-analysis=kernel-resource-usage]\n"
+                f"./x.hpp:1:1: remark:     Occupancy [waves/SIMD]: {occ} [-Rpass-analysis=kernel-resource-usage]\n"
+                f"./x.hpp:1:1: remark:     SGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+                f"./x.hpp:1:1: remark:     VGPRs Spill: {vspill} [-Rpass-analysis=kernel-resource-usage]\n")
+
+    def run(text):
+        return subprocess.run([sys.executable, script], input=text, capture_output=True, text=True)
+
+    ok = run(remarks("_ZN4calk18fused_dense_kernelILb1EEEvNS_8MfmaArgsE", 0, 0) + remarks("_ZN4calk12adam2_kernelIfLi0EEEv", 16, 4))
+    assert ok.returncode == 0, ok.stderr
+    bad = run(remarks("_ZN4calk20fused_dense64_kernelILb1EEEvNS_11Dense64ArgsE", 8, 1))
+    assert bad.returncode != 0 and "fused_dense64_kernel" in bad.stderr and "VGPRs Spill = 1" in bad.stderr
+    assert run(remarks("_ZN4calk18fused_dense_kernelILb1EEEvNS_8MfmaArgsE", 0, 0, occ=1)).returncode != 0
+    assert run(remarks("_ZN4calk12adam2_kernelIfLi0EEEv", 0, 0)).returncode != 0  # no dense kernel in the log at all
