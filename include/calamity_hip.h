@@ -108,7 +108,7 @@ typedef struct cal_run_result {
   int32_t reserved;
 } cal_run_result;
 
-typedef struct cal_kernel_timing { /* HIP-event timing of the fused basis-streaming kernel (bench.py roofline) */
+typedef struct cal_kernel_timing { /* HIP-event timing of the dominant kernel of a pass: the fused basis-streaming kernel or the dense kernel (bench.py roofline) */
   int64_t launches;
   double total_ms;
   double algorithmic_bytes_per_launch; /* SURVEY.md 8(d) B_step figure restated for this problem */
