@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="hera350", choices=["hera350", "hera37", "tutorial"])
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
-    ap.add_argument("--layout", default="stream", choices=["stream", "shared"])
+    ap.add_argument("--layout", default=None, choices=["stream", "shared"],
+                    help="basis layout; default: stream for hera350 (the headline: every baseline owns its tiles), shared (the product default) for the small configurations")
     ap.add_argument("--optimizer", default="Adam")
     ap.add_argument("--reg", default="none", choices=["none", "sum"])
     ap.add_argument("--max-bls", type=int, default=None, help="bounded sample of the baselines (debugging)")
@@ -237,6 +238,8 @@ def dense_rooflines(prob, tim, kernel_ms, dtype, config=None):
 
 def main():
     args = parse()
+    if args.layout is None:
+        args.layout = "stream" if args.config == "hera350" else "shared"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -304,13 +307,22 @@ def main():
         return [s.run(n, record=record, tol=0.0)[0] for s in solvers][0]
 
     run_steps(args.warmup, False) if args.warmup > 0 else None
+    # Problems whose step is tens of microseconds are replayed from a hipGraph (two launches per step); HIP events around
+    # every fused pass would force launch-by-launch issue, so for those the kernel duration is measured in a second pass
+    # right after the timed one.  The headline keeps its events inside the timed region (they cost < 0.1 % of a 4.8-ms step).
+    launch_bound = args.config != "hera350"
     for s in solvers:
-        s.timing_enable(True)
+        s.timing_enable(not launch_bound)
     sync()
     t0 = time.perf_counter()
     timed_losses = run_steps(args.steps, True)
     sync()
     dt = time.perf_counter() - t0
+    if launch_bound:
+        for s in solvers:
+            s.timing_enable(True)
+        run_steps(min(args.steps, 200), False)
+        sync()
     if dist is not None:
         import torch
 
@@ -412,8 +424,10 @@ def main():
                         traffic, traffic_src = v["hbm_bytes"], os.path.relpath(pmc_path, ROOT)
             else:
                 traffic_src = f"{os.path.relpath(pmc_path, ROOT)} is stale (measured on other kernel sources): not reported"
+        cache_resident = tim["algorithmic_bytes_per_launch"] < 200e6  # the working set sits in the 256 MB Infinity Cache
         hbm_roofline = {
-            "bound": "hbm",
+            "bound": "hbm" if not cache_resident else "launch latency (a {:.0f} MB working set lives in the 256 MB Infinity Cache: 'achieved' is cache "
+                     "bandwidth, not an HBM figure; the step is bounded by the launches it takes)".format(tim["algorithmic_bytes_per_launch"] / 1e6),
             "kernel": "fused_basis_kernel<MODE_GRAD>",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

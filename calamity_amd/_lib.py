@@ -7,13 +7,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CALAMITY_HIP_LIB") or os.path.join(_HERE, "csrc", "libcalamity_hip.so")  # env override: kernel experiments
+LIB_PATH = os.path.join(_HERE, "csrc", "libcalamity_hip.so")  # the one shipped build; experiment harnesses (tools/) assign this attribute before load()
 
 CAL_F32, CAL_F64 = 0, 1
 CAL_OPT_ADAM, CAL_OPT_ADAMAX = 0, 1
 CAL_REG_NONE, CAL_REG_SUM = 0, 1
 CAL_LAYOUT_STREAM, CAL_LAYOUT_SHARED = 0, 1
 CAL_PATH_AUTO, CAL_PATH_GENERAL, CAL_PATH_DENSE = 0, 1, 2
+CAL_LAUNCH_AUTO, CAL_LAUNCH_KERNELS, CAL_LAUNCH_ONE_TAIL, CAL_LAUNCH_GRAPH = 0, 1, 2, 3
 CAL_COMM_ID_BYTES = 128
 CAL_ERR_NONFINITE = -6
 
@@ -100,6 +101,7 @@ SYMBOLS = {
     "cal_solver_model": (C.c_int, [_P, _P, _P]),
     "cal_solver_init_coeffs": (C.c_int, [_P, _P, _P]),
     "cal_solver_synchronize": (C.c_int, [_P]),
+    "cal_solver_set_launch_mode": (C.c_int, [_P, C.c_int]),
     "cal_solver_timing_enable": (C.c_int, [_P, C.c_int]),
     "cal_solver_timing_get": (C.c_int, [_P, C.POINTER(KernelTiming)]),
     "cal_solver_memory_bytes": (C.c_int, [_P, C.POINTER(C.c_int64)]),

@@ -114,6 +114,7 @@ struct cal_solver {
   virtual int timing_get(cal_kernel_timing* out) = 0;
   virtual int memory_bytes(int64_t* b) = 0;
   virtual int comm_init(const void* id, int rank, int nranks) = 0;
+  virtual int set_launch_mode(int mode) = 0;
 };
 
 template <typename T>
@@ -134,6 +135,7 @@ struct SolverT final : cal_solver {
   DevBuf tiles, bl_tile, bl_ant, runs, items, ant_ptr, ant_ent, coef_grp, grp_coff, grp_item_ptr, item_goff;
   DevBuf data_r, data_i, wgts;
   DevBuf gains, gains_m, gains_v, gains_snap;  // [nants][fpad] T2
+  DevBuf gains_alt;                            // one-launch tail (step_tail_kernel): gains are read from one buffer and written to the other; `gains` is always the current one
   DevBuf coef, coef_m, coef_v, coef_snap;      // [2][ncoef] T (r plane then i plane)
   DevBuf q0, q1, comm;                         // comm: r0 | r1 | r2 (gain gradient parts), contiguous for the all-reduce
   DevBuf scal;                                 // 4 doubles: loss, s_r, s_i
@@ -142,10 +144,23 @@ struct SolverT final : cal_solver {
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
-  int mf_split = 0;                            // panels [0, mf_split) are of the wide class (more vector tiles: the kernel body with more accumulators)
+  DevBuf mf_map;                               // [mf_grid] workgroup -> panel (-1: empty slot): XCD-affine dispatch of the dense launch
+  int mf_grid = 0;
   size_t mf_lds_grad[2] = {0, 0}, mf_lds_loss[2] = {0, 0};  // per launch class
   bool mf_ok = false;
   int steps_per_sync = 1;                      // train steps enqueued between two host synchronisations of run()
+  // small problems: a train step is two launches (fused pass, step_tail_kernel), replayed kGraphSteps at a time from a hipGraph
+  int launch_mode = CAL_LAUNCH_AUTO;
+  static constexpr int kGraphSteps = 16;       // even: the double-buffered loop state and gains end a replay where they began
+  hipGraphExec_t graph_exec = nullptr;
+  struct GraphKey {
+    int optimizer, freeze, reg, losses_cap, st_par;
+    const void *gains, *snap, *losses;
+    bool operator==(const GraphKey& o) const {
+      return optimizer == o.optimizer && freeze == o.freeze && reg == o.reg && losses_cap == o.losses_cap && st_par == o.st_par &&
+             gains == o.gains && snap == o.snap && losses == o.losses;
+    }
+  } graph_key{};
   DevBuf agree_buf;
   DevState* h_state = nullptr;                 // pinned mirror
   int st_par = 0;                              // which half of `state` is current
@@ -168,6 +183,7 @@ struct SolverT final : cal_solver {
   ~SolverT() override {
     (void)hipSetDevice(device);
     if (nccl) (void)ncclCommDestroy(nccl);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     for (auto& e : ev_pool) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
@@ -212,9 +228,38 @@ struct SolverT final : cal_solver {
   }
 
   // ------------------------------------------------------------------------------------------------------------
+  // With a communicator attached, every decision a rank takes from its OWN shard and that changes what it exchanges must
+  // be taken by all ranks together -- and a rank whose set-up fails must not leave the others waiting in a collective.
+  // So the rank-local part (validation, eligibility, every allocation and upload: set_problem_local) contains no collective
+  // at all, and ONE agreement follows it on every path, failure included: the minimum over ranks of
+  // {set-up ok ? dense kernels built : -1, steps per host synchronisation}.  A negative minimum fails the call on every rank;
+  // a rank that built the dense path while another could not drops back to the general kernels (same buffers).
   int set_problem(const cal_problem_desc* d) override {
+    const int rc = set_problem_local(d);
+    if (!nccl) return rc;
+    const std::string msg = g_err;
+    int v[2] = {rc == CAL_OK ? (mf_ok ? 1 : 0) : -1, rc == CAL_OK ? steps_per_sync : (1 << 30)};
+    const int arc = agree_min(v, 2);
+    if (arc != CAL_OK) {
+      has_problem = false;
+      return arc;
+    }
+    if (rc != CAL_OK) {
+      g_err = msg;
+      return rc;
+    }
+    if (v[0] < 0) {
+      has_problem = false;
+      return fail(CAL_ERR_STATE, "set_problem failed on another rank of the communicator");
+    }
+    if (!v[0]) mf_ok = false;
+    steps_per_sync = v[1];
+    return CAL_OK;
+  }
+  int set_problem_local(const cal_problem_desc* d) {
     HIP_TRY(hipSetDevice(device));
     has_problem = has_data = has_gains = has_coef = false;
+    drop_graph();
     if (!d || d->nants <= 0 || d->nfreqs <= 0 || d->ngrps <= 0 || d->nbls <= 0 || d->nbasis <= 0)
       return fail(CAL_ERR_INVALID, "set_problem: non-positive dimension");
     if (!d->basis_offset || !d->basis_nvec || !d->basis_nrowblk || !d->basis_data || !d->grp_basis || !d->grp_bl_start ||
@@ -266,12 +311,9 @@ struct SolverT final : cal_solver {
                   "basis_nvec <= %d and nfreqs > 64", DenseCfg<T>::max_nvec);
     // a panel of 16 baselines occupies one CU for 60-70 us whatever the problem size; below ~2000 baselines the panels do
     // not fill the chip and the general kernel (one workgroup per baseline) is 2-3x faster (HERA-37 fp32: 25 vs 71 us)
-    bool want_mfma = dense_ok && d->kernel_path != CAL_PATH_GENERAL && (d->kernel_path == CAL_PATH_DENSE || nbls >= 2048);
-    if (nccl) {  // one path for all ranks: the exchange payload of the "sum" regulariser differs between the two
-      int v = want_mfma ? 1 : 0;
-      CAL_TRY(agree_min(v));
-      want_mfma = v != 0;
-    }
+    // (with a communicator the ranks then agree on ONE path -- the exchange payload of the "sum" regulariser differs between
+    // the two -- in set_problem, behind all the rank-local work)
+    const bool want_mfma = dense_ok && d->kernel_path != CAL_PATH_GENERAL && (d->kernel_path == CAL_PATH_DENSE || nbls >= 2048);
     lds_bytes = 0;
     for (int u = 0; u < nbasis; ++u) lds_bytes = std::max(lds_bytes, lds_for(fb_u[u]));
     for (int b = 0; b < d->nbls; ++b) {
@@ -378,32 +420,27 @@ struct SolverT final : cal_solver {
         // rate of the operand requests is only 55-65 % without them) measured 3-5 % SLOWER with every generation of this
         // kernel: panels of one block then walk the same lines in step.
         std::vector<PanelItem> h_panels;
-        mf_split = 0;
-        for (int cls = 0; cls < 2; ++cls) {
-          for (int u : uorder) {
-            if ((nvp32[u] > 128) != (cls == 0)) continue;
-            for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
-              PanelItem pi{};
-              for (int k = 0; k < kPanel; ++k) {
-                const int b = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
-                pi.bl[k] = b;
-                pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
-                pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
-              }
-              pi.a_kf4 = okf4[u];
-              pi.a_fk4 = 0;
-              pi.nvec = d->basis_nvec[u];
-              pi.nvp2 = nvp2[u];
-              pi.nvp32 = nvp32[u];
-              h_panels.push_back(pi);
+        std::vector<double> h_cost;
+        for (int u : uorder) {
+          for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
+            PanelItem pi{};
+            for (int k = 0; k < kPanel; ++k) {
+              const int b = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+              pi.bl[k] = b;
+              pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
+              pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
             }
+            pi.a_kf4 = okf4[u];
+            pi.a_fk4 = 0;
+            pi.nvec = d->basis_nvec[u];
+            pi.nvp2 = nvp2[u];
+            pi.nvp32 = nvp32[u];
+            h_panels.push_back(pi);
+            // a panel's time on a CU: a fixed part (prologue, element stage, epilogue) + its MFMA positions (stamps of the HERA-350 pass)
+            h_cost.push_back(60e3 + 600.0 * (fpad / kChunk) * ((d->basis_nvec[u] + 7) / 8 + nvp32[u] / 32 * 4));
           }
-          if (cls == 0) mf_split = (int)h_panels.size();
         }
-        mf_npanels = (int)h_panels.size();
-        CAL_TRY(mf_panels.alloc(h_panels.size() * sizeof(PanelItem), false));
-        HIP_TRY(hipMemcpyAsync(mf_panels.p, h_panels.data(), h_panels.size() * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        CAL_TRY(order_panels(h_panels, h_cost));
         // one launch serves both panel classes (up to 4 / up to 8 vector tiles): the larger of their LDS footprints
         mf_lds_grad[0] = std::max(dense_lds_bytes(nvec_max, true, nvec_max > 128 ? 8 : 4), dense_lds_bytes(std::min(nvec_max, 128), true, 4));
         mf_lds_loss[0] = std::max(dense_lds_bytes(nvec_max, false, nvec_max > 128 ? 8 : 4), dense_lds_bytes(std::min(nvec_max, 128), false, 4));
@@ -431,31 +468,25 @@ struct SolverT final : cal_solver {
         std::iota(uorder.begin(), uorder.end(), 0);
         std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
         std::vector<PanelItem> h_panels;
-        mf_split = 0;
-        for (int cls = 0; cls < 2; ++cls) {
-          const int width = cls == 0 ? 8 : 16;
-          for (int u : uorder) {
-            if ((d->basis_nvec[u] > 128) != (cls == 0)) continue;
-            for (size_t i = 0; i < by_u[u].size(); i += width) {
-              PanelItem pi{};
-              for (int k = 0; k < kPanel; ++k) {
-                const int b = k < width && i + k < by_u[u].size() ? by_u[u][i + k] : -1;
-                pi.bl[k] = b;
-                pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
-                pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
-              }
-              pi.a_kf4 = okf[u];
-              pi.a_fk4 = 0;
-              pi.nvec = d->basis_nvec[u];
-              h_panels.push_back(pi);
+        std::vector<double> h_cost;
+        for (int u : uorder) {
+          const int width = d->basis_nvec[u] > 128 ? 8 : 16;
+          for (size_t i = 0; i < by_u[u].size(); i += width) {
+            PanelItem pi{};
+            for (int k = 0; k < kPanel; ++k) {
+              const int b = k < width && i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+              pi.bl[k] = b;
+              pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
+              pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
             }
+            pi.a_kf4 = okf[u];
+            pi.a_fk4 = 0;
+            pi.nvec = d->basis_nvec[u];
+            h_panels.push_back(pi);
+            h_cost.push_back(60e3 + 300.0 * (width / 8) * (fpad / (4 * kCB64)) * ((d->basis_nvec[u] + 7) / 8 + (d->basis_nvec[u] + kVT64 - 1) / kVT64 * 2));
           }
-          if (cls == 0) mf_split = (int)h_panels.size();
         }
-        mf_npanels = (int)h_panels.size();
-        CAL_TRY(mf_panels.alloc(h_panels.size() * sizeof(PanelItem), false));
-        HIP_TRY(hipMemcpyAsync(mf_panels.p, h_panels.data(), h_panels.size() * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        CAL_TRY(order_panels(h_panels, h_cost));
         mf_lds_grad[0] = std::max(dense64_lds_bytes(nvec_a, 1, true), dense64_lds_bytes(nvec_b, 2, true));
         mf_lds_loss[0] = std::max(dense64_lds_bytes(nvec_a, 1, false), dense64_lds_bytes(nvec_b, 2, false));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
@@ -644,6 +675,7 @@ struct SolverT final : cal_solver {
     CAL_TRY(gains_m.alloc(gbytes));
     CAL_TRY(gains_v.alloc(gbytes));
     gains_snap.release();
+    gains_alt.release();
     const size_t cbytes = 2 * (size_t)ncoef * sizeof(T);
     CAL_TRY(coef.alloc(cbytes));
     CAL_TRY(coef_m.alloc(cbytes));
@@ -663,17 +695,61 @@ struct SolverT final : cal_solver {
     // ~ tens of milliseconds of GPU time between two host synchronisations of run(); the same on every rank, or ranks
     // would notice a tolerance stop after different step counts and issue different numbers of all-reduces
     steps_per_sync = (int)std::max(1.0, std::min(256.0, 2.0e11 / ((double)basis_bytes + 1.0)));
-    if (nccl) CAL_TRY(agree_min(steps_per_sync));
+    return CAL_OK;
+  }
+
+  // XCD-affine dispatch of the dense launch (dense_kernels.hpp: fused_dense_kernel): every basis block -- all its panels -- goes
+  // to ONE of 8 lists, blocks dealt longest-processing-time first so the lists carry equal cost; inside a list the heaviest
+  // panels come first (the tail of the pass is made of the lightest).  Workgroup b takes entry b / 8 of list b % 8: the slot
+  // map interleaves the lists, -1 where a list is shorter than the longest.  Uploads the records and the map.
+  int order_panels(std::vector<PanelItem>& panels, const std::vector<double>& cost) {
+    const int n = (int)panels.size();
+    std::vector<long long> keys;
+    std::vector<double> kcost;
+    std::vector<int> blk(n);
+    for (int i = 0; i < n; ++i) {
+      size_t k = std::find(keys.begin(), keys.end(), panels[i].a_kf4) - keys.begin();
+      if (k == keys.size()) { keys.push_back(panels[i].a_kf4); kcost.push_back(0.0); }
+      kcost[k] += cost[i];
+      blk[i] = (int)k;
+    }
+    std::vector<int> border(keys.size());
+    std::iota(border.begin(), border.end(), 0);
+    std::stable_sort(border.begin(), border.end(), [&](int a, int b) { return kcost[a] > kcost[b]; });
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<int> list_of(keys.size());
+    for (int k : border) {
+      const int x = (int)(std::min_element(load, load + 8) - load);
+      list_of[k] = x;
+      load[x] += kcost[k];
+    }
+    std::vector<std::vector<int>> lists(8);
+    for (int i = 0; i < n; ++i) lists[list_of[blk[i]]].push_back(i);
+    size_t longest = 0;
+    for (auto& l : lists) {
+      std::stable_sort(l.begin(), l.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+      longest = std::max(longest, l.size());
+    }
+    std::vector<int> h_map(8 * longest, -1);
+    for (int x = 0; x < 8; ++x)
+      for (size_t j = 0; j < lists[x].size(); ++j) h_map[j * 8 + x] = lists[x][j];
+    mf_npanels = n;
+    mf_grid = (int)h_map.size();
+    CAL_TRY(mf_panels.alloc((size_t)n * sizeof(PanelItem), false));
+    HIP_TRY(hipMemcpyAsync(mf_panels.p, panels.data(), (size_t)n * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
+    CAL_TRY(mf_map.alloc(h_map.size() * sizeof(int), false));
+    HIP_TRY(hipMemcpyAsync(mf_map.p, h_map.data(), h_map.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return CAL_OK;
   }
 
   // min over the ranks of the communicator (set-up decisions that every rank must take identically)
-  int agree_min(int& v) {
+  int agree_min(int* v, int n) {
     if (!nccl) return CAL_OK;
-    if (!agree_buf.p) CAL_TRY(agree_buf.alloc(sizeof(int)));
-    HIP_TRY(hipMemcpyAsync(agree_buf.p, &v, sizeof(int), hipMemcpyHostToDevice, stream));
-    NCCL_TRY(ncclAllReduce(agree_buf.p, agree_buf.p, 1, ncclInt32, ncclMin, nccl, stream));
-    HIP_TRY(hipMemcpyAsync(&v, agree_buf.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (!agree_buf.p) CAL_TRY(agree_buf.alloc(4 * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(agree_buf.p, v, n * sizeof(int), hipMemcpyHostToDevice, stream));
+    NCCL_TRY(ncclAllReduce(agree_buf.p, agree_buf.p, n, ncclInt32, ncclMin, nccl, stream));
+    HIP_TRY(hipMemcpyAsync(v, agree_buf.p, n * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return CAL_OK;
   }
@@ -828,9 +904,16 @@ struct SolverT final : cal_solver {
     if (cm_i) HIP_TRY(hipMemcpy(coef_m.as<T>() + ncoef, cm_i, cb, hipMemcpyHostToDevice));
     if (cv_r) HIP_TRY(hipMemcpy(coef_v.as<T>(), cv_r, cb, hipMemcpyHostToDevice));
     if (cv_i) HIP_TRY(hipMemcpy(coef_v.as<T>() + ncoef, cv_i, cb, hipMemcpyHostToDevice));
+    // beta^t as the device keeps it: a running product, one factor per update (pow() differs from it in the last bits, and a
+    // resumed fit must continue bit for bit).  Uses the betas of the optimizer set so far: set_optimizer comes first.
     h_state->t = t;
-    h_state->b1t = std::pow(opt.beta_1, (double)t);
-    h_state->b2t = std::pow(opt.beta_2, (double)t);
+    double b1t = 1.0, b2t = 1.0;
+    for (int64_t k = 0; k < t; ++k) {
+      b1t *= opt.beta_1;
+      b2t *= opt.beta_2;
+    }
+    h_state->b1t = b1t;
+    h_state->b2t = b2t;
     return CAL_OK;
   }
 
@@ -886,18 +969,19 @@ struct SolverT final : cal_solver {
   }
   // the dense pass: panels with more than four vector tiles (kernel instance with eight accumulator tiles per wave), then the rest
   template <bool GRAD> void launch_dense(Dense64Args m) {
-    m.panel_base = 0;
-    hipLaunchKernelGGL((fused_dense64_kernel<GRAD>), dim3(mf_npanels), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
+    m.slot_map = mf_map.as<int>();
+    hipLaunchKernelGGL((fused_dense64_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
   }
   template <bool GRAD> void launch_dense(MfmaArgs m) {
-    m.panel_base = 0;
-    hipLaunchKernelGGL((fused_dense_kernel<GRAD>), dim3(mf_npanels), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
+    m.slot_map = mf_map.as<int>();
+    hipLaunchKernelGGL((fused_dense_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
   }
   T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
   T* grad_c1() { return gc_direct ? gcp1.as<T>() : gc1.as<T>(); }
 
   // enqueue: loss (+ gradients) of the current parameters; leaves loss in state, final gradients in comm[0] / grad_c0()
-  int enqueue_pass(bool grads, bool apply_update, int losses_cap) {
+  // one_launch_tail: the caller follows up with step_tail_kernel (enqueue_update), which does everything behind the fused pass
+  int enqueue_pass(bool grads, bool apply_update, int losses_cap, bool one_launch_tail = false) {
     const bool R = reg == CAL_REG_SUM;
     FusedArgs<T> a = fused_args();
     DevState* st = st_cur();
@@ -954,6 +1038,10 @@ struct SolverT final : cal_solver {
     }
     const int n_parts = use_mfma ? mf_npanels : nitems;
     if (timing) HIP_TRY(hipEventRecord(e1, stream));
+    if (one_launch_tail) {
+      HIP_TRY(hipGetLastError());
+      return CAL_OK;
+    }
     const size_t gn = (size_t)nants * fpad;
     T2* r0 = comm.as<T2>();
     T2* r1 = r0 + gn;
@@ -1009,6 +1097,52 @@ struct SolverT final : cal_solver {
   // tail of a step; with millions of parameters the per-block decision prologue of the fused kernel costs more than the two
   // kernel boundaries it saves (HERA-350: 105 us against 5 + 56 us), so those keep finalize_kernel + adam2_kernel.
   bool tail_fits_one_launch() const { return 2LL * nants * fpad + 2LL * ncoef <= (1LL << 20); }
+  // Problems whose step is tens of microseconds: the whole tail as ONE launch (step_tail_kernel) -- no communicator (the
+  // exchange sits between the reduction and the update), general kernels, and not when every kernel is asked to be its own launch
+  bool one_launch_tail() const { return !nccl && !mf_ok && tail_fits_one_launch() && launch_mode != CAL_LAUNCH_KERNELS; }
+  template <int OPT> void launch_tail(const TailArgs<T>& a, unsigned grid, bool R) {
+    if (R)
+      hipLaunchKernelGGL((step_tail_kernel<T, OPT, true>), dim3(grid), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL((step_tail_kernel<T, OPT, false>), dim3(grid), dim3(256), 0, stream, a);
+  }
+  int enqueue_tail(bool freeze_model, int losses_cap) {
+    const bool R = reg == CAL_REG_SUM;
+    TailArgs<T> a{};
+    a.q0 = q0.as<T2>();
+    a.q1 = q1.as<T2>();
+    a.gains_in = gains.as<T2>();
+    a.gains_out = gains_alt.as<T2>();
+    a.gains_m = gains_m.as<T>();
+    a.gains_v = gains_v.as<T>();
+    a.gains_snap = gains_snap.p ? gains_snap.as<T>() : gains_alt.as<T>();  // only written when use_min found a new minimum
+    a.ant_ptr = ant_ptr.as<int>();
+    a.ant_ent = ant_ent.as<int2>();
+    a.coef = AdamSet<T>{coef.as<T>(), gcp0.as<T>(), coef_m.as<T>(), coef_v.as<T>(), coef_snap.p ? coef_snap.as<T>() : coef.as<T>(),
+                        freeze_model ? 0LL : 2LL * ncoef};
+    a.coef_g1 = gcp1.as<T>();
+    if (!gc_direct) {
+      a.ps0 = PartialSum<T>{gcp0.as<T>(), gcp0.as<T>() + gcp_len, coef_grp.as<int>(), grp_coff.as<int>(), grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef};
+      a.ps1 = PartialSum<T>{gcp1.as<T>(), gcp1.p ? gcp1.as<T>() + gcp_len : nullptr, coef_grp.as<int>(), grp_coff.as<int>(), grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef};
+    }
+    a.part = part.as<double>();
+    a.nparts = nitems;
+    a.nants = nants;
+    a.fpad = fpad;
+    const int cpl = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;
+    a.nblk_gain = nants * ((fpad + 64 * cpl - 1) / (64 * cpl));
+    a.in = st_cur();
+    a.out = st_nxt();
+    a.losses = losses.as<double>();
+    a.losses_cap = losses_cap;
+    const long long nblk_c = freeze_model ? 0 : std::min<long long>((2LL * ncoef + 255) / 256, 4096);
+    const unsigned grid = (unsigned)(a.nblk_gain + nblk_c);
+    if (opt.optimizer == CAL_OPT_ADAM) launch_tail<0>(a, grid, R); else launch_tail<1>(a, grid, R);
+    st_par ^= 1;
+    std::swap(gains.p, gains_alt.p);  // the buffer just written is the current one
+    HIP_TRY(hipGetLastError());
+    return CAL_OK;
+  }
   int enqueue_update(bool freeze_model, int losses_cap) {
     DevState* st = st_cur();
     const long long gn = 2LL * nants * fpad;
@@ -1040,6 +1174,50 @@ struct SolverT final : cal_solver {
     else
       hipLaunchKernelGGL((adam2_kernel<T, 1>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st);
     HIP_TRY(hipGetLastError());
+    return CAL_OK;
+  }
+
+  void drop_graph() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    graph_exec = nullptr;
+  }
+  // kGraphSteps train steps (fused pass + one-launch tail each) captured once per configuration and replayed.  Everything a
+  // step reads that changes between steps lives in device memory (loop state, parameters, moments); what is baked into the
+  // captured launches -- buffer pointers, optimizer, frozen model, regulariser, loss-history capacity, which halves of the
+  // double-buffered state and gains are current -- is the key.  kGraphSteps is even, so a replay leaves both double buffers
+  // where it found them and the same graph serves the next replay.
+  int replay_steps(bool freeze_model, int cap) {
+    const GraphKey key{opt.optimizer, freeze_model ? 1 : 0, reg, cap, st_par, gains.p, gains_snap.p, losses.p};
+    if (!graph_exec || !(key == graph_key)) {
+      drop_graph();
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      int rc = CAL_OK;
+      for (int k = 0; k < kGraphSteps && rc == CAL_OK; ++k) {
+        rc = enqueue_pass(true, true, cap, true);
+        if (rc == CAL_OK) rc = enqueue_tail(freeze_model, cap);
+      }
+      const hipError_t e = hipStreamEndCapture(stream, &graph);
+      if (rc != CAL_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (e != hipSuccess) return fail(CAL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      const hipError_t ei = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ei != hipSuccess) {
+        graph_exec = nullptr;
+        return fail(CAL_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+      }
+      graph_key = key;
+    }
+    HIP_TRY(hipGraphLaunch(graph_exec, stream));
+    return CAL_OK;
+  }
+  int set_launch_mode(int mode) override {
+    if (mode != CAL_LAUNCH_AUTO && mode != CAL_LAUNCH_KERNELS && mode != CAL_LAUNCH_ONE_TAIL && mode != CAL_LAUNCH_GRAPH)
+      return fail(CAL_ERR_INVALID, "set_launch_mode: unknown mode %d", mode);
+    launch_mode = mode;
     return CAL_OK;
   }
 
@@ -1119,12 +1297,22 @@ struct SolverT final : cal_solver {
     // steps are enqueued in chunks; the device decides when the loop ends (finalize_kernel) and later steps of a
     // chunk fall through at once, so the host only synchronises once per chunk instead of once per step (:701)
     const int chunk = steps_per_sync;
+    const int cap = r->record ? r->nsteps : 0;
+    const bool tail1 = one_launch_tail();
+    if (tail1 && !gains_alt.p) CAL_TRY(gains_alt.alloc(gains.bytes));
+    // hipGraph replay of kGraphSteps train steps at a time: the steps of such problems are bound by launch latency.  Timed
+    // runs (HIP events around every fused pass) issue their launches one by one.
+    const bool replay = tail1 && !timing && (launch_mode == CAL_LAUNCH_AUTO || launch_mode == CAL_LAUNCH_GRAPH);
     int issued = 0;
     while (issued < r->nsteps) {
       const int n = std::min(chunk, r->nsteps - issued);
-      for (int s = 0; s < n; ++s) {
-        CAL_TRY(enqueue_pass(true, true, r->record ? r->nsteps : 0));
-        CAL_TRY(enqueue_update(r->freeze_model != 0, r->record ? r->nsteps : 0));
+      int s = 0;
+      if (replay) {
+        for (; s + kGraphSteps <= n; s += kGraphSteps) CAL_TRY(replay_steps(r->freeze_model != 0, cap));
+      }
+      for (; s < n; ++s) {
+        CAL_TRY(enqueue_pass(true, true, cap, tail1));
+        if (tail1) CAL_TRY(enqueue_tail(r->freeze_model != 0, cap)); else CAL_TRY(enqueue_update(r->freeze_model != 0, cap));
       }
       issued += n;
       CAL_TRY(pull_state());
@@ -1218,9 +1406,9 @@ struct SolverT final : cal_solver {
   int memory_bytes(int64_t* b) override {
     if (!b) return fail(CAL_ERR_INVALID, "memory_bytes: null");
     const DevBuf* all[] = {&tiles, &bl_tile, &bl_ant, &items, &ant_ptr, &ant_ent, &coef_grp, &grp_coff, &grp_item_ptr, &item_goff,
-                           &data_r, &data_i, &wgts, &gains, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
+                           &data_r, &data_i, &wgts, &gains, &gains_alt, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
                            &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf,
-                           &mf_ops, &mf_panels};
+                           &mf_ops, &mf_panels, &mf_map};
     int64_t n = 0;
     for (auto* d : all) n += (int64_t)d->bytes;
     *b = n;
@@ -1242,10 +1430,10 @@ struct SolverT final : cal_solver {
     if (has_problem) {
       // a problem set before the communicator existed: agree now (fpad is rank-independent by construction; a rank
       // that chose the dense path falls back to the general kernel, which runs on the same buffers)
-      int v = mf_ok ? 1 : 0;
-      CAL_TRY(agree_min(v));
-      if (!v) mf_ok = false;
-      CAL_TRY(agree_min(steps_per_sync));
+      int v[2] = {mf_ok ? 1 : 0, steps_per_sync};
+      CAL_TRY(agree_min(v, 2));
+      if (!v[0]) mf_ok = false;
+      steps_per_sync = v[1];
     }
     return CAL_OK;
   }
@@ -1412,6 +1600,7 @@ int cal_solver_run(cal_solver* s, const cal_run_desc* r, double* losses_out, cal
 int cal_solver_model(cal_solver* s, void* mr, void* mi) { NEED(s); return s->model(mr, mi); }
 int cal_solver_init_coeffs(cal_solver* s, const void* sr, const void* si) { NEED(s); return s->init_coeffs(sr, si); }
 int cal_solver_synchronize(cal_solver* s) { NEED(s); return s->synchronize(); }
+int cal_solver_set_launch_mode(cal_solver* s, int mode) { NEED(s); return s->set_launch_mode(mode); }
 int cal_solver_timing_enable(cal_solver* s, int e) { NEED(s); return s->timing_enable(e); }
 int cal_solver_timing_get(cal_solver* s, cal_kernel_timing* out) { NEED(s); return s->timing_get(out); }
 int cal_solver_memory_bytes(cal_solver* s, int64_t* b) { NEED(s); return s->memory_bytes(b); }

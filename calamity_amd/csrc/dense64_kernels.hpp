@@ -42,7 +42,7 @@ struct Dense64Args {
   int fpad;
   int use_alpha;
   int nbls;
-  int panel_base;
+  const int* slot_map;         // [grid] workgroup -> panel, -1 for an empty slot (XCD-affine dispatch: dense_kernels.hpp)
 };
 
 __device__ __forceinline__ double swap8(double x) {  // the value of lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
@@ -56,7 +56,7 @@ __device__ __forceinline__ double swap8(double x) {  // the value of lane l ^ 8 
 template <bool GRAD, int NC, int NTMAX>
 __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned char* smem_raw) {
   constexpr int kRing = GRAD ? 8 : 4;  // powers of two (slot index by mask)
-  const int panel_idx = A.panel_base + (int)blockIdx.x;
+  const int panel_idx = A.slot_map[blockIdx.x];  // never negative here: the kernel returns for empty slots
   const PanelItem& P = A.panels[panel_idx];
   const int stopped = A.state->done | A.state->done_after;
   const int tid = threadIdx.x;
@@ -371,7 +371,9 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
 template <bool GRAD>
 __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense64_kernel(const Dense64Args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (A.panels[A.panel_base + (int)blockIdx.x].nvec > 128)
+  const int slot = A.slot_map[blockIdx.x];
+  if (slot < 0) return;
+  if (A.panels[slot].nvec > 128)
     dense64_panel<GRAD, 1, 16>(A, smem_raw);
   else
     dense64_panel<GRAD, 2, 8>(A, smem_raw);

@@ -67,7 +67,7 @@ struct MfmaArgs {
   int fpad;
   int use_alpha;               // "sum" regulariser, second pass: e = -2 w r + alpha w with alpha = 2 (S - P) read from state
   int nbls;                    // row nbls of data_r / data_i / wgts / q0 is an all-zero spare row for padding slots
-  int panel_base;              // first panel of this launch (panels are launched in two classes, by vector-tile count)
+  const int* slot_map;         // [grid] workgroup -> panel, -1 for an empty slot: XCD-affine dispatch, see fused_dense_kernel
 };
 
 // ---- operand stream: an LDS ring filled by direct-to-LDS loads.
@@ -116,7 +116,7 @@ __device__ __forceinline__ void dense_panel(const MfmaArgs& A, unsigned char* sm
   // 1.00 ms); the class with more than four vector tiles has the larger coefficient panel and gets 6
   constexpr int kRing = dense_ring_slots(GRAD, NTMAX);
   STAMP_T(t_entry);
-  const int panel_idx = A.panel_base + (int)blockIdx.x;
+  const int panel_idx = A.slot_map[blockIdx.x];  // never negative here: the kernel returns for empty slots
   const PanelItem& P = A.panels[panel_idx];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -510,12 +510,19 @@ __device__ __forceinline__ void dense_panel(const MfmaArgs& A, unsigned char* sm
   STAMP_EXIT()
 }
 
-// One launch for all panels, heaviest first: the body is instantiated for panels of up to 4 and of up to 8 vector tiles
-// (registers for 64 / 128 gradient accumulators; two launches, one per class, leave the CUs idle while the first drains)
+// One launch for all panels: the body is instantiated for panels of up to 4 and of up to 8 vector tiles (registers for 64 / 128
+// gradient accumulators; two launches, one per class, leave the CUs idle while the first drains).
+// XCD-affine dispatch: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), and each XCD has its
+// own 4-MiB L2.  The host gives every basis block -- all its panels -- to ONE of 8 lists of equal cost (SolverT::order_panels)
+// and workgroup b takes entry b / 8 of list b % 8 (slot_map; lists shorter than the longest leave empty slots), heaviest
+// panels first in every list.  A block's packed operands then stream through one XCD's L2 instead of all eight: with panels
+// dealt in one global order every XCD fetched every block.  (Placement is a speed matter only: any workgroup computes any panel.)
 template <bool GRAD>
 __global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_kernel(const MfmaArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (A.panels[A.panel_base + (int)blockIdx.x].nvp32 > 128)
+  const int slot = A.slot_map[blockIdx.x];
+  if (slot < 0) return;
+  if (A.panels[slot].nvp32 > 128)
     dense_panel<GRAD, 8>(A, smem_raw);
   else
     dense_panel<GRAD, 4>(A, smem_raw);

@@ -1190,6 +1190,281 @@ __global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, co
   }
 }
 
+// ---- the WHOLE tail of a train step in one launch, for problems whose step is a few tens of microseconds (the tutorial,
+// HERA-37): the per-antenna reduction of gain_grad_kernel, the loop bookkeeping of finalize_kernel, the regulariser's fold of
+// combine_*_kernel and the optimizer update -- a step is then TWO launches (fused pass, tail), which cal_solver_run replays
+// from a hipGraph.  Same arithmetic, operation for operation and in the same order, as the separate kernels (shared helpers
+// below; bit-identical trajectories are tested), arranged so that no block depends on another:
+//   * every block sums the per-item loss partials itself (the fixed order of gain_grad_kernel's last block) and derives the
+//     step's decisions from the OLD state copy, as step_update_kernel does;
+//   * gain blocks = (antenna, 64 CPL channels): segmented reduction over the antenna's baselines, then the update of exactly
+//     those gains.  They READ the other antennas' gains while their owners update them, so the gains are double-buffered
+//     (read `gains_in`, write `gains_out`; the host swaps the two after every step);
+//   * the remaining blocks update the coefficients (partial gradients of split groups summed on the fly).
+template <typename T> __device__ __forceinline__ void fold_gain(T& ax, T& ay, T bx, T by, T cx, T cy, T ar, T ai) {
+  // + alpha * r1 + conj(alpha) * r2   (combine_gain_kernel)
+  ax += ar * bx - ai * by + ar * cx + ai * cy;
+  ay += ar * by + ai * bx + ar * cy - ai * cx;
+}
+template <typename T, int OPT> __device__ __forceinline__ T optimizer_step(T pi, T gi, T& mi_io, T& vi_io, T b1, T b2, T eps, T lr_t, T lr_u) {
+  const T mi = b1 * mi_io + ((T)1 - b1) * gi;
+  if (OPT == 0) {
+    const T vi = b2 * vi_io + ((T)1 - b2) * gi * gi;
+    vi_io = vi;
+    pi -= lr_t * mi / (sqrt(vi) + eps);
+  } else {
+    const T ui = fmax(b2 * vi_io, fabs(gi));
+    vi_io = ui;
+    pi -= lr_u * mi / (ui + eps);
+  }
+  mi_io = mi;
+  return pi;
+}
+template <typename T>
+struct TailArgs {
+  const vec2_t<T>* q0; const vec2_t<T>* q1;
+  const vec2_t<T>* gains_in; vec2_t<T>* gains_out;
+  T* gains_m; T* gains_v; T* gains_snap;         // flat [nants][fpad][2]
+  const int* ant_ptr; const int2* ant_ent;
+  AdamSet<T> coef;                               // g = first gradient set; n = 0 when the model is frozen
+  const T* coef_g1;                              // REG: the set that multiplies alpha (summed sets when ps1.ncoef == 0)
+  PartialSum<T> ps0, ps1;
+  const double* part; int nparts;
+  int nants, fpad, nblk_gain;
+  const DevState* in; DevState* out;
+  double* losses; int losses_cap;
+};
+template <typename T, int OPT, bool REG>
+__global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
+  using T2 = vec2_t<T>;
+  constexpr int CPL = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;
+  typedef T vec_t __attribute__((ext_vector_type(2 * CPL)));
+  __shared__ double sh[3][256];
+  __shared__ double sh_lr_t, sh_lr_u, sh_b1, sh_b2, sh_eps, sh_ar, sh_ai;
+  __shared__ int sh_update, sh_improved;
+  __shared__ T s_part[3][3][64][2 * CPL];
+  const int tid = threadIdx.x;
+  // ---- loss partial sums: the reduction of gain_grad_kernel's last block, in every block
+  {
+    double a = 0, b = 0, c = 0;
+    for (int i = tid; i < A.nparts; i += 256) {
+      a += A.part[(size_t)i * 4 + 0];
+      b += A.part[(size_t)i * 4 + 1];
+      c += A.part[(size_t)i * 4 + 2];
+    }
+    sh[0][tid] = a;
+    sh[1][tid] = b;
+    sh[2][tid] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st) {
+        sh[0][tid] += sh[0][tid + st];
+        sh[1][tid] += sh[1][tid + st];
+        sh[2][tid] += sh[2][tid + st];
+      }
+      __syncthreads();
+    }
+  }
+  // ---- the step's decisions (step_update_kernel / finalize_kernel): thread 0 of every block, block 0 records them
+  if (tid == 0) {
+    DevState s = *A.in;
+    const bool writer = blockIdx.x == 0;
+    bool update = false;
+    if (s.done) {
+    } else if (s.done_after) {
+      s.done = 1;
+    } else {
+      double loss = sh[0][0];
+      if (s.reg) {
+        s.s_r = sh[1][0];
+        s.s_i = sh[2][0];
+        const double dr = sh[1][0] - s.prior_r, di = sh[2][0] - s.prior_i;
+        loss += dr * dr + di * di;
+        s.alpha_r = 2.0 * dr;
+        s.alpha_i = 2.0 * di;
+      }
+      s.loss = loss;
+      s.improved = 0;
+      if (!(loss == loss) || loss > 1.7e308 || loss < -1.7e308) {
+        s.nonfinite = 1;
+        s.done = 1;
+      } else {
+        update = true;
+        s.t += 1;
+        s.nupdates += 1;
+        s.b1t *= s.beta1;
+        s.b2t *= s.beta2;
+        s.bc1 = 1.0 - s.b1t;
+        s.lr_t = s.lr * sqrt(1.0 - s.b2t) / s.bc1;
+        s.lr_u = s.lr / s.bc1;
+        if (s.record) {
+          if (writer && s.n_recorded < A.losses_cap) A.losses[s.n_recorded] = loss;
+          s.n_recorded += 1;
+          const double lc = s.f32 ? (double)(float)loss : loss;
+          if (s.use_min && lc < s.min_loss) {
+            s.min_loss = lc;
+            s.improved = 1;
+          }
+          if (s.n_recorded_total >= 1 && fabs(lc - s.prev_loss) < s.tol) s.done_after = 1;
+          s.prev_loss = lc;
+          s.n_recorded_total += 1;
+        }
+      }
+    }
+    if (writer) *A.out = s;
+    sh_update = update ? 1 : 0;
+    sh_improved = s.improved;
+    sh_lr_t = s.lr_t; sh_lr_u = s.lr_u; sh_b1 = s.beta1; sh_b2 = s.beta2; sh_eps = s.eps;
+    sh_ar = s.alpha_r; sh_ai = s.alpha_i;
+  }
+  __syncthreads();
+  const bool update = sh_update != 0;
+  const T b1 = (T)sh_b1, b2 = (T)sh_b2, eps = (T)sh_eps, lr_t = (T)sh_lr_t, lr_u = (T)sh_lr_u;
+  const T ar = (T)sh_ar, ai = (T)sh_ai;
+  const bool improved = sh_improved != 0;
+  if ((int)blockIdx.x < A.nblk_gain) {
+    // ---- gain block: gain_grad_kernel's reduction, then the update of these gains.  A step that does not update (loop
+    // ended, non-finite loss) still copies its gains to the other buffer: the host swaps the buffers after every step
+    const int cb = blockIdx.x / A.nants;
+    const int a = blockIdx.x - cb * A.nants;
+    const int lane = tid & 63, seg = tid >> 6;
+    const int f = (cb * 64 + lane) * CPL;
+    const bool ok = f < A.fpad;
+    const long long idx = (long long)a * A.fpad + f;
+    if (!update) {
+      if (seg == 0 && ok) *reinterpret_cast<vec_t*>(A.gains_out + idx) = *reinterpret_cast<const vec_t*>(A.gains_in + idx);
+      return;
+    }
+    T s0[2 * CPL], s1[2 * CPL], s2[2 * CPL];
+#pragma unroll
+    for (int c = 0; c < 2 * CPL; ++c) s0[c] = s1[c] = s2[c] = 0;
+    const int e0 = A.ant_ptr[a], e1 = A.ant_ptr[a + 1];
+    const int per = (e1 - e0 + 3) >> 2;
+    const int eb = e0 + seg * per, ee = min(e1, eb + per);
+    if (ok) {
+#pragma unroll 8
+      for (int e = eb; e < ee; ++e) {
+        const int2 ent = A.ant_ent[e];
+        const int bl = ent.x >> 1;
+        const int role = ent.x & 1;
+        const vec_t q = *reinterpret_cast<const vec_t*>(A.q0 + (long long)bl * A.fpad + f);
+        const vec_t go = *reinterpret_cast<const vec_t*>(A.gains_in + (long long)ent.y * A.fpad + f);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const T qr = q[2 * c], qi = role ? -q[2 * c + 1] : q[2 * c + 1];
+          s0[2 * c] += qr * go[2 * c] - qi * go[2 * c + 1];
+          s0[2 * c + 1] += qr * go[2 * c + 1] + qi * go[2 * c];
+        }
+        if (REG) {
+          const vec_t p = *reinterpret_cast<const vec_t*>(A.q1 + (long long)bl * A.fpad + f);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const T pr = p[2 * c], pi = p[2 * c + 1];
+            if (role == 0) {
+              s1[2 * c] += pr * go[2 * c] - pi * go[2 * c + 1];
+              s1[2 * c + 1] += pr * go[2 * c + 1] + pi * go[2 * c];
+            } else {
+              s2[2 * c] += pr * go[2 * c] + pi * go[2 * c + 1];
+              s2[2 * c + 1] += pr * go[2 * c + 1] - pi * go[2 * c];
+            }
+          }
+        }
+      }
+    }
+    if (seg > 0) {
+#pragma unroll
+      for (int c = 0; c < 2 * CPL; ++c) {
+        s_part[seg - 1][0][lane][c] = s0[c];
+        if (REG) {
+          s_part[seg - 1][1][lane][c] = s1[c];
+          s_part[seg - 1][2][lane][c] = s2[c];
+        }
+      }
+    }
+    __syncthreads();
+    if (seg == 0 && ok) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+#pragma unroll
+        for (int c = 0; c < 2 * CPL; ++c) {
+          s0[c] += s_part[g][0][lane][c];
+          if (REG) {
+            s1[c] += s_part[g][1][lane][c];
+            s2[c] += s_part[g][2][lane][c];
+          }
+        }
+      }
+      if (REG) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) fold_gain(s0[2 * c], s0[2 * c + 1], s1[2 * c], s1[2 * c + 1], s2[2 * c], s2[2 * c + 1], ar, ai);
+      }
+      const vec_t pin = *reinterpret_cast<const vec_t*>(A.gains_in + idx);
+      vec_t mm = *reinterpret_cast<const vec_t*>(A.gains_m + 2 * idx), vv = *reinterpret_cast<const vec_t*>(A.gains_v + 2 * idx), pout;
+#pragma unroll
+      for (int c = 0; c < 2 * CPL; ++c) {
+        T mi = mm[c], vi = vv[c];
+        pout[c] = optimizer_step<T, OPT>(pin[c], s0[c], mi, vi, b1, b2, eps, lr_t, lr_u);
+        mm[c] = mi;
+        vv[c] = vi;
+      }
+      *reinterpret_cast<vec_t*>(A.gains_m + 2 * idx) = mm;
+      *reinterpret_cast<vec_t*>(A.gains_v + 2 * idx) = vv;
+      *reinterpret_cast<vec_t*>(A.gains_out + idx) = pout;
+      if (improved) *reinterpret_cast<vec_t*>(A.gains_snap + 2 * idx) = pout;
+    }
+    return;
+  }
+  // ---- coefficient blocks
+  if (!update) return;
+  const AdamSet<T>& S = A.coef;
+  const long long nb = (long long)gridDim.x - A.nblk_gain;
+  for (long long i = ((long long)blockIdx.x - A.nblk_gain) * blockDim.x + tid; i < S.n; i += nb * blockDim.x) {
+    T gi, g1 = 0;
+    if (A.ps0.ncoef > 0) {
+      const int plane = i >= A.ps0.ncoef ? 1 : 0;
+      const int n = (int)(i - (long long)plane * A.ps0.ncoef);
+      const int g = A.ps0.coef_grp[n];
+      const int k = n - A.ps0.grp_coff[g];
+      const T* src = plane ? A.ps0.gcp_i : A.ps0.gcp_r;
+      gi = 0;
+      for (int q = A.ps0.grp_item_ptr[g]; q < A.ps0.grp_item_ptr[g + 1]; ++q) gi += src[A.ps0.item_goff[q] + k];
+      if (REG) {
+        const T* src1 = plane ? A.ps1.gcp_i : A.ps1.gcp_r;
+        for (int q = A.ps0.grp_item_ptr[g]; q < A.ps0.grp_item_ptr[g + 1]; ++q) g1 += src1[A.ps0.item_goff[q] + k];
+      }
+    } else {
+      gi = S.g[i];
+      if (REG) g1 = A.coef_g1[i];
+    }
+    if (REG) {
+      // combine_coeff_kernel: g0_r += ar g1_r - ai g1_i ; g0_i += ar g1_i + ai g1_r  (planes: [r | i], each n2 long)
+      const long long n2 = S.n / 2;
+      const bool imag = i >= n2;
+      const long long j = imag ? i - n2 : i + n2;  // the same coefficient's other plane
+      T o1;
+      if (A.ps0.ncoef > 0) {
+        const int plane = imag ? 0 : 1;
+        const int n = (int)(j - (long long)plane * A.ps0.ncoef);
+        const int g = A.ps0.coef_grp[n];
+        const int k = n - A.ps0.grp_coff[g];
+        const T* src1 = plane ? A.ps1.gcp_i : A.ps1.gcp_r;
+        o1 = 0;
+        for (int q = A.ps0.grp_item_ptr[g]; q < A.ps0.grp_item_ptr[g + 1]; ++q) o1 += src1[A.ps0.item_goff[q] + k];
+      } else {
+        o1 = A.coef_g1[j];
+      }
+      if (!imag) gi += ar * g1 - ai * o1;
+      else gi += ar * g1 + ai * o1;
+    }
+    T mi = S.m[i], vi = S.v[i];
+    const T pi = optimizer_step<T, OPT>(S.p[i], gi, mi, vi, b1, b2, eps, lr_t, lr_u);
+    S.m[i] = mi;
+    S.v[i] = vi;
+    S.p[i] = pi;
+    if (improved) S.snap[i] = pi;
+  }
+}
+
 // ---- setup kernels -------------------------------------------------------------------------------------------
 // unique basis block (row-major [nrb * nfreqs][nvec]) -> tile-major [rowblk][channel block][vec][FB], zero padded
 template <typename T>

@@ -5,13 +5,94 @@ the reference lives in the un-vendored third-party ``hera_filters.dspec.dpss_ope
 unpinned in setup.py:59-66); ``dpss_operator`` below restates its published algorithm with
 ``scipy.signal.windows.dpss``.  Mode-count parity with hera_filters is unpinned.
 """
+import concurrent.futures
 import datetime
+import os
 
 import numpy as np
 from scipy.signal import windows
 
 from . import simple_cov
 from .utils import PBARS, echo
+
+
+def _lapack_dstemr():
+    """LAPACK's dstemr as a ctypes function (the pointer SciPy's own cython_lapack exports).  ctypes releases the GIL for the
+    call, SciPy's f2py wrappers (scipy.linalg.eigh_tridiagonal, which scipy.signal.windows.dpss goes through) do not: the
+    120 eigenproblems of a HERA-350 basis then really run side by side on the host's cores."""
+    import ctypes as C
+
+    from scipy.linalg import cython_lapack
+
+    cap = cython_lapack.__pyx_capi__["dstemr"]
+    C.pythonapi.PyCapsule_GetName.restype, C.pythonapi.PyCapsule_GetName.argtypes = C.c_char_p, [C.py_object]
+    C.pythonapi.PyCapsule_GetPointer.restype, C.pythonapi.PyCapsule_GetPointer.argtypes = C.c_void_p, [C.py_object, C.c_char_p]
+    ptr = C.pythonapi.PyCapsule_GetPointer(cap, C.pythonapi.PyCapsule_GetName(cap))
+    P, I, D = C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    # dstemr(jobz, range, n, d, e, vl, vu, il, iu, m, w, z, ldz, nzc, isuppz, tryrac, work, lwork, iwork, liwork, info)
+    return C.CFUNCTYPE(None, P, P, I, D, D, D, D, I, I, I, D, D, I, I, I, I, D, I, I, I, I)(ptr)
+
+
+_DSTEMR = None
+
+
+def dpss_windows(M, NW, Kmax):
+    """The first ``Kmax`` discrete prolate spheroidal sequences of length ``M`` and half bandwidth ``NW``, (Kmax, M), unit
+    norm -- what ``scipy.signal.windows.dpss(M, NW, Kmax)`` returns (the function hera_filters builds its operator from), by
+    the same route: the ``Kmax`` largest eigenpairs of the symmetric tridiagonal matrix that commutes with the sinc kernel
+    (Slepian 1978), symmetric sequences with positive mean, antisymmetric ones starting with a positive lobe (Percival &
+    Walden 1993, p. 379).  The eigenproblem is LAPACK dstemr called without the GIL (``_lapack_dstemr``); where that entry is
+    not to be had, SciPy's function itself."""
+    import ctypes as C
+
+    global _DSTEMR
+    if _DSTEMR is None:
+        try:
+            _DSTEMR = _lapack_dstemr()
+        except Exception:  # noqa: BLE001 -- any SciPy without the capsule: fall back to its own (GIL-holding) path
+            _DSTEMR = False
+    if _DSTEMR is False:
+        return windows.dpss(M, NW, Kmax)
+    W = float(NW) / M
+    nidx = np.arange(M, dtype=np.float64)
+    d = ((M - 1 - 2 * nidx) / 2.0) ** 2 * np.cos(2 * np.pi * W)
+    e = np.zeros(M)
+    e[: M - 1] = nidx[1:] * (M - nidx[1:]) / 2.0
+    n, il, iu, m = C.c_int(M), C.c_int(M - Kmax + 1), C.c_int(M), C.c_int(0)
+    ldz, nzc, tryrac, info = C.c_int(M), C.c_int(Kmax), C.c_int(1), C.c_int(0)
+    w = np.zeros(M)
+    z = np.zeros((Kmax, M))  # column-major (M, Kmax) for LAPACK = row-major (Kmax, M): one eigenvector per row
+    isuppz = np.zeros(2 * Kmax, dtype=np.int32)
+    lwork, liwork = C.c_int(18 * M), C.c_int(10 * M)
+    work, iwork = np.zeros(18 * M), np.zeros(10 * M, dtype=np.int32)
+    zero = C.c_double(0.0)
+    as_d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    as_i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+    _DSTEMR(b"V", b"I", C.byref(n), as_d(d), as_d(e), C.byref(zero), C.byref(zero), C.byref(il), C.byref(iu), C.byref(m), as_d(w), as_d(z),
+            C.byref(ldz), C.byref(nzc), as_i(isuppz), C.byref(tryrac), as_d(work), C.byref(lwork), as_i(iwork), C.byref(liwork), C.byref(info))
+    if info.value != 0 or m.value != Kmax:
+        return windows.dpss(M, NW, Kmax)
+    seqs = z[::-1].copy()  # ascending eigenvalues -> the most concentrated sequence first
+    fix_even = seqs[::2].sum(axis=1) < 0
+    seqs[::2][fix_even] *= -1
+    thresh = max(1e-7, 1.0 / M)
+    for i, s_ in enumerate(seqs[1::2]):
+        if s_[s_ * s_ > thresh][0] < 0:
+            seqs[2 * i + 1] *= -1
+    return seqs
+
+
+def _sinc_eigenvalues(vecs, dx, fw):
+    """Rayleigh quotients ``v_k^T S v_k`` of unit-norm rows ``vecs`` (kmax, N) with the sinc kernel
+    ``S[i, j] = 2 dx fw sinc(2 fw dx (i - j))`` -- the eigenvalue hera_filters' cut is applied to.  ``S`` is symmetric
+    Toeplitz on a uniform grid, so ``v^T S v = sum_n acorr_v[n] t[|n|]``: one FFT autocorrelation per sequence instead
+    of an N x N sinc evaluation and an N x N x kmax product (110 of the 160 ms a 1024-channel block used to cost)."""
+    kmax, nf = vecs.shape
+    spec = np.fft.rfft(vecs, n=2 * nf, axis=1)
+    acorr = np.fft.irfft(spec.real**2 + spec.imag**2, n=2 * nf, axis=1)[:, :nf]  # lags 0 .. N-1
+    t = 2.0 * dx * fw * np.sinc(2.0 * fw * dx * np.arange(nf))
+    t[1:] *= 2.0  # lags -n and +n
+    return acorr @ t
 
 
 def dpss_operator(x, filter_centers, filter_half_widths, eigenval_cutoff, cache=None, xc=None):
@@ -21,6 +102,11 @@ def dpss_operator(x, filter_centers, filter_half_widths, eigenval_cutoff, cache=
     eigenval_cutoff=..., cache=...)`` as called at modeling.py:294-300.  For each (centre, half width) the
     number of terms is the index of the last DPSS sequence whose sinc-kernel eigenvalue is at least the
     cutoff; the block is ``exp(2 pi i (x - xc) fc) * dpss(N, N dx fw, nterms)``.
+
+    The eigenvalues fall off a cliff (about a decade per index) a few indices beyond ``2 N dx fw``: sequences are
+    generated in growing batches until the batch reaches below the cutoff, instead of a fixed generous margin, and the
+    eigenvalues are FFT Rayleigh quotients (``_sinc_eigenvalues``).  An eigenvalue within 1e-6 (relative) of the cutoff
+    is re-evaluated against the dense kernel, so the count never hangs on FFT rounding.
 
     Returns (amat [N, sum nterms] complex, nterms list).
     """
@@ -39,11 +125,18 @@ def dpss_operator(x, filter_centers, filter_half_widths, eigenval_cutoff, cache=
     blocks, nterms = [], []
     for fc, fw, ec in zip(filter_centers, filter_half_widths, eigenval_cutoff):
         nw = nf * dx * fw
-        # eigenvalues fall off a cliff beyond 2 NW; a margin of 64 sequences covers cutoffs down to 1e-16.
-        kmax = int(min(nf, np.ceil(2.0 * nw) + 64))
-        vecs = windows.dpss(nf, nw, kmax)  # (kmax, nf), unit norm rows
-        smat = np.sinc(2.0 * fw * (x[:, None] - x[None, :])) * 2.0 * dx * fw
-        eigvals = np.sum((smat @ vecs.T) * vecs.T, axis=0)
+        margin = 24
+        while True:
+            kmax = int(min(nf, np.ceil(2.0 * nw) + margin))
+            vecs = dpss_windows(nf, nw, kmax)  # (kmax, nf), unit norm rows
+            eigvals = _sinc_eigenvalues(vecs, dx, fw)
+            if kmax == nf or eigvals[-1] < ec * (1.0 - 1e-6):
+                break
+            margin *= 2
+        close = np.where(np.abs(eigvals - ec) <= 1e-6 * ec)[0]
+        if len(close):
+            smat = np.sinc(2.0 * fw * (x[:, None] - x[None, :])) * 2.0 * dx * fw
+            eigvals[close] = np.sum((vecs[close] @ smat) * vecs[close], axis=1)
         nt = int(np.max(np.where(eigvals >= ec)))
         nterms.append(nt)
         blocks.append(np.exp(2j * np.pi * (x[:, None] - xc) * fc) * vecs[:nt].T)
@@ -65,9 +158,14 @@ def yield_dpss_model_comps_bl_grp(
     Baselines that round to the same delay share ONE ndarray through ``operator_cache`` (the C-ABI upload
     de-duplicates on object identity).
     """
+    return _dpss_block(dly_ns(length, horizon=horizon, min_dly=min_dly, offset=offset), freqs, eigenval_cutoff, operator_cache)
+
+
+def _dpss_block(delay_ns, freqs, eigenval_cutoff, operator_cache=None):
+    """The real DPSS block of one delay half width (ns), cached by delay: modeling.py:291-301."""
     if operator_cache is None:
         operator_cache = {}
-    dly = dly_ns(length, horizon=horizon, min_dly=min_dly, offset=offset) / 1e9
+    dly = delay_ns / 1e9
     key = ("bl_grp", dly, len(freqs), float(freqs[0]), float(freqs[-1]), eigenval_cutoff)
     if key not in operator_cache:
         operator_cache[key] = np.ascontiguousarray(
@@ -114,27 +212,50 @@ def yield_pbl_dpss_model_comps(
     notebook_progressbar=False,
     verbose=False,
 ):
-    """Per-baseline DPSS modeling components keyed by fitting group -- modeling.py:304-374."""
-    operator_cache = {}
-    _, red_grps, vec_bin_centers, _ = get_redundant_grps_data(
-        uvdata, remove_redundancy=not (use_redundancy), tol=red_tol, include_autos=include_autos
+    """Per-baseline DPSS modeling components keyed by fitting group -- modeling.py:304-374.
+
+    Same keys and values as the reference (``((antpair, ...),) -> (Nfreqs, Ncomponents)`` real array, groups of one
+    delay sharing ONE array object), built the other way round: the delay of every group first, then one DPSS block per
+    DISTINCT delay -- independent eigenproblems, solved side by side on the host's cores (SciPy's LAPACK calls release
+    the GIL) -- and only then the group -> block assignment.  HERA-350: 122 blocks for 61 075 groups."""
+    _, red_grps, centres, _ = get_redundant_grps_data(
+        uvdata, remove_redundancy=not use_redundancy, tol=red_tol, include_autos=include_autos
     )
-    fitting_grps = [(tuple(red_grp),) for red_grp in red_grps]
-    modeling_vectors = {}
-    freqs = uvdata.freq_array[0] if np.ndim(uvdata.freq_array) == 2 else uvdata.freq_array
+    freqs = _freqs_of(uvdata)
     echo(f"{datetime.datetime.now()} Computing DPSS modeling vectors...\n", verbose=verbose)
-    for grpnum in PBARS[notebook_progressbar](range(len(fitting_grps)), disable=not verbose):
-        bllen = np.linalg.norm(vec_bin_centers[grpnum])
-        modeling_vectors[fitting_grps[grpnum]] = yield_dpss_model_comps_bl_grp(
-            freqs=freqs,
-            length=bllen,
-            offset=offset,
-            horizon=horizon,
-            min_dly=min_dly,
-            operator_cache=operator_cache,
-            eigenval_cutoff=eigenval_cutoff,
-        )
-    return modeling_vectors
+    lengths = np.linalg.norm(np.asarray(centres, dtype=np.float64).reshape(len(red_grps), -1), axis=1) if len(red_grps) else np.zeros(0)
+    delays = [dly_ns(float(bllen), horizon=horizon, min_dly=min_dly, offset=offset) for bllen in lengths]
+    distinct = sorted(set(delays))
+    cache = {}
+
+    def block_of(dly):
+        # a private operator cache per task: the shared dict is only written from this thread, below
+        return _dpss_block(dly, freqs, eigenval_cutoff, {})
+
+    workers = max(1, min(len(distinct), _usable_cores()))
+    if workers > 1:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+            blocks = list(PBARS[notebook_progressbar](pool.map(block_of, distinct), total=len(distinct), disable=not verbose))
+    else:
+        blocks = [block_of(d) for d in PBARS[notebook_progressbar](distinct, disable=not verbose)]
+    cache.update(zip(distinct, blocks))
+    return {(tuple(grp),): cache[dly] for grp, dly in zip(red_grps, delays)}
+
+
+def _usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box hands a one-GPU job
+    16 of the host's 256 cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(float(quota) / float(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _freqs_of(uvdata):

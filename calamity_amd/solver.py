@@ -164,6 +164,12 @@ class HipFitSolver:
     def synchronize(self):
         _lib.check(self._lib.cal_solver_synchronize(self._h))
 
+    def set_launch_mode(self, mode="auto"):
+        """How a train step is issued: "auto", "kernels" (every kernel its own launch), "one_tail" (two launches per step),
+        "graph" (two-launch steps replayed from a hipGraph).  Same numbers in every mode."""
+        ids = {"auto": _lib.CAL_LAUNCH_AUTO, "kernels": _lib.CAL_LAUNCH_KERNELS, "one_tail": _lib.CAL_LAUNCH_ONE_TAIL, "graph": _lib.CAL_LAUNCH_GRAPH}
+        _lib.check(self._lib.cal_solver_set_launch_mode(self._h, ids[mode]))
+
     def timing_enable(self, enable=True):
         _lib.check(self._lib.cal_solver_timing_enable(self._h, int(bool(enable))))
 

@@ -54,6 +54,15 @@ enum cal_kernel_path {
                            group, basis_nvec <= 256, nfreqs > 64); CAL_ERR_UNSUPPORTED when it is not */
 };
 
+enum cal_launch_mode {
+  CAL_LAUNCH_AUTO = 0,     /* the fastest form for the problem: large problems one launch per kernel; problems whose step is tens of
+                              microseconds (no communicator, general kernels, at most 2^20 parameters) a two-launch step replayed
+                              from a hipGraph, 16 steps per replay */
+  CAL_LAUNCH_KERNELS = 1,  /* every kernel its own launch (per-antenna reduction, loop bookkeeping, regulariser fold, update) */
+  CAL_LAUNCH_ONE_TAIL = 2, /* small problems: fused pass + ONE tail launch per step, launched one by one (no graph) */
+  CAL_LAUNCH_GRAPH = 3     /* as AUTO where the two-launch step applies */
+};
+
 /* Ragged description of one fit (replaces the zero-padded chunk tensors built by
  * tensorize_fg_model_comps_dict / tensorize_data, calibration.py:104-310).
  * A fitting group g shares ONE coefficient vector of basis_nvec[grp_basis[g]] complex numbers; its baselines are
@@ -147,7 +156,8 @@ int cal_solver_set_optimizer(cal_solver* s, const cal_optimizer_desc* desc); /* 
 int cal_solver_set_params(cal_solver* s, const void* g_r, const void* g_i, const void* c_r, const void* c_i);
 /* .value() snapshots, calibration.py:706-710, :724-728.  which = 0: current parameters; 1: use_min snapshot */
 int cal_solver_get_params(cal_solver* s, int which, void* g_r, void* g_i, void* c_r, void* c_i);
-/* optimizer slots (checkpoint / resume; no counterpart in the reference): m and v (Adam) / u (Adamax) */
+/* optimizer slots (checkpoint / resume; no counterpart in the reference): m and v (Adam) / u (Adamax).  A fit resumed with
+ * set_params + set_moments (after set_optimizer, whose betas the bias corrections are rebuilt from) continues bit for bit. */
 int cal_solver_get_moments(cal_solver* s, void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i,
                            void* cv_r, void* cv_i, int64_t* t);
 int cal_solver_set_moments(cal_solver* s, const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i,
@@ -166,6 +176,10 @@ int cal_solver_model(cal_solver* s, void* model_r, void* model_i);
 int cal_solver_init_coeffs(cal_solver* s, const void* src_r, const void* src_i);
 
 int cal_solver_synchronize(cal_solver* s);
+/* How cal_solver_run issues a train step (cal_launch_mode).  Every mode computes the same numbers, bit for bit: the python
+ * loop of calibration.py:699-717 pays a host synchronisation per step (:701); here the choice is only how many launches a
+ * step costs. */
+int cal_solver_set_launch_mode(cal_solver* s, int mode);
 int cal_solver_timing_enable(cal_solver* s, int enable);
 int cal_solver_timing_get(cal_solver* s, cal_kernel_timing* out);
 int cal_solver_memory_bytes(cal_solver* s, int64_t* device_bytes);

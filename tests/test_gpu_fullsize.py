@@ -145,18 +145,25 @@ def test_hera350_against_the_c_oracle(hera350):
 
     p, start = hera350
     c = CRef(p, np.float64, nthreads=16)
-    s = solver_for(p, start, np.float64, "stream")
-    for reg in (False, True):
-        if reg:
-            pr, pi = float(np.sum(p.sky_r * p.wgts)) * 0.9, float(np.sum(p.sky_i * p.wgts)) * 1.1
-            c.set_regularization("sum", pr, pi)
-            s.set_regularization("sum", pr, pi)
-        loss, og_r, og_i, oc_r, oc_i = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
-        l2, hg_r, hg_i, hc_r, hc_i = s.eval_grads()
-        assert abs(l2 - loss) <= 1e-10 * abs(loss)
-        assert relnorm(hg_r, og_r) <= 1e-10 and relnorm(hg_i, og_i) <= 1e-10
-        assert relnorm(hc_r, oc_r) <= 1e-10 and relnorm(hc_i, oc_i) <= 1e-10
-    s.close()
+    # every fp64 kernel family DIRECTLY against the C oracle at 1e-10 (the dense kernel used to be tied to it
+    # only through the general kernel of the other layout): streaming general, shared general, shared dense (v_mfma_f64; with the
+    # regulariser its two-pass form)
+    refs = {}
+    for layout, path in (("stream", "general"), ("shared", "general"), ("shared", "dense")):
+        s = solver_for(p, start, np.float64, layout, kernel_path=path)
+        for reg in (False, True):
+            pr, pi = (float(np.sum(p.sky_r * p.wgts)) * 0.9, float(np.sum(p.sky_i * p.wgts)) * 1.1) if reg else (0.0, 0.0)
+            s.set_regularization("sum" if reg else None, pr, pi)
+            if reg not in refs:
+                c.set_regularization("sum" if reg else None, pr, pi)
+                refs[reg] = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+            loss, og_r, og_i, oc_r, oc_i = refs[reg]
+            l2, hg_r, hg_i, hc_r, hc_i = s.eval_grads()
+            assert abs(l2 - loss) <= 1e-10 * abs(loss), (layout, path, reg)
+            assert abs(s.eval_loss() - loss) <= 1e-10 * abs(loss), (layout, path, reg)
+            assert relnorm(hg_r, og_r) <= 1e-10 and relnorm(hg_i, og_i) <= 1e-10, (layout, path, reg)
+            assert relnorm(hc_r, oc_r) <= 1e-10 and relnorm(hc_i, oc_i) <= 1e-10, (layout, path, reg)
+        s.close()
     # fp32 streaming kernel, 5 Adam updates, against the fp64 C trajectory
     c.set_regularization(None)
     og_r, og_i, oc_r, oc_i, olosses, _ = c.fit(start["g_r"], start["g_i"], start["c_r"], start["c_i"], 5, optimizer="Adam", learning_rate=1e-2)
@@ -167,6 +174,39 @@ def test_hera350_against_the_c_oracle(hera350):
     assert np.allclose(losses, olosses, rtol=1e-4)
     assert relnorm(g_r, og_r) <= 1e-3 and relnorm(c_r, oc_r) <= 1e-3 and relnorm(c_i, oc_i) <= 1e-3
     s.close()
+
+
+@pytest.mark.parametrize("optimizer", ["Adam", "Adamax"])
+def test_hera350_resume_through_the_separate_update_kernel(hera350, optimizer):
+    """Checkpoint / resume at a size whose update runs as finalize_kernel + adam2_kernel (more than 2^20 parameters; the
+    one-launch tails of small problems are covered in test_gpu_launch_modes.py): 4 steps == 2 steps, get_params + get_moments,
+    a new solver, set_params + set_moments, 2 more steps -- bitwise."""
+    p, start = hera350
+
+    def fresh():
+        s = solver_for(p, start, np.float32, "shared")
+        s.set_optimizer(optimizer, learning_rate=1e-2)
+        return s
+
+    s = fresh()
+    l4, _, _ = s.run(4, record=True, tol=0.0)
+    want = s.get_params()
+    s.close()
+    s = fresh()
+    l2, _, _ = s.run(2, record=True, tol=0.0)
+    params, moments = s.get_params(), s.get_moments()
+    s.close()
+    t = moments.pop("t")
+    assert t == 2
+    s = fresh()
+    s.set_params(*params)
+    s.set_moments(**moments, t=t)
+    l2b, _, _ = s.run(2, record=True, tol=0.0)
+    got = s.get_params()
+    s.close()
+    np.testing.assert_array_equal(np.concatenate([l2, l2b]), l4)
+    for x, y in zip(got, want):
+        np.testing.assert_array_equal(x, y)
 
 
 def test_hera350_redundant_groups_against_the_c_oracle():

@@ -1,0 +1,125 @@
+"""GPU tests of the launch forms of a train step (include/calamity_hip.h: cal_launch_mode) and of checkpoint / resume.
+
+The reference's loop (/root/reference/calamity/calibration.py:699-717) pays a host synchronisation per step (:701).  Here
+a step of a small problem is two launches replayed from a hipGraph; "kernels" issues every kernel on its own (per-antenna
+reduction, bookkeeping, regulariser fold, update).  All forms must produce the SAME numbers, bit for bit: recorded
+losses, parameters, use_min snapshots, the step a tolerance stop or a non-finite loss lands on.
+"""
+import numpy as np
+import pytest
+
+from calamity_amd import _lib
+from test_gpu_parity import make_case, make_solver
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["kernels", "one_tail", "graph"]
+
+
+def run_fit(p, start, dtype, mode, optimizer="Adam", lr=2e-2, reg=False, nsteps=53, layout="stream", **run_kw):
+    s = make_solver(p, start, dtype, layout=layout, reg=reg)
+    s.set_launch_mode(mode)
+    s.set_optimizer(optimizer, learning_rate=lr)
+    s.run(1, record=False, freeze_model=run_kw.get("freeze_model", False))  # the unrecorded step of calibration.py:693
+    losses, stopped, nupd = s.run(nsteps, record=True, **run_kw)
+    cur = s.get_params()
+    snap = s.get_params(which=1) if run_kw.get("use_min") else None
+    s.close()
+    return losses, stopped, nupd, cur, snap
+
+
+def assert_same(a, b):
+    assert a[1] == b[1] and a[2] == b[2]
+    np.testing.assert_array_equal(a[0], b[0])
+    for x, y in zip(a[3], b[3]):
+        np.testing.assert_array_equal(x, y)
+    if a[4] is not None:
+        for x, y in zip(a[4], b[4]):
+            np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("optimizer", ["Adam", "Adamax"])
+@pytest.mark.parametrize("reg", [False, True])
+@pytest.mark.parametrize("layout", ["stream", "shared"])
+def test_trajectories_bit_identical_across_launch_modes(dtype, optimizer, reg, layout):
+    """53 recorded steps = three graph replays of 16 + 5 single steps (+ the unrecorded one in front), use_min on."""
+    p, start = make_case(seed=21, with_sky=reg, nants=10, nfreqs=72)
+    ref = run_fit(p, start, dtype, "kernels", optimizer=optimizer, reg=reg, layout=layout, use_min=True, tol=0.0)
+    assert len(ref[0]) == 53 and np.all(np.isfinite(ref[0])) and ref[0][-1] < ref[0][0]
+    for mode in MODES[1:] + ["auto"]:
+        assert_same(ref, run_fit(p, start, dtype, mode, optimizer=optimizer, reg=reg, layout=layout, use_min=True, tol=0.0))
+
+
+def test_split_groups_and_redundant_group_across_launch_modes():
+    """Groups cut into several work items (partial coefficient gradients summed in the tail) and a multi-baseline group."""
+    p, start = make_case(seed=5, nants=7, nfreqs=300, redundant=True)
+    ref = run_fit(p, start, np.float64, "kernels", nsteps=40, tol=0.0)
+    for mode in MODES[1:]:
+        assert_same(ref, run_fit(p, start, np.float64, mode, nsteps=40, tol=0.0))
+    ref = run_fit(p, start, np.float32, "kernels", nsteps=40, tol=0.0, reg=False, freeze_model=True)
+    for mode in MODES[1:]:
+        assert_same(ref, run_fit(p, start, np.float32, mode, nsteps=40, tol=0.0, freeze_model=True))
+
+
+def test_tolerance_stop_lands_on_the_same_step():
+    p, start = make_case(seed=7, perturb=False)
+    ref = run_fit(p, start, np.float64, "kernels", lr=5e-2, nsteps=400, tol=1e-6)
+    assert ref[1] and 20 < len(ref[0]) < 400  # stopped inside a replay, not at its edge
+    for mode in MODES[1:]:
+        assert_same(ref, run_fit(p, start, np.float64, mode, lr=5e-2, nsteps=400, tol=1e-6))
+
+
+def test_nonfinite_loss_stops_every_mode_at_the_same_update():
+    """A float32 fit driven to overflow: CAL_ERR_NONFINITE after the same number of updates, parameters as they were."""
+    p, start = make_case(seed=3)
+    out = []
+    for mode in MODES:
+        s = make_solver(p, start, np.float32)
+        s.set_launch_mode(mode)
+        s.set_optimizer("Adam", learning_rate=3e37)
+        with pytest.raises(_lib.CalamityHipError) as err:
+            s.run(64, record=True, tol=0.0)
+        assert err.value.code == _lib.CAL_ERR_NONFINITE
+        out.append((str(err.value), s.get_params()))
+        s.close()
+    for msg, params in out[1:]:
+        assert msg == out[0][0]
+        for x, y in zip(params, out[0][1]):
+            np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("optimizer", ["Adam", "Adamax"])
+@pytest.mark.parametrize("mode", ["kernels", "graph"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_resume_from_parameters_and_moments(optimizer, mode, dtype):
+    """Checkpoint / resume (no counterpart in the reference): 10 steps == 5 steps, get_params +
+    get_moments, a NEW solver, set_params + set_moments, 5 more steps -- bitwise, for both update paths (the separate
+    update kernel of large problems is covered in test_gpu_fullsize.py::test_hera350_resume_through_the_separate_update_kernel)."""
+    p, start = make_case(seed=13, nants=8, nfreqs=64)
+
+    def fresh():
+        s = make_solver(p, start, dtype)
+        s.set_launch_mode(mode)
+        s.set_optimizer(optimizer, learning_rate=1e-2)
+        return s
+
+    s = fresh()
+    l10, _, _ = s.run(10, record=True, tol=0.0)
+    want = s.get_params()
+    s.close()
+    s = fresh()
+    l5, _, _ = s.run(5, record=True, tol=0.0)
+    params, moments = s.get_params(), s.get_moments()
+    s.close()
+    t = moments.pop("t")
+    assert t == 5
+    s = fresh()  # set_optimizer has zeroed moments and the iteration count
+    s.set_params(*params)
+    s.set_moments(**moments, t=t)
+    l5b, _, _ = s.run(5, record=True, tol=0.0)
+    got = s.get_params()
+    s.close()
+    np.testing.assert_array_equal(np.concatenate([l5, l5b]), l10)
+    for x, y in zip(got, want):
+        np.testing.assert_array_equal(x, y)

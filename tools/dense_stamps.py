@@ -4,8 +4,8 @@ usage on the GPU box: python tools/dense_stamps.py calamity_amd/csrc/variants/li
 import sys, os, numpy as np, pickle, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["CALAMITY_HIP_LIB"] = os.path.abspath(sys.argv[1])
 from calamity_amd import synthetic, _lib
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])  # the -DCAL_STAMP build
 from calamity_amd.solver import HipFitSolver
 cache = "/tmp/kbench_problem.pkl"
 if os.path.exists(cache):
@@ -19,7 +19,7 @@ s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
 s.set_optimizer("Adam", learning_rate=1e-2)
 s.run(3, record=False)
 lib = _lib.load()
-buf = np.zeros((4096, 4, 8), dtype=np.int64)
+buf = np.zeros((4096, 4, 32), dtype=np.int64)
 rc = lib.cal_debug_read_stamps(buf.ctypes.data_as(C.c_void_p))
 print("rc", rc)
 nv = np.sort(prob.grp_nvec)[::-1]
@@ -38,4 +38,5 @@ print(f"share of panel lifetime: prologue {b[:, :, 4].mean() / life.mean():.3f} 
 ent = np.sort(b[:, 0, 6] - t0); ex = np.sort(b[:, :, 7].max(axis=1) - t0)
 for q in (0.5, 0.8, 0.9, 0.95, 0.99, 1.0):
     print(f"  {q:4.2f} of the panels entered by {ent[int(q * (npan - 1))]:9d}, exited by {ex[int(q * (npan - 1))]:9d}")
-np.save(os.path.join(ROOT, "gpurun_out", "dense_stamps.npy"), b)
+tag = sys.argv[2] if len(sys.argv) > 2 else "dense_stamps"
+np.save(os.path.join(ROOT, "gpurun_out", tag + ".npy"), b)

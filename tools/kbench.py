@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel experiment harness: time the fused basis kernel of several library builds on the same problem, in one
-process per build (CALAMITY_HIP_LIB selects the .so).  Usage: kbench.py [--config hera350] [--max-bls N] lib1.so lib2.so ..."""
+process per build (the child assigns calamity_amd._lib.LIB_PATH before the library is loaded).  Usage: kbench.py [--config hera350] [--max-bls N] lib1.so lib2.so ..."""
 import argparse
 import json
 import os
@@ -13,7 +13,10 @@ sys.path.insert(0, ROOT)
 
 def child(args):
     import numpy as np
-    from calamity_amd import synthetic
+    from calamity_amd import _lib, synthetic
+
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)  # experiment build instead of the shipped one
     from calamity_amd.solver import HipFitSolver
 
     dtype = np.float64 if args.dtype == "f64" else np.float32
@@ -63,6 +66,7 @@ if __name__ == "__main__":
     ap.add_argument("--redundant", action="store_true", help="merge redundant baselines into shared-coefficient groups")
     ap.add_argument("--cache", default="/tmp/kbench_problem.pkl")
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--lib", default=None, help="(child) the library build to load")
     ap.add_argument("libs", nargs="*")
     args = ap.parse_args()
     if args.child:
@@ -70,8 +74,7 @@ if __name__ == "__main__":
         sys.exit(0)
     for rnd in range(2):
         for lib in args.libs:
-            env = dict(os.environ, CALAMITY_HIP_LIB=os.path.abspath(lib))
-            cmd = [sys.executable, os.path.abspath(__file__), "--child"] + [a for a in sys.argv[1:] if not a.endswith(".so")]
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+            cmd = [sys.executable, os.path.abspath(__file__), "--child", "--lib", os.path.abspath(lib)] + [a for a in sys.argv[1:] if not a.endswith(".so")]
+            r = subprocess.run(cmd, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("KBENCH ")]
             print(rnd, os.path.basename(lib), line[0][7:] if line else ("FAILED " + r.stderr[-400:]), flush=True)
