@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcalamity_hip.so")  # the one shipped build; experiment harnesses (tools/) assign this attribute before load()
 
 CAL_F32, CAL_F64 = 0, 1
-CAL_OPT_ADAM, CAL_OPT_ADAMAX = 0, 1
+CAL_OPT_ADAM, CAL_OPT_ADAMAX, CAL_OPT_SGD, CAL_OPT_RMSPROP, CAL_OPT_ADAGRAD, CAL_OPT_NADAM, CAL_OPT_ADADELTA = range(7)
 CAL_REG_NONE, CAL_REG_SUM = 0, 1
 CAL_LAYOUT_STREAM, CAL_LAYOUT_SHARED = 0, 1
 CAL_PATH_AUTO, CAL_PATH_GENERAL, CAL_PATH_DENSE = 0, 1, 2
@@ -47,6 +47,11 @@ class OptimizerDesc(C.Structure):
         ("beta_1", C.c_double),
         ("beta_2", C.c_double),
         ("epsilon", C.c_double),
+        ("rho", C.c_double),
+        ("momentum", C.c_double),
+        ("initial_accumulator_value", C.c_double),
+        ("nesterov", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -107,7 +112,12 @@ SYMBOLS = {
     "cal_solver_memory_bytes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "cal_comm_unique_id": (C.c_int, [_P]),
     "cal_solver_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "cal_solver_set_exchange_hook": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
 }
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)  # cal_exchange_fn
+CAL_XCHG_F32, CAL_XCHG_F64, CAL_XCHG_I32 = 0, 1, 2
+CAL_XCHG_SUM, CAL_XCHG_MIN = 0, 1
 
 _lib = None
 

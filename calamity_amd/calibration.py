@@ -10,7 +10,8 @@ gradient-descent fitter: ``calibrate_and_model_dpss`` (:1503-1584) -> ``calibrat
   (:140-146, :167); ``fg_comps`` arguments accept either form;
 * ``graph_mode`` / ``graph_args_dict`` are accepted and ignored (there is no tracing compiler on this path);
 * ``n_profile_steps`` writes HIP-event kernel timings as JSON into ``profile_log_dir`` instead of a TF profile;
-* optimizers: "Adam" and "Adamax" (Keras semantics); every other name raises ``KeyError`` like ``OPTIMIZERS[...]`` (:571).
+* optimizers: "Adamax", "Adam", "SGD", "RMSprop", "Adagrad", "Adadelta", "Nadam" with the Keras (OptimizerV2) semantics, defaults
+  and constructor arguments; "Ftrl", "LAMB" and every other name raise ``KeyError`` like ``OPTIMIZERS[...]`` (:571).
 
 There is no CPU fallback: without the HIP library / a GPU these functions raise.
 """

@@ -19,6 +19,7 @@
 #include "dense_kernels.hpp"
 #include "dense64_kernels.hpp"
 #include <cstdlib>
+#include <dlfcn.h>
 #include <type_traits>
 
 using namespace calk;
@@ -83,6 +84,29 @@ struct DevBuf {  // owning device allocation
   template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
 };
 
+// roctx ranges around the chunks of a PROFILED run (n_profile_steps of the reference wraps its profiled steps in
+// tf.profiler.experimental.Trace, calibration.py:681-687): rocprofv3 --marker-trace then shows "calamity: train steps [a, b)"
+// over the kernels of each chunk.  The marker library is looked up at run time; without it the ranges are no-ops.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr;
+        pop = nullptr;
+      }
+    }
+  }
+};
+inline Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+
 inline int grid_for(long long n, int block = 256, int cap = 16384) {
   long long g = (n + block - 1) / block;
   return (int)std::max<long long>(1, std::min<long long>(g, cap));
@@ -115,6 +139,7 @@ struct cal_solver {
   virtual int memory_bytes(int64_t* b) = 0;
   virtual int comm_init(const void* id, int rank, int nranks) = 0;
   virtual int set_launch_mode(int mode) = 0;
+  virtual int set_exchange_hook(cal_exchange_fn fn, void* ctx, int rank, int nranks) = 0;
 };
 
 template <typename T>
@@ -167,7 +192,7 @@ struct SolverT final : cal_solver {
   DevState* st_cur() { return state.as<DevState>() + st_par; }
   DevState* st_nxt() { return state.as<DevState>() + (st_par ^ 1); }
   // settings
-  cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7};
+  cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7, 0.9, 0.0, 0.1, 0, 0};
   int reg = CAL_REG_NONE;
   double prior_r = 0, prior_i = 0;
   // timing
@@ -179,10 +204,18 @@ struct SolverT final : cal_solver {
   // comm
   ncclComm_t nccl = nullptr;
   int nranks = 1, rank = 0;
+  // caller-supplied exchange (cal_solver_set_exchange_hook): the same buffers and counts RCCL would reduce, staged through
+  // pinned host memory and reduced by the callback
+  cal_exchange_fn hook = nullptr;
+  void* hook_ctx = nullptr;
+  void* hook_buf = nullptr;
+  size_t hook_bytes = 0;
+  bool comm_on() const { return nccl != nullptr || hook != nullptr; }
 
   ~SolverT() override {
     (void)hipSetDevice(device);
     if (nccl) (void)ncclCommDestroy(nccl);
+    if (hook_buf) (void)hipHostFree(hook_buf);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     for (auto& e : ev_pool) {
       (void)hipEventDestroy(e.first);
@@ -236,7 +269,7 @@ struct SolverT final : cal_solver {
   // a rank that built the dense path while another could not drops back to the general kernels (same buffers).
   int set_problem(const cal_problem_desc* d) override {
     const int rc = set_problem_local(d);
-    if (!nccl) return rc;
+    if (!comm_on()) return rc;
     const std::string msg = g_err;
     int v[2] = {rc == CAL_OK ? (mf_ok ? 1 : 0) : -1, rc == CAL_OK ? steps_per_sync : (1 << 30)};
     const int arc = agree_min(v, 2);
@@ -744,11 +777,35 @@ struct SolverT final : cal_solver {
   }
 
   // min over the ranks of the communicator (set-up decisions that every rank must take identically)
+  // one in-place all-reduce over the ranks of the job, on the solver's stream: RCCL, or the caller's exchange hook (the
+  // stream is drained, the buffer staged through pinned host memory, reduced by the callback and copied back)
+  int all_reduce(void* dev, size_t count, int dtype_code, int op) {
+    if (nccl) {
+      const ncclDataType_t dt = dtype_code == CAL_XCHG_F32 ? ncclFloat : dtype_code == CAL_XCHG_F64 ? ncclDouble : ncclInt32;
+      NCCL_TRY(ncclAllReduce(dev, dev, count, dt, op == CAL_XCHG_MIN ? ncclMin : ncclSum, nccl, stream));
+      return CAL_OK;
+    }
+    if (!hook) return CAL_OK;
+    const size_t bytes = count * (dtype_code == CAL_XCHG_F64 ? 8 : 4);
+    if (hook_bytes < bytes) {
+      if (hook_buf) (void)hipHostFree(hook_buf);
+      hook_buf = nullptr;
+      hook_bytes = 0;
+      HIP_TRY(hipHostMalloc(&hook_buf, bytes, hipHostMallocDefault));
+      hook_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(hook_buf, dev, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const int rc = hook(hook_ctx, hook_buf, (int64_t)count, dtype_code, op);
+    if (rc != 0) return fail(CAL_ERR_RCCL, "the exchange hook returned %d", rc);
+    HIP_TRY(hipMemcpyAsync(dev, hook_buf, bytes, hipMemcpyHostToDevice, stream));
+    return CAL_OK;
+  }
   int agree_min(int* v, int n) {
-    if (!nccl) return CAL_OK;
+    if (!comm_on()) return CAL_OK;
     if (!agree_buf.p) CAL_TRY(agree_buf.alloc(4 * sizeof(int)));
     HIP_TRY(hipMemcpyAsync(agree_buf.p, v, n * sizeof(int), hipMemcpyHostToDevice, stream));
-    NCCL_TRY(ncclAllReduce(agree_buf.p, agree_buf.p, n, ncclInt32, ncclMin, nccl, stream));
+    CAL_TRY(all_reduce(agree_buf.p, n, CAL_XCHG_I32, CAL_XCHG_MIN));
     HIP_TRY(hipMemcpyAsync(v, agree_buf.p, n * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return CAL_OK;
@@ -821,16 +878,27 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipSetDevice(device));
     if (!has_problem) return fail(CAL_ERR_STATE, "set_optimizer before set_problem");
     if (!d) return fail(CAL_ERR_INVALID, "set_optimizer: null");
-    if (d->optimizer != CAL_OPT_ADAM && d->optimizer != CAL_OPT_ADAMAX)
+    if (d->optimizer < CAL_OPT_ADAM || d->optimizer > CAL_OPT_ADADELTA)
       return fail(CAL_ERR_INVALID, "set_optimizer: unknown optimizer id %d", d->optimizer);
     opt = *d;
     HIP_TRY(hipMemsetAsync(gains_m.p, 0, gains_m.bytes, stream));
-    HIP_TRY(hipMemsetAsync(gains_v.p, 0, gains_v.bytes, stream));
     HIP_TRY(hipMemsetAsync(coef_m.p, 0, coef_m.bytes, stream));
-    HIP_TRY(hipMemsetAsync(coef_v.p, 0, coef_v.bytes, stream));
+    if (d->optimizer == CAL_OPT_ADAGRAD && d->initial_accumulator_value != 0.0) {
+      // Adagrad's accumulator starts at initial_accumulator_value (Keras default 0.1)
+      hipLaunchKernelGGL(fill_kernel<T>, dim3(grid_for((long long)(gains_v.bytes / sizeof(T)))), dim3(256), 0, stream, gains_v.as<T>(),
+                         (long long)(gains_v.bytes / sizeof(T)), (T)d->initial_accumulator_value);
+      hipLaunchKernelGGL(fill_kernel<T>, dim3(grid_for((long long)(coef_v.bytes / sizeof(T)))), dim3(256), 0, stream, coef_v.as<T>(),
+                         (long long)(coef_v.bytes / sizeof(T)), (T)d->initial_accumulator_value);
+      HIP_TRY(hipGetLastError());
+    } else {
+      HIP_TRY(hipMemsetAsync(gains_v.p, 0, gains_v.bytes, stream));
+      HIP_TRY(hipMemsetAsync(coef_v.p, 0, coef_v.bytes, stream));
+    }
+    drop_graph();
     // a new fit begins: loop state of calibration.py:573-574
     h_state->t = 0;
     h_state->b1t = h_state->b2t = 1.0;
+    h_state->nadam_sched = 1.0;
     h_state->min_loss = 9e99;
     h_state->prev_loss = 0;
     h_state->n_recorded_total = 0;
@@ -907,13 +975,15 @@ struct SolverT final : cal_solver {
     // beta^t as the device keeps it: a running product, one factor per update (pow() differs from it in the last bits, and a
     // resumed fit must continue bit for bit).  Uses the betas of the optimizer set so far: set_optimizer comes first.
     h_state->t = t;
-    double b1t = 1.0, b2t = 1.0;
+    double b1t = 1.0, b2t = 1.0, sched = 1.0;
     for (int64_t k = 0; k < t; ++k) {
       b1t *= opt.beta_1;
       b2t *= opt.beta_2;
+      sched *= opt.beta_1 * (1.0 - 0.5 * std::pow(0.96, 0.004 * (double)(k + 1)));  // Nadam's momentum schedule (advance_state)
     }
     h_state->b1t = b1t;
     h_state->b2t = b2t;
+    h_state->nadam_sched = sched;
     return CAL_OK;
   }
 
@@ -1027,7 +1097,7 @@ struct SolverT final : cal_solver {
           hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                              ant_ptr.as<int>(), ant_ent.as<int2>(), comm.as<T2>(), comm.as<T2>(), comm.as<T2>(), 0, fpad, part.as<double>(),
                              mf_npanels, scal.as<double>(), st);
-          if (nccl) NCCL_TRY(ncclAllReduce(scal.p, scal.p, 4, ncclDouble, ncclSum, nccl, stream));
+          if (comm_on()) CAL_TRY(all_reduce(scal.p, 4, CAL_XCHG_F64, CAL_XCHG_SUM));
           hipLaunchKernelGGL(alpha_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>());
           m.use_alpha = 1;
         }
@@ -1072,14 +1142,16 @@ struct SolverT final : cal_solver {
       hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                          ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, 0, fpad, part.as<double>(), n_parts, scal.as<double>(), st);
     }
-    if (nccl) {
+    if (comm_on()) {
       // the one exchange step of the sharded fit: sum gain-gradient parts and loss scalars over ranks
       // (issued for a 1-rank communicator too, so the path can be exercised on a single GPU)
-      NCCL_TRY(ncclGroupStart());
-      if (grads)
-        NCCL_TRY(ncclAllReduce(r0, r0, (Rk ? 3 : 1) * gn * 2, sizeof(T) == 4 ? ncclFloat : ncclDouble, ncclSum, nccl, stream));
-      NCCL_TRY(ncclAllReduce(scal.p, scal.p, 4, ncclDouble, ncclSum, nccl, stream));
-      NCCL_TRY(ncclGroupEnd());
+      const int gdt = sizeof(T) == 4 ? CAL_XCHG_F32 : CAL_XCHG_F64;
+      if (nccl) NCCL_TRY(ncclGroupStart());
+      int rc = CAL_OK;
+      if (grads) rc = all_reduce(r0, (size_t)(Rk ? 3 : 1) * gn * 2, gdt, CAL_XCHG_SUM);
+      if (rc == CAL_OK) rc = all_reduce(scal.p, 4, CAL_XCHG_F64, CAL_XCHG_SUM);
+      if (nccl) NCCL_TRY(ncclGroupEnd());
+      CAL_TRY(rc);
     }
     if (!fused_tail)
       hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>(), losses.as<double>(), losses_cap,
@@ -1099,12 +1171,12 @@ struct SolverT final : cal_solver {
   bool tail_fits_one_launch() const { return 2LL * nants * fpad + 2LL * ncoef <= (1LL << 20); }
   // Problems whose step is tens of microseconds: the whole tail as ONE launch (step_tail_kernel) -- no communicator (the
   // exchange sits between the reduction and the update), general kernels, and not when every kernel is asked to be its own launch
-  bool one_launch_tail() const { return !nccl && !mf_ok && tail_fits_one_launch() && launch_mode != CAL_LAUNCH_KERNELS; }
-  template <int OPT> void launch_tail(const TailArgs<T>& a, unsigned grid, bool R) {
+  bool one_launch_tail() const { return !comm_on() && !mf_ok && tail_fits_one_launch() && launch_mode != CAL_LAUNCH_KERNELS; }
+  void launch_tail(const TailArgs<T>& a, unsigned grid, bool R) {
     if (R)
-      hipLaunchKernelGGL((step_tail_kernel<T, OPT, true>), dim3(grid), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL((step_tail_kernel<T, true>), dim3(grid), dim3(256), 0, stream, a);
     else
-      hipLaunchKernelGGL((step_tail_kernel<T, OPT, false>), dim3(grid), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL((step_tail_kernel<T, false>), dim3(grid), dim3(256), 0, stream, a);
   }
   int enqueue_tail(bool freeze_model, int losses_cap) {
     const bool R = reg == CAL_REG_SUM;
@@ -1137,7 +1209,7 @@ struct SolverT final : cal_solver {
     a.losses_cap = losses_cap;
     const long long nblk_c = freeze_model ? 0 : std::min<long long>((2LL * ncoef + 255) / 256, 4096);
     const unsigned grid = (unsigned)(a.nblk_gain + nblk_c);
-    if (opt.optimizer == CAL_OPT_ADAM) launch_tail<0>(a, grid, R); else launch_tail<1>(a, grid, R);
+    launch_tail(a, grid, R);
     st_par ^= 1;
     std::swap(gains.p, gains_alt.p);  // the buffer just written is the current one
     HIP_TRY(hipGetLastError());
@@ -1159,20 +1231,13 @@ struct SolverT final : cal_solver {
         ps = PartialSum<T>{gcp0.as<T>(), gcp0.as<T>() + gcp_len, coef_grp.as<int>(), grp_coff.as<int>(), grp_item_ptr.as<int>(),
                            item_goff.as<int>(), ncoef};
       const unsigned nb = (unsigned)std::max(1, std::min(nblk_a + nblk_b, 16384));
-      if (opt.optimizer == CAL_OPT_ADAM)
-        hipLaunchKernelGGL((step_update_kernel<T, 0>), dim3(nb), dim3(256), 0, stream, ga, ca, ps, st, st_nxt(), scal.as<double>(),
-                           losses.as<double>(), losses_cap);
-      else
-        hipLaunchKernelGGL((step_update_kernel<T, 1>), dim3(nb), dim3(256), 0, stream, ga, ca, ps, st, st_nxt(), scal.as<double>(),
-                           losses.as<double>(), losses_cap);
+      hipLaunchKernelGGL((step_update_kernel<T>), dim3(nb), dim3(256), 0, stream, ga, ca, ps, st, st_nxt(), scal.as<double>(),
+                         losses.as<double>(), losses_cap);
       st_par ^= 1;
       HIP_TRY(hipGetLastError());
       return CAL_OK;
     }
-    if (opt.optimizer == CAL_OPT_ADAM)
-      hipLaunchKernelGGL((adam2_kernel<T, 0>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st);
-    else
-      hipLaunchKernelGGL((adam2_kernel<T, 1>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st);
+    hipLaunchKernelGGL((adam2_kernel<T>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st);
     HIP_TRY(hipGetLastError());
     return CAL_OK;
   }
@@ -1226,6 +1291,10 @@ struct SolverT final : cal_solver {
     h_state->beta1 = opt.beta_1;
     h_state->beta2 = opt.beta_2;
     h_state->eps = opt.epsilon;
+    h_state->opt = opt.optimizer;
+    h_state->nesterov = opt.nesterov;
+    h_state->momentum = opt.momentum;
+    h_state->rho = opt.rho;
     h_state->reg = reg == CAL_REG_SUM;
     h_state->f32 = std::is_same<T, float>::value ? 1 : 0;
     h_state->prior_r = prior_r;
@@ -1306,6 +1375,12 @@ struct SolverT final : cal_solver {
     int issued = 0;
     while (issued < r->nsteps) {
       const int n = std::min(chunk, r->nsteps - issued);
+      const bool mark = timing && roctx().push;
+      if (mark) {
+        char label[96];
+        snprintf(label, sizeof(label), "calamity: train steps [%d, %d)%s", issued, issued + n, r->record ? "" : " (unrecorded)");
+        roctx().push(label);
+      }
       int s = 0;
       if (replay) {
         for (; s + kGraphSteps <= n; s += kGraphSteps) CAL_TRY(replay_steps(r->freeze_model != 0, cap));
@@ -1315,7 +1390,9 @@ struct SolverT final : cal_solver {
         if (tail1) CAL_TRY(enqueue_tail(r->freeze_model != 0, cap)); else CAL_TRY(enqueue_update(r->freeze_model != 0, cap));
       }
       issued += n;
-      CAL_TRY(pull_state());
+      const int prc = pull_state();
+      if (mark) roctx().pop();
+      CAL_TRY(prc);
       if (timing) CAL_TRY(collect_timing());
       if (h_state->done || h_state->done_after || h_state->nonfinite) break;
     }
@@ -1425,8 +1502,29 @@ struct SolverT final : cal_solver {
     static_assert(sizeof(ncclUniqueId) <= CAL_COMM_ID_BYTES, "unique id does not fit");
     memcpy(&uid, id, sizeof(uid));
     NCCL_TRY(ncclCommInitRank(&nccl, nr, uid, rk));
+    hook = nullptr;
+    return joined(rk, nr);
+  }
+  int set_exchange_hook(cal_exchange_fn fn, void* ctx, int rk, int nr) override {
+    HIP_TRY(hipSetDevice(device));
+    if (fn && (nr < 1 || rk < 0 || rk >= nr)) return fail(CAL_ERR_INVALID, "set_exchange_hook: bad rank/nranks");
+    if (nccl) {
+      (void)ncclCommDestroy(nccl);
+      nccl = nullptr;
+    }
+    hook = fn;
+    hook_ctx = ctx;
+    if (!fn) {
+      nranks = 1;
+      rank = 0;
+      return CAL_OK;
+    }
+    return joined(rk, nr);
+  }
+  int joined(int rk, int nr) {
     nranks = nr;
     rank = rk;
+    drop_graph();
     if (has_problem) {
       // a problem set before the communicator existed: agree now (fpad is rank-independent by construction; a rank
       // that chose the dense path falls back to the general kernel, which runs on the same buffers)
@@ -1614,5 +1712,6 @@ int cal_comm_unique_id(void* id_out) {
   return CAL_OK;
 }
 int cal_solver_comm_init(cal_solver* s, const void* id, int rank, int nranks) { NEED(s); return s->comm_init(id, rank, nranks); }
+int cal_solver_set_exchange_hook(cal_solver* s, cal_exchange_fn fn, void* ctx, int rank, int nranks) { NEED(s); return s->set_exchange_hook(fn, ctx, rank, nranks); }
 
 }  // extern "C"

@@ -60,7 +60,13 @@ struct DevState {
   int nonfinite;
   int nupdates;
   int f32;            // the fit runs in float32: loop decisions compare float32 losses, as loss.numpy() of a float32 fit does (:701, :712)
+  int opt;            // cal_optimizer (OPTIMIZERS, :17-27)
+  int nesterov;       // SGD
+  double momentum, rho;      // SGD / RMSprop momentum; RMSprop / Adadelta decay
+  double nadam_sched;        // Nadam: running product of its momentum schedule (Keras' _m_cache), 1 before the first update
+  double k[6];               // the current step's update coefficients, per optimizer: see optimizer_step
 };
+enum { OPT_ADAM = 0, OPT_ADAMAX = 1, OPT_SGD = 2, OPT_RMSPROP = 3, OPT_ADAGRAD = 4, OPT_NADAM = 5, OPT_ADADELTA = 6 };
 
 struct Item {        // one workgroup's share of a fitting group
   int bl0;           // first baseline of the GROUP
@@ -157,6 +163,13 @@ __device__ __forceinline__ void fma_cols(double2& acc, const double __attribute_
   acc.x += a[0] * b[0].x + a[1] * b[1].x;
   acc.y += a[0] * b[0].y + a[1] * b[1].y;
 }
+
+// Fused multiply-add spelled out.  Code that two different kernels must evaluate to the SAME bits (the launch forms of a step:
+// gain_grad_kernel / step_tail_kernel, combine_* / step_tail_kernel, every update kernel) cannot leave a * b + c to the
+// compiler, which contracts it or not depending on the surrounding code: it uses fma_() where a fused operation is wanted and
+// `#pragma clang fp contract(off)` where it is not.
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 template <typename T> __device__ __forceinline__ T ldsum(T v) {
   // full-wave butterfly sum
@@ -828,6 +841,83 @@ __global__ void coeff_partial_reduce_kernel(const T* __restrict__ gcp_r, const T
   gc_i[n] = b;
 }
 
+// The per-antenna reduction shared by gain_grad_kernel and step_tail_kernel (ONE body: the two launch forms of a step must
+// agree bit for bit).  The calling block is 256 threads = 4 segments of the antenna's sorted baseline list; lane = CPL adjacent
+// channels starting at f.  Returns true on the lanes of segment 0 that own channels (f < fpad): they hold the sums
+// s0 (and s1, s2 with the regulariser), combined over the four segments in fixed order through s_part.
+template <typename T, bool REG>
+__device__ __forceinline__ bool antenna_sums(const vec2_t<T>* __restrict__ q0, const vec2_t<T>* __restrict__ q1, const vec2_t<T>* __restrict__ gains,
+                                             const int* __restrict__ ant_ptr, const int2* __restrict__ ant_ent, int a, int f, int fpad,
+                                             T (*s_part)[3][64][2 * (16 / (int)sizeof(vec2_t<T>) > 0 ? 16 / (int)sizeof(vec2_t<T>) : 1)],
+                                             T* s0, T* s1, T* s2) {
+  constexpr int CPL = 16 / (int)sizeof(vec2_t<T>) > 0 ? 16 / (int)sizeof(vec2_t<T>) : 1;
+  typedef T vec_t __attribute__((ext_vector_type(2 * CPL)));
+  const int lane = threadIdx.x & 63;
+  const int seg = threadIdx.x >> 6;
+  const bool ok = f < fpad;  // fpad is a multiple of CPL
+#pragma unroll
+  for (int c = 0; c < 2 * CPL; ++c) s0[c] = s1[c] = s2[c] = 0;
+  const int e0 = ant_ptr[a], e1 = ant_ptr[a + 1];
+  const int per = (e1 - e0 + 3) >> 2;
+  const int eb = e0 + seg * per, ee = min(e1, eb + per);
+  if (ok) {
+#pragma unroll 8  // eight rows' loads in flight per wave (4: 25 us slower behind the streaming kernel at HERA-350; one channel per lane: 50 us slower)
+    for (int e = eb; e < ee; ++e) {
+      const int2 ent = ant_ent[e];  // (bl * 2 + role, other antenna): wave-uniform
+      const int bl = ent.x >> 1;
+      const int role = ent.x & 1;
+      const vec_t q = *reinterpret_cast<const vec_t*>(q0 + (long long)bl * fpad + f);
+      const vec_t go = *reinterpret_cast<const vec_t*>(gains + (long long)ent.y * fpad + f);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const T qr = q[2 * c], qi = role ? -q[2 * c + 1] : q[2 * c + 1];
+        s0[2 * c] = fma_(-qi, go[2 * c + 1], fma_(qr, go[2 * c], s0[2 * c]));
+        s0[2 * c + 1] = fma_(qi, go[2 * c], fma_(qr, go[2 * c + 1], s0[2 * c + 1]));
+      }
+      if (REG) {
+        const vec_t p = *reinterpret_cast<const vec_t*>(q1 + (long long)bl * fpad + f);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const T pr = p[2 * c], pi = p[2 * c + 1];
+          if (role == 0) {
+            s1[2 * c] = fma_(-pi, go[2 * c + 1], fma_(pr, go[2 * c], s1[2 * c]));
+            s1[2 * c + 1] = fma_(pi, go[2 * c], fma_(pr, go[2 * c + 1], s1[2 * c + 1]));
+          } else {
+            s2[2 * c] = fma_(pi, go[2 * c + 1], fma_(pr, go[2 * c], s2[2 * c]));
+            s2[2 * c + 1] = fma_(-pi, go[2 * c], fma_(pr, go[2 * c + 1], s2[2 * c + 1]));
+          }
+        }
+      }
+    }
+  }
+  if (seg > 0) {
+#pragma unroll
+    for (int c = 0; c < 2 * CPL; ++c) {
+      s_part[seg - 1][0][lane][c] = s0[c];
+      if (REG) {
+        s_part[seg - 1][1][lane][c] = s1[c];
+        s_part[seg - 1][2][lane][c] = s2[c];
+      }
+    }
+  }
+  __syncthreads();
+  if (seg == 0 && ok) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+      for (int c = 0; c < 2 * CPL; ++c) {
+        s0[c] += s_part[g][0][lane][c];
+        if (REG) {
+          s1[c] += s_part[g][1][lane][c];
+          s2[c] += s_part[g][2][lane][c];
+        }
+      }
+    }
+    return true;
+  }
+  return false;
+}
+
 // ---- per-antenna segmented reduction of gbar_G (gradient of the gain gathers) + loss partial sums.
 // block = (antenna a, 64 * CPL channels); the antenna's baselines are a sorted CSR list (entry = bl * 2 + role, other
 // antenna) split into 4 segments, one per wave; lane = CPL adjacent channels (16-byte loads of gbar_G and of the other
@@ -882,68 +972,10 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
   const int cb = blockIdx.x / nants;
   const int a = blockIdx.x - cb * nants;
   const int lane = threadIdx.x & 63;
-  const int seg = threadIdx.x >> 6;
   const int f = (cb * 64 + lane) * CPL;
-  const bool ok = f < fpad;  // fpad is a multiple of CPL
   T s0[2 * CPL], s1[2 * CPL], s2[2 * CPL];
-#pragma unroll
-  for (int c = 0; c < 2 * CPL; ++c) s0[c] = s1[c] = s2[c] = 0;
-  const int e0 = ant_ptr[a], e1 = ant_ptr[a + 1];
-  const int per = (e1 - e0 + 3) >> 2;
-  const int eb = e0 + seg * per, ee = min(e1, eb + per);
-  if (ok) {
-#pragma unroll 8  // eight rows' loads in flight per wave (4: 25 us slower behind the streaming kernel at HERA-350; one channel per lane: 50 us slower)
-    for (int e = eb; e < ee; ++e) {
-      const int2 ent = ant_ent[e];  // (bl * 2 + role, other antenna): wave-uniform
-      const int bl = ent.x >> 1;
-      const int role = ent.x & 1;
-      const vec_t q = *reinterpret_cast<const vec_t*>(q0 + (long long)bl * fpad + f);
-      const vec_t go = *reinterpret_cast<const vec_t*>(gains + (long long)ent.y * fpad + f);
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const T qr = q[2 * c], qi = role ? -q[2 * c + 1] : q[2 * c + 1];
-        s0[2 * c] += qr * go[2 * c] - qi * go[2 * c + 1];
-        s0[2 * c + 1] += qr * go[2 * c + 1] + qi * go[2 * c];
-      }
-      if (REG) {
-        const vec_t p = *reinterpret_cast<const vec_t*>(q1 + (long long)bl * fpad + f);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          const T pr = p[2 * c], pi = p[2 * c + 1];
-          if (role == 0) {
-            s1[2 * c] += pr * go[2 * c] - pi * go[2 * c + 1];
-            s1[2 * c + 1] += pr * go[2 * c + 1] + pi * go[2 * c];
-          } else {
-            s2[2 * c] += pr * go[2 * c] + pi * go[2 * c + 1];
-            s2[2 * c + 1] += pr * go[2 * c + 1] - pi * go[2 * c];
-          }
-        }
-      }
-    }
-  }
-  if (seg > 0) {
-#pragma unroll
-    for (int c = 0; c < 2 * CPL; ++c) {
-      s_part[seg - 1][0][lane][c] = s0[c];
-      if (REG) {
-        s_part[seg - 1][1][lane][c] = s1[c];
-        s_part[seg - 1][2][lane][c] = s2[c];
-      }
-    }
-  }
-  __syncthreads();
-  if (seg == 0 && ok) {
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-#pragma unroll
-      for (int c = 0; c < 2 * CPL; ++c) {
-        s0[c] += s_part[g][0][lane][c];
-        if (REG) {
-          s1[c] += s_part[g][1][lane][c];
-          s2[c] += s_part[g][2][lane][c];
-        }
-      }
-    }
+  const bool mine = antenna_sums<T, REG>(q0, q1, gains, ant_ptr, ant_ent, a, f, fpad, s_part, s0, s1, s2);
+  if (mine) {
     vec_t o0, o1, o2;
 #pragma unroll
     for (int c = 0; c < 2 * CPL; ++c) {
@@ -960,55 +992,163 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
   }
 }
 
-// ---- loop bookkeeping of calibration.py:699-717 on the device (one thread)
-__global__ void finalize_kernel(DevState* st, const double* __restrict__ scal, double* __restrict__ losses, int losses_cap,
-                                int apply_update) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (st->done) return;
-  if (st->done_after) {
-    st->done = 1;
-    return;
+// ---- loop bookkeeping of calibration.py:699-717 on the device: one function for the three kernels that run it
+// (finalize_kernel: large problems, one thread; step_update_kernel / step_tail_kernel: thread 0 of every block).
+// s: the state BEFORE this step, advanced in place; l0, l1, l2: the reduced loss sums (chi^2, S_r, S_i).  Returns whether the
+// step updates the parameters.  `writer` records the loss (one block does).
+__device__ inline bool advance_state(DevState& s, double l0, double l1, double l2, bool writer, double* __restrict__ losses, int losses_cap,
+                                     bool apply_update) {
+  if (s.done) return false;
+  if (s.done_after) {
+    s.done = 1;
+    return false;
   }
-  double loss = scal[0];
-  if (st->reg) {
-    st->s_r = scal[1];
-    st->s_i = scal[2];
-    const double dr = scal[1] - st->prior_r, di = scal[2] - st->prior_i;
+  double loss = l0;
+  if (s.reg) {
+    s.s_r = l1;
+    s.s_i = l2;
+    const double dr = l1 - s.prior_r, di = l2 - s.prior_i;
     loss += dr * dr + di * di;
-    st->alpha_r = 2.0 * dr;
-    st->alpha_i = 2.0 * di;
+    s.alpha_r = 2.0 * dr;
+    s.alpha_i = 2.0 * di;
   }
-  st->loss = loss;
-  st->improved = 0;
-  if (!apply_update) return;
+  s.loss = loss;
+  s.improved = 0;
+  if (!apply_update) return false;
   if (!(loss == loss) || loss > 1.7e308 || loss < -1.7e308) {
     // non-finite loss: never silently continued: stop before this step's update
-    st->nonfinite = 1;
-    st->done = 1;
-    return;
+    s.nonfinite = 1;
+    s.done = 1;
+    return false;
   }
-  st->t += 1;
-  st->nupdates += 1;
-  st->b1t *= st->beta1;
-  st->b2t *= st->beta2;
-  st->bc1 = 1.0 - st->b1t;
-  st->lr_t = st->lr * sqrt(1.0 - st->b2t) / st->bc1;
-  st->lr_u = st->lr / st->bc1;
-  if (st->record) {
-    if (st->n_recorded < losses_cap) losses[st->n_recorded] = loss;
-    st->n_recorded += 1;
+  s.t += 1;
+  s.nupdates += 1;
+  s.b1t *= s.beta1;
+  s.b2t *= s.beta2;
+  s.bc1 = 1.0 - s.b1t;
+  s.lr_t = s.lr * sqrt(1.0 - s.b2t) / s.bc1;
+  s.lr_u = s.lr / s.bc1;
+  // the step's update coefficients (Keras OptimizerV2 semantics; optimizer_step reads them)
+  s.k[0] = s.lr;
+  switch (s.opt) {
+    case OPT_ADAM: s.k[0] = s.lr_t; break;
+    case OPT_ADAMAX: s.k[0] = s.lr_u; break;
+    case OPT_SGD: s.k[1] = s.momentum; s.k[2] = s.nesterov ? 1.0 : 0.0; break;
+    case OPT_RMSPROP: s.k[1] = s.rho; s.k[2] = s.momentum; break;
+    case OPT_ADADELTA: s.k[1] = s.rho; break;
+    case OPT_NADAM: {
+      const double mu_t = s.beta1 * (1.0 - 0.5 * pow(0.96, 0.004 * (double)s.t));
+      const double mu_t1 = s.beta1 * (1.0 - 0.5 * pow(0.96, 0.004 * (double)(s.t + 1)));
+      const double sched_new = s.nadam_sched * mu_t, sched_next = sched_new * mu_t1;
+      s.nadam_sched = sched_new;
+      s.k[1] = 1.0 - sched_new;
+      s.k[2] = 1.0 - sched_next;
+      s.k[3] = 1.0 - s.b2t;
+      s.k[4] = 1.0 - mu_t;
+      s.k[5] = mu_t1;
+      break;
+    }
+    default: break;
+  }
+  if (s.record) {
+    if (writer && s.n_recorded < losses_cap) losses[s.n_recorded] = loss;
+    s.n_recorded += 1;
     // The reference compares the values loss.numpy() returns (:702, :712): float32 numbers in a float32 fit, so such a
     // fit stops once its loss stagnates in float32 (difference exactly 0 < tol).  The loss itself is accumulated and
     // recorded in double here; only the two comparisons see it rounded.
-    const double lc = st->f32 ? (double)(float)loss : loss;
-    if (st->use_min && lc < st->min_loss) {
-      st->min_loss = lc;
-      st->improved = 1;
+    const double lc = s.f32 ? (double)(float)loss : loss;
+    if (s.use_min && lc < s.min_loss) {
+      s.min_loss = lc;
+      s.improved = 1;
     }
-    if (st->n_recorded_total >= 1 && fabs(lc - st->prev_loss) < st->tol) st->done_after = 1;
-    st->prev_loss = lc;
-    st->n_recorded_total += 1;
+    if (s.n_recorded_total >= 1 && fabs(lc - s.prev_loss) < s.tol) s.done_after = 1;
+    s.prev_loss = lc;
+    s.n_recorded_total += 1;
   }
+  return true;
+}
+
+// ---- one parameter's update: tf.keras.optimizers.* as of OptimizerV2 (TensorFlow 2.4 - 2.10, the versions the reference
+// was written against; calibration.py:17-27, :571, :667), applied to the re and im variables independently (:596-603).
+// pi: parameter, gi: gradient, m / v: the optimizer's two slots (zero at the start unless noted), k: DevState::k of the step.
+//   Adam     m <- b1 m + (1 - b1) g; v <- b2 v + (1 - b2) g^2; p -= k0 m / (sqrt(v) + eps), k0 = lr sqrt(1 - b2^t) / (1 - b1^t)
+//   Adamax   m likewise; v <- max(b2 v, |g|); p -= k0 m / (v + eps), k0 = lr / (1 - b1^t)       (epsilon outside the bias correction)
+//   SGD      k1 = momentum: 0 -> p -= lr g; else m <- k1 m - lr g, p += m (nesterov: p += k1 m - lr g)
+//   RMSprop  v <- rho v + (1 - rho) g^2; momentum 0 -> p -= lr g / (sqrt(v) + eps); else m <- mom m + lr g / sqrt(v + eps), p -= m
+//   Adagrad  v <- v + g^2 (v starts at initial_accumulator_value); p -= lr g / (sqrt(v) + eps)
+//   Adadelta v <- rho v + (1 - rho) g^2; u = sqrt(m + eps) / sqrt(v + eps) g; p -= lr u; m <- rho m + (1 - rho) u^2
+//   Nadam    g' = g / k1; m <- b1 m + (1 - b1) g; m' = m / k2; v <- b2 v + (1 - b2) g^2; v' = v / k3; p -= lr (k4 g' + k5 m') / (sqrt(v') + eps)
+template <typename T>
+struct StepCoef { T b1, b2, eps, k[6]; int opt; };
+template <typename T> __device__ __forceinline__ StepCoef<T> step_coef(const DevState& s) {
+  StepCoef<T> c;
+  c.b1 = (T)s.beta1; c.b2 = (T)s.beta2; c.eps = (T)s.eps; c.opt = s.opt;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) c.k[i] = (T)s.k[i];
+  return c;
+}
+template <typename T> __device__ __forceinline__ T optimizer_step(T pi, T gi, T& mi_io, T& vi_io, const StepCoef<T>& c) {
+#pragma clang fp contract(off)
+  switch (c.opt) {
+    case OPT_ADAM: {
+      const T mi = c.b1 * mi_io + ((T)1 - c.b1) * gi;
+      const T vi = c.b2 * vi_io + ((T)1 - c.b2) * gi * gi;
+      vi_io = vi;
+      mi_io = mi;
+      return pi - c.k[0] * mi / (sqrt(vi) + c.eps);
+    }
+    case OPT_ADAMAX: {
+      const T mi = c.b1 * mi_io + ((T)1 - c.b1) * gi;
+      const T ui = fmax(c.b2 * vi_io, fabs(gi));
+      vi_io = ui;
+      mi_io = mi;
+      return pi - c.k[0] * mi / (ui + c.eps);
+    }
+    case OPT_SGD: {
+      if (c.k[1] == (T)0) return pi - c.k[0] * gi;
+      const T acc = c.k[1] * mi_io - c.k[0] * gi;
+      mi_io = acc;
+      return c.k[2] != (T)0 ? pi + (c.k[1] * acc - c.k[0] * gi) : pi + acc;
+    }
+    case OPT_RMSPROP: {
+      const T rms = c.k[1] * vi_io + ((T)1 - c.k[1]) * gi * gi;
+      vi_io = rms;
+      if (c.k[2] == (T)0) return pi - c.k[0] * gi / (sqrt(rms) + c.eps);
+      const T mom = c.k[2] * mi_io + c.k[0] * gi / sqrt(rms + c.eps);
+      mi_io = mom;
+      return pi - mom;
+    }
+    case OPT_ADAGRAD: {
+      const T acc = vi_io + gi * gi;
+      vi_io = acc;
+      return pi - c.k[0] * gi / (sqrt(acc) + c.eps);
+    }
+    case OPT_ADADELTA: {
+      const T acc = c.k[1] * vi_io + ((T)1 - c.k[1]) * gi * gi;
+      vi_io = acc;
+      const T upd = sqrt(mi_io + c.eps) / sqrt(acc + c.eps) * gi;
+      mi_io = c.k[1] * mi_io + ((T)1 - c.k[1]) * upd * upd;
+      return pi - c.k[0] * upd;
+    }
+    default: {  // OPT_NADAM
+      const T g_prime = gi / c.k[1];
+      const T mi = c.b1 * mi_io + ((T)1 - c.b1) * gi;
+      const T m_prime = mi / c.k[2];
+      const T vi = c.b2 * vi_io + ((T)1 - c.b2) * gi * gi;
+      const T v_prime = vi / c.k[3];
+      mi_io = mi;
+      vi_io = vi;
+      return pi - c.k[0] * (c.k[4] * g_prime + c.k[5] * m_prime) / (sqrt(v_prime) + c.eps);
+    }
+  }
+}
+
+__global__ void finalize_kernel(DevState* st, const double* __restrict__ scal, double* __restrict__ losses, int losses_cap,
+                                int apply_update) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  DevState s = *st;
+  advance_state(s, scal[0], scal[1], scal[2], true, losses, losses_cap, apply_update != 0);
+  *st = s;
 }
 
 // ---- "sum" regulariser, two-pass form (dense path): alpha = 2 (S - P) from the reduced sums of a loss-only pass
@@ -1019,7 +1159,19 @@ __global__ void alpha_kernel(DevState* st, const double* __restrict__ scal) {
   st->alpha_i = 2.0 * (scal[2] - st->prior_i);
 }
 
-// ---- "sum" regulariser: fold the alpha-weighted parts into the gradients once alpha is known
+// ---- "sum" regulariser: fold the alpha-weighted parts into the gradients once alpha is known.  The two folds are functions
+// of their own because two kernels apply them (combine_* here, step_tail_kernel) and must round identically.
+template <typename T> __device__ __forceinline__ void fold_gain(T& ax, T& ay, T bx, T by, T cx, T cy, T ar, T ai) {
+#pragma clang fp contract(off)
+  // + alpha * r1 + conj(alpha) * r2
+  ax += ar * bx - ai * by + ar * cx + ai * cy;
+  ay += ar * by + ai * bx + ar * cy - ai * cx;
+}
+// one real component of g0 + alpha g1 (complex): `same` is g1's component of the same plane, `other` that of the other plane
+template <typename T> __device__ __forceinline__ T fold_coeff(T g0, T same, T other, T ar, T ai, bool imag) {
+#pragma clang fp contract(off)
+  return imag ? g0 + (ar * same + ai * other) : g0 + (ar * same - ai * other);
+}
 template <typename T>
 __global__ void combine_gain_kernel(vec2_t<T>* __restrict__ r0, const vec2_t<T>* __restrict__ r1,
                                     const vec2_t<T>* __restrict__ r2, int n, const DevState* st) {
@@ -1029,9 +1181,7 @@ __global__ void combine_gain_kernel(vec2_t<T>* __restrict__ r0, const vec2_t<T>*
   const T ar = (T)st->alpha_r, ai = (T)st->alpha_i;
   vec2_t<T> a = r0[i];
   const vec2_t<T> b = r1[i], c = r2[i];
-  // + alpha * r1 + conj(alpha) * r2
-  a.x += ar * b.x - ai * b.y + ar * c.x + ai * c.y;
-  a.y += ar * b.y + ai * b.x + ar * c.y - ai * c.x;
+  fold_gain(a.x, a.y, b.x, b.y, c.x, c.y, ar, ai);
   r0[i] = a;
 }
 
@@ -1042,38 +1192,27 @@ __global__ void combine_coeff_kernel(T* __restrict__ g0_r, T* __restrict__ g0_i,
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const T ar = (T)st->alpha_r, ai = (T)st->alpha_i;
-  g0_r[i] += ar * g1_r[i] - ai * g1_i[i];
-  g0_i[i] += ar * g1_i[i] + ai * g1_r[i];
+  g0_r[i] = fold_coeff(g0_r[i], g1_r[i], g1_i[i], ar, ai, false);
+  g0_i[i] = fold_coeff(g0_i[i], g1_i[i], g1_r[i], ar, ai, true);
 }
 
-// ---- Keras Adam / Adamax on flat real arrays (re and im planes are independent real variables, :596-603):
-//   m <- b1 m + (1 - b1) g;  Adam: v <- b2 v + (1 - b2) g^2, p <- p - lr_t m / (sqrt(v) + eps), lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
-//   Adamax: u <- max(b2 u, |g|), p <- p - lr / (1 - b1^t) m / (u + eps);  epsilon outside the bias correction.
-// both parameter sets in one launch (one launch less per step matters for problems whose whole step is ~20 us): blocks
-// [0, nblk_a) update set a (the gains), the rest set b (the coefficients).
+// ---- the optimizer update on flat real arrays (optimizer_step), both parameter sets in one launch (one launch less per
+// step matters for problems whose whole step is ~20 us): blocks [0, nblk_a) update set a (the gains), the rest set b (the
+// coefficients).
 template <typename T>
 struct AdamSet { T* p; const T* g; T* m; T* v; T* snap; long long n; };
-template <typename T, int OPT>
+template <typename T>
 __global__ __launch_bounds__(256) void adam2_kernel(const AdamSet<T> a, const AdamSet<T> b, int nblk_a, const DevState* st) {
   if (st->done) return;
   const bool first = (int)blockIdx.x < nblk_a;
   const AdamSet<T>& S = first ? a : b;
   const long long i = (long long)(first ? blockIdx.x : blockIdx.x - nblk_a) * blockDim.x + threadIdx.x;
   if (i >= S.n) return;
-  const T b1 = (T)st->beta1, b2 = (T)st->beta2, eps = (T)st->eps;
-  const T gi = S.g[i];
-  const T mi = b1 * S.m[i] + ((T)1 - b1) * gi;
-  T pi = S.p[i];
-  if (OPT == 0) {
-    const T vi = b2 * S.v[i] + ((T)1 - b2) * gi * gi;
-    S.v[i] = vi;
-    pi -= (T)st->lr_t * mi / (sqrt(vi) + eps);
-  } else {
-    const T ui = fmax(b2 * S.v[i], fabs(gi));
-    S.v[i] = ui;
-    pi -= (T)st->lr_u * mi / (ui + eps);
-  }
+  const StepCoef<T> c = step_coef<T>(*st);
+  T mi = S.m[i], vi = S.v[i];
+  const T pi = optimizer_step<T>(S.p[i], S.g[i], mi, vi, c);
   S.m[i] = mi;
+  S.v[i] = vi;
   S.p[i] = pi;
   if (st->improved) S.snap[i] = pi;
 }
@@ -1091,70 +1230,27 @@ struct PartialSum {          // gradient of coefficient n = sum over the items q
   const int* coef_grp; const int* grp_coff; const int* grp_item_ptr; const int* item_goff;
   int ncoef;                 // 0: the gradient is read from AdamSet::g as it stands
 };
-template <typename T, int OPT>
+template <typename T>
 __global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, const AdamSet<T> b, const PartialSum<T> ps,
                                                          const DevState* __restrict__ in, DevState* __restrict__ out,
                                                          const double* __restrict__ scal, double* __restrict__ losses, int losses_cap) {
   // ---- the step's decisions: thread 0 of every block derives them (identically), block 0 records them
-  __shared__ double sh_lr_t, sh_lr_u, sh_b1, sh_b2, sh_eps;
+  __shared__ StepCoef<T> sh_c;
   __shared__ int sh_update, sh_improved;
   if (threadIdx.x == 0) {
-  DevState s = *in;
-  const bool writer = blockIdx.x == 0;
-  bool update = false;
-  if (s.done) {
-    // nothing
-  } else if (s.done_after) {
-    s.done = 1;
-  } else {
-    double loss = scal[0];
-    if (s.reg) {
-      s.s_r = scal[1];
-      s.s_i = scal[2];
-      const double dr = scal[1] - s.prior_r, di = scal[2] - s.prior_i;
-      loss += dr * dr + di * di;
-      s.alpha_r = 2.0 * dr;
-      s.alpha_i = 2.0 * di;
-    }
-    s.loss = loss;
-    s.improved = 0;
-    if (!(loss == loss) || loss > 1.7e308 || loss < -1.7e308) {
-      s.nonfinite = 1;  // never silently continued: stop before this step's update
-      s.done = 1;
-    } else {
-      update = true;
-      s.t += 1;
-      s.nupdates += 1;
-      s.b1t *= s.beta1;
-      s.b2t *= s.beta2;
-      s.bc1 = 1.0 - s.b1t;
-      s.lr_t = s.lr * sqrt(1.0 - s.b2t) / s.bc1;
-      s.lr_u = s.lr / s.bc1;
-      if (s.record) {
-        if (writer && s.n_recorded < losses_cap) losses[s.n_recorded] = loss;
-        s.n_recorded += 1;
-        const double lc = s.f32 ? (double)(float)loss : loss;  // see finalize_kernel
-        if (s.use_min && lc < s.min_loss) {
-          s.min_loss = lc;
-          s.improved = 1;
-        }
-        if (s.n_recorded_total >= 1 && fabs(lc - s.prev_loss) < s.tol) s.done_after = 1;
-        s.prev_loss = lc;
-        s.n_recorded_total += 1;
-      }
-    }
-  }
-  if (writer) *out = s;
-  sh_update = update ? 1 : 0;
-  sh_improved = s.improved;
-  sh_lr_t = s.lr_t; sh_lr_u = s.lr_u; sh_b1 = s.beta1; sh_b2 = s.beta2; sh_eps = s.eps;
+    DevState s = *in;
+    const bool writer = blockIdx.x == 0;
+    const bool update = advance_state(s, scal[0], scal[1], scal[2], writer, losses, losses_cap, true);
+    if (writer) *out = s;
+    sh_update = update ? 1 : 0;
+    sh_improved = s.improved;
+    sh_c = step_coef<T>(s);
   }
   __syncthreads();
   if (!sh_update) return;
   // ---- the update: sets a (gains) and b (coefficients) as one index space, grid-stride (the decisions above are taken
   // once per block, so a big problem runs a few thousand blocks, not one per 256 elements)
-  const T b1 = (T)sh_b1, b2 = (T)sh_b2, eps = (T)sh_eps;
-  const T lr_t = (T)sh_lr_t, lr_u = (T)sh_lr_u;
+  const StepCoef<T> c = sh_c;
   const bool improved = sh_improved != 0;
   const long long total = a.n + b.n;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -1173,18 +1269,10 @@ __global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, co
     } else {
       gi = S.g[i];
     }
-    const T mi = b1 * S.m[i] + ((T)1 - b1) * gi;
-    T pi = S.p[i];
-    if (OPT == 0) {
-      const T vi = b2 * S.v[i] + ((T)1 - b2) * gi * gi;
-      S.v[i] = vi;
-      pi -= lr_t * mi / (sqrt(vi) + eps);
-    } else {
-      const T ui = fmax(b2 * S.v[i], fabs(gi));
-      S.v[i] = ui;
-      pi -= lr_u * mi / (ui + eps);
-    }
+    T mi = S.m[i], vi = S.v[i];
+    const T pi = optimizer_step<T>(S.p[i], gi, mi, vi, c);
     S.m[i] = mi;
+    S.v[i] = vi;
     S.p[i] = pi;
     if (improved) S.snap[i] = pi;
   }
@@ -1201,25 +1289,6 @@ __global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, co
 //     those gains.  They READ the other antennas' gains while their owners update them, so the gains are double-buffered
 //     (read `gains_in`, write `gains_out`; the host swaps the two after every step);
 //   * the remaining blocks update the coefficients (partial gradients of split groups summed on the fly).
-template <typename T> __device__ __forceinline__ void fold_gain(T& ax, T& ay, T bx, T by, T cx, T cy, T ar, T ai) {
-  // + alpha * r1 + conj(alpha) * r2   (combine_gain_kernel)
-  ax += ar * bx - ai * by + ar * cx + ai * cy;
-  ay += ar * by + ai * bx + ar * cy - ai * cx;
-}
-template <typename T, int OPT> __device__ __forceinline__ T optimizer_step(T pi, T gi, T& mi_io, T& vi_io, T b1, T b2, T eps, T lr_t, T lr_u) {
-  const T mi = b1 * mi_io + ((T)1 - b1) * gi;
-  if (OPT == 0) {
-    const T vi = b2 * vi_io + ((T)1 - b2) * gi * gi;
-    vi_io = vi;
-    pi -= lr_t * mi / (sqrt(vi) + eps);
-  } else {
-    const T ui = fmax(b2 * vi_io, fabs(gi));
-    vi_io = ui;
-    pi -= lr_u * mi / (ui + eps);
-  }
-  mi_io = mi;
-  return pi;
-}
 template <typename T>
 struct TailArgs {
   const vec2_t<T>* q0; const vec2_t<T>* q1;
@@ -1234,13 +1303,14 @@ struct TailArgs {
   const DevState* in; DevState* out;
   double* losses; int losses_cap;
 };
-template <typename T, int OPT, bool REG>
+template <typename T, bool REG>
 __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
   using T2 = vec2_t<T>;
   constexpr int CPL = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;
   typedef T vec_t __attribute__((ext_vector_type(2 * CPL)));
   __shared__ double sh[3][256];
-  __shared__ double sh_lr_t, sh_lr_u, sh_b1, sh_b2, sh_eps, sh_ar, sh_ai;
+  __shared__ double sh_ar, sh_ai;
+  __shared__ StepCoef<T> sh_c;
   __shared__ int sh_update, sh_improved;
   __shared__ T s_part[3][3][64][2 * CPL];
   const int tid = threadIdx.x;
@@ -1265,61 +1335,21 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
       __syncthreads();
     }
   }
-  // ---- the step's decisions (step_update_kernel / finalize_kernel): thread 0 of every block, block 0 records them
+  // ---- the step's decisions (advance_state): thread 0 of every block, block 0 records them
   if (tid == 0) {
     DevState s = *A.in;
     const bool writer = blockIdx.x == 0;
-    bool update = false;
-    if (s.done) {
-    } else if (s.done_after) {
-      s.done = 1;
-    } else {
-      double loss = sh[0][0];
-      if (s.reg) {
-        s.s_r = sh[1][0];
-        s.s_i = sh[2][0];
-        const double dr = sh[1][0] - s.prior_r, di = sh[2][0] - s.prior_i;
-        loss += dr * dr + di * di;
-        s.alpha_r = 2.0 * dr;
-        s.alpha_i = 2.0 * di;
-      }
-      s.loss = loss;
-      s.improved = 0;
-      if (!(loss == loss) || loss > 1.7e308 || loss < -1.7e308) {
-        s.nonfinite = 1;
-        s.done = 1;
-      } else {
-        update = true;
-        s.t += 1;
-        s.nupdates += 1;
-        s.b1t *= s.beta1;
-        s.b2t *= s.beta2;
-        s.bc1 = 1.0 - s.b1t;
-        s.lr_t = s.lr * sqrt(1.0 - s.b2t) / s.bc1;
-        s.lr_u = s.lr / s.bc1;
-        if (s.record) {
-          if (writer && s.n_recorded < A.losses_cap) A.losses[s.n_recorded] = loss;
-          s.n_recorded += 1;
-          const double lc = s.f32 ? (double)(float)loss : loss;
-          if (s.use_min && lc < s.min_loss) {
-            s.min_loss = lc;
-            s.improved = 1;
-          }
-          if (s.n_recorded_total >= 1 && fabs(lc - s.prev_loss) < s.tol) s.done_after = 1;
-          s.prev_loss = lc;
-          s.n_recorded_total += 1;
-        }
-      }
-    }
+    const bool upd = advance_state(s, sh[0][0], sh[1][0], sh[2][0], writer, A.losses, A.losses_cap, true);
     if (writer) *A.out = s;
-    sh_update = update ? 1 : 0;
+    sh_update = upd ? 1 : 0;
     sh_improved = s.improved;
-    sh_lr_t = s.lr_t; sh_lr_u = s.lr_u; sh_b1 = s.beta1; sh_b2 = s.beta2; sh_eps = s.eps;
-    sh_ar = s.alpha_r; sh_ai = s.alpha_i;
+    sh_c = step_coef<T>(s);
+    sh_ar = s.alpha_r;
+    sh_ai = s.alpha_i;
   }
   __syncthreads();
   const bool update = sh_update != 0;
-  const T b1 = (T)sh_b1, b2 = (T)sh_b2, eps = (T)sh_eps, lr_t = (T)sh_lr_t, lr_u = (T)sh_lr_u;
+  const StepCoef<T> sc = sh_c;
   const T ar = (T)sh_ar, ai = (T)sh_ai;
   const bool improved = sh_improved != 0;
   if ((int)blockIdx.x < A.nblk_gain) {
@@ -1336,64 +1366,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
       return;
     }
     T s0[2 * CPL], s1[2 * CPL], s2[2 * CPL];
-#pragma unroll
-    for (int c = 0; c < 2 * CPL; ++c) s0[c] = s1[c] = s2[c] = 0;
-    const int e0 = A.ant_ptr[a], e1 = A.ant_ptr[a + 1];
-    const int per = (e1 - e0 + 3) >> 2;
-    const int eb = e0 + seg * per, ee = min(e1, eb + per);
-    if (ok) {
-#pragma unroll 8
-      for (int e = eb; e < ee; ++e) {
-        const int2 ent = A.ant_ent[e];
-        const int bl = ent.x >> 1;
-        const int role = ent.x & 1;
-        const vec_t q = *reinterpret_cast<const vec_t*>(A.q0 + (long long)bl * A.fpad + f);
-        const vec_t go = *reinterpret_cast<const vec_t*>(A.gains_in + (long long)ent.y * A.fpad + f);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          const T qr = q[2 * c], qi = role ? -q[2 * c + 1] : q[2 * c + 1];
-          s0[2 * c] += qr * go[2 * c] - qi * go[2 * c + 1];
-          s0[2 * c + 1] += qr * go[2 * c + 1] + qi * go[2 * c];
-        }
-        if (REG) {
-          const vec_t p = *reinterpret_cast<const vec_t*>(A.q1 + (long long)bl * A.fpad + f);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            const T pr = p[2 * c], pi = p[2 * c + 1];
-            if (role == 0) {
-              s1[2 * c] += pr * go[2 * c] - pi * go[2 * c + 1];
-              s1[2 * c + 1] += pr * go[2 * c + 1] + pi * go[2 * c];
-            } else {
-              s2[2 * c] += pr * go[2 * c] + pi * go[2 * c + 1];
-              s2[2 * c + 1] += pr * go[2 * c + 1] - pi * go[2 * c];
-            }
-          }
-        }
-      }
-    }
-    if (seg > 0) {
-#pragma unroll
-      for (int c = 0; c < 2 * CPL; ++c) {
-        s_part[seg - 1][0][lane][c] = s0[c];
-        if (REG) {
-          s_part[seg - 1][1][lane][c] = s1[c];
-          s_part[seg - 1][2][lane][c] = s2[c];
-        }
-      }
-    }
-    __syncthreads();
-    if (seg == 0 && ok) {
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-#pragma unroll
-        for (int c = 0; c < 2 * CPL; ++c) {
-          s0[c] += s_part[g][0][lane][c];
-          if (REG) {
-            s1[c] += s_part[g][1][lane][c];
-            s2[c] += s_part[g][2][lane][c];
-          }
-        }
-      }
+    if (antenna_sums<T, REG>(A.q0, A.q1, A.gains_in, A.ant_ptr, A.ant_ent, a, f, A.fpad, s_part, s0, s1, s2)) {
       if (REG) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) fold_gain(s0[2 * c], s0[2 * c + 1], s1[2 * c], s1[2 * c + 1], s2[2 * c], s2[2 * c + 1], ar, ai);
@@ -1403,7 +1376,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
 #pragma unroll
       for (int c = 0; c < 2 * CPL; ++c) {
         T mi = mm[c], vi = vv[c];
-        pout[c] = optimizer_step<T, OPT>(pin[c], s0[c], mi, vi, b1, b2, eps, lr_t, lr_u);
+        pout[c] = optimizer_step<T>(pin[c], s0[c], mi, vi, sc);
         mm[c] = mi;
         vv[c] = vi;
       }
@@ -1453,11 +1426,10 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
       } else {
         o1 = A.coef_g1[j];
       }
-      if (!imag) gi += ar * g1 - ai * o1;
-      else gi += ar * g1 + ai * o1;
+      gi = fold_coeff(gi, g1, o1, ar, ai, imag);
     }
     T mi = S.m[i], vi = S.v[i];
-    const T pi = optimizer_step<T, OPT>(S.p[i], gi, mi, vi, b1, b2, eps, lr_t, lr_u);
+    const T pi = optimizer_step<T>(S.p[i], gi, mi, vi, sc);
     S.m[i] = mi;
     S.v[i] = vi;
     S.p[i] = pi;
@@ -1466,6 +1438,11 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
 }
 
 // ---- setup kernels -------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void fill_kernel(T* __restrict__ dst, long long n, T value) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = value;
+}
+
 // unique basis block (row-major [nrb * nfreqs][nvec]) -> tile-major [rowblk][channel block][vec][FB], zero padded
 template <typename T>
 __global__ void retile_kernel(const T* __restrict__ src, T* __restrict__ dst, int nfreqs, int fpad, int nvec, int nrb, int fb) {

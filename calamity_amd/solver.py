@@ -6,11 +6,22 @@ import numpy as np
 from . import _lib
 from .problem import FitProblem
 
-# OPTIMIZERS of /root/reference/calamity/calibration.py:17-27 that the HIP fitter implements; any other name raises
-# KeyError exactly like ``OPTIMIZERS[optimizer]`` at calibration.py:571.
-OPTIMIZERS = {"Adam": _lib.CAL_OPT_ADAM, "Adamax": _lib.CAL_OPT_ADAMAX}
-_OPT_KEYS = ("learning_rate", "beta_1", "beta_2", "epsilon")
-_OPT_DEFAULTS = dict(learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)  # Keras defaults
+# OPTIMIZERS of /root/reference/calamity/calibration.py:17-27 that the HIP fitter implements ("Ftrl" and the
+# tensorflow-addons "LAMB" are not provided); any other name raises KeyError exactly like ``OPTIMIZERS[optimizer]`` at
+# calibration.py:571.  Constructor arguments and defaults are those of tf.keras.optimizers.* (OptimizerV2, TF 2.4 - 2.10);
+# an argument the optimizer does not take raises TypeError, as the Keras constructor would.
+OPTIMIZERS = {"Adam": _lib.CAL_OPT_ADAM, "Adamax": _lib.CAL_OPT_ADAMAX, "SGD": _lib.CAL_OPT_SGD, "RMSprop": _lib.CAL_OPT_RMSPROP,
+              "Adagrad": _lib.CAL_OPT_ADAGRAD, "Nadam": _lib.CAL_OPT_NADAM, "Adadelta": _lib.CAL_OPT_ADADELTA}
+_MOMENTS = dict(learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
+_OPT_DEFAULTS = {
+    "Adam": _MOMENTS,
+    "Adamax": _MOMENTS,
+    "Nadam": _MOMENTS,
+    "SGD": dict(learning_rate=1e-2, momentum=0.0, nesterov=False),
+    "RMSprop": dict(learning_rate=1e-3, rho=0.9, momentum=0.0, epsilon=1e-7),
+    "Adagrad": dict(learning_rate=1e-3, initial_accumulator_value=0.1, epsilon=1e-7),
+    "Adadelta": dict(learning_rate=1e-3, rho=0.95, epsilon=1e-7),
+}
 
 
 def _ptr(a):
@@ -94,11 +105,14 @@ class HipFitSolver:
 
     def set_optimizer(self, optimizer="Adamax", **opt_kwargs):
         opt_id = OPTIMIZERS[optimizer]  # KeyError for anything else, like calibration.py:571
-        unknown = set(opt_kwargs) - set(_OPT_KEYS)
+        defaults = _OPT_DEFAULTS[optimizer]
+        unknown = set(opt_kwargs) - set(defaults)
         if unknown:
             raise TypeError(f"Unexpected keyword argument(s) passed to optimizer: {sorted(unknown)}")
-        kw = dict(_OPT_DEFAULTS, **opt_kwargs)
-        d = _lib.OptimizerDesc(opt_id, kw["learning_rate"], kw["beta_1"], kw["beta_2"], kw["epsilon"])
+        kw = dict(defaults, **opt_kwargs)
+        d = _lib.OptimizerDesc(opt_id, kw["learning_rate"], kw.get("beta_1", 0.9), kw.get("beta_2", 0.999), kw.get("epsilon", 1e-7),
+                               kw.get("rho", 0.9), kw.get("momentum", 0.0), kw.get("initial_accumulator_value", 0.1),
+                               int(bool(kw.get("nesterov", False))), 0)
         _lib.check(self._lib.cal_solver_set_optimizer(self._h, C.byref(d)))
 
     # ---- parameters ----------------------------------------------------------------------------------------
@@ -184,6 +198,31 @@ class HipFitSolver:
         n = C.c_int64(0)
         _lib.check(self._lib.cal_solver_memory_bytes(self._h, C.byref(n)))
         return n.value
+
+    def set_exchange_hook(self, all_reduce, rank: int, nranks: int):
+        """Run the per-step exchange through ``all_reduce(array, op)`` instead of RCCL: ``array`` is a NumPy view (float32,
+        float64 or int32) of the library's staging buffer, to be reduced IN PLACE over the ``nranks`` callers; ``op`` is
+        "sum" or "min".  ``None`` detaches.  (cal_solver_set_exchange_hook)"""
+        if all_reduce is None:
+            self._hook = None
+            _lib.check(self._lib.cal_solver_set_exchange_hook(self._h, None, None, 0, 1))
+            return
+        dtypes = {_lib.CAL_XCHG_F32: np.float32, _lib.CAL_XCHG_F64: np.float64, _lib.CAL_XCHG_I32: np.int32}
+
+        def trampoline(ctx, buf, count, dtype, op):
+            try:
+                dt = np.dtype(dtypes[dtype])
+                arr = np.frombuffer((C.c_char * (count * dt.itemsize)).from_address(buf), dtype=dt)
+                all_reduce(arr, "min" if op == _lib.CAL_XCHG_MIN else "sum")
+                return 0
+            except Exception:  # noqa: BLE001 -- never unwind through the C frames: report failure to the library
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._hook = _lib.EXCHANGE_FN(trampoline)  # keep the callback alive as long as the solver uses it
+        _lib.check(self._lib.cal_solver_set_exchange_hook(self._h, C.cast(self._hook, C.c_void_p), None, int(rank), int(nranks)))
 
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(bytes(unique_id), _lib.CAL_COMM_ID_BYTES)

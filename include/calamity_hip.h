@@ -39,7 +39,9 @@ enum cal_status {
 };
 
 enum cal_dtype { CAL_F32 = 0, CAL_F64 = 1 };                 /* dtype kwarg, calibration.py:464, :974 */
-enum cal_optimizer { CAL_OPT_ADAM = 0, CAL_OPT_ADAMAX = 1 }; /* OPTIMIZERS, calibration.py:17-27 */
+enum cal_optimizer { /* OPTIMIZERS, calibration.py:17-27 (Ftrl and the tensorflow-addons LAMB are not provided) */
+  CAL_OPT_ADAM = 0, CAL_OPT_ADAMAX = 1, CAL_OPT_SGD = 2, CAL_OPT_RMSPROP = 3, CAL_OPT_ADAGRAD = 4, CAL_OPT_NADAM = 5, CAL_OPT_ADADELTA = 6
+};
 enum cal_regularization { CAL_REG_NONE = 0, CAL_REG_SUM = 1 }; /* model_regularization, calibration.py:619-661 */
 enum cal_layout {
   CAL_LAYOUT_STREAM = 0, /* every baseline owns its basis tiles in HBM (the reference's per-baseline tensor,
@@ -93,12 +95,18 @@ typedef struct cal_problem_desc {
   int32_t kernel_path;           /* cal_kernel_path; with a communicator attached the ranks agree on one path */
 } cal_problem_desc;
 
-typedef struct cal_optimizer_desc { /* **opt_kwargs -> tf.optimizers.X(...), calibration.py:571 */
+typedef struct cal_optimizer_desc { /* **opt_kwargs -> tf.optimizers.X(...), calibration.py:571; semantics: Keras OptimizerV2
+                                     * (TensorFlow 2.4 - 2.10), formulae in fit_kernels.hpp: optimizer_step */
   int32_t optimizer;              /* cal_optimizer */
-  double learning_rate;           /* Keras defaults: 1e-3, 0.9, 0.999, 1e-7 */
-  double beta_1;
-  double beta_2;
-  double epsilon;
+  double learning_rate;           /* Keras defaults: 1e-3 (SGD: 1e-2) */
+  double beta_1;                  /* Adam, Adamax, Nadam: 0.9 */
+  double beta_2;                  /* 0.999 */
+  double epsilon;                 /* 1e-7 */
+  double rho;                     /* RMSprop 0.9, Adadelta 0.95 */
+  double momentum;                /* SGD, RMSprop: 0 */
+  double initial_accumulator_value; /* Adagrad: 0.1 */
+  int32_t nesterov;               /* SGD */
+  int32_t reserved;
 } cal_optimizer_desc;
 
 typedef struct cal_run_desc { /* loop controls of fit_gains_and_foregrounds, calibration.py:457-461 */
@@ -157,7 +165,9 @@ int cal_solver_set_params(cal_solver* s, const void* g_r, const void* g_i, const
 /* .value() snapshots, calibration.py:706-710, :724-728.  which = 0: current parameters; 1: use_min snapshot */
 int cal_solver_get_params(cal_solver* s, int which, void* g_r, void* g_i, void* c_r, void* c_i);
 /* optimizer slots (checkpoint / resume; no counterpart in the reference): m and v (Adam) / u (Adamax).  A fit resumed with
- * set_params + set_moments (after set_optimizer, whose betas the bias corrections are rebuilt from) continues bit for bit. */
+ * set_params + set_moments (after set_optimizer, whose betas the bias corrections are rebuilt from) continues bit for bit.
+ * The two slots per parameter, (m, v): Adam / Nadam first and second moment; Adamax (m, u); SGD (momentum accumulator, unused);
+ * RMSprop (momentum accumulator, mean square); Adagrad (unused, accumulator); Adadelta (accumulated updates, accumulated gradients). */
 int cal_solver_get_moments(cal_solver* s, void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i,
                            void* cv_r, void* cv_i, int64_t* t);
 int cal_solver_set_moments(cal_solver* s, const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i,
@@ -190,6 +200,15 @@ int cal_solver_memory_bytes(cal_solver* s, int64_t* device_bytes);
 #define CAL_COMM_ID_BYTES 128
 int cal_comm_unique_id(void* id_out);
 int cal_solver_comm_init(cal_solver* s, const void* id, int rank, int nranks);
+/* The same exchange through a transport of the caller's (MPI, gloo, ...; and the vehicle of the two-ranks-on-one-GPU tests:
+ * RCCL refuses two ranks on one device).  Wherever the library would call ncclAllReduce -- the set-up agreement, the gain
+ * gradients and the loss scalars of every step -- it drains its stream, hands the callback the SAME buffer and element
+ * count staged in pinned host memory, and expects it reduced in place over the nranks callers (0 = success), then copies it
+ * back.  Replaces a communicator of cal_solver_comm_init and vice versa; fn = NULL detaches. */
+enum cal_exchange_dtype { CAL_XCHG_F32 = 0, CAL_XCHG_F64 = 1, CAL_XCHG_I32 = 2 };
+enum cal_exchange_op { CAL_XCHG_SUM = 0, CAL_XCHG_MIN = 1 };
+typedef int (*cal_exchange_fn)(void* ctx, void* host_buf, int64_t count, int dtype, int op);
+int cal_solver_set_exchange_hook(cal_solver* s, cal_exchange_fn fn, void* ctx, int rank, int nranks);
 
 #ifdef __cplusplus
 }

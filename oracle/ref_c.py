@@ -16,9 +16,10 @@ _LIB = None
 def load():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libref_c.so")
+        # ORACLE_REF_C_LIB: the sanitizer build (oracle/Makefile: libref_c_san.so), chosen by the test that runs under it
+        path = os.environ.get("ORACLE_REF_C_LIB") or os.path.join(_HERE, "libref_c.so")
         if not os.path.exists(path):
-            subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+            subprocess.run(["make", "-C", _HERE, os.path.basename(path)], check=True, capture_output=True)
         _LIB = C.CDLL(path)
     return _LIB
 

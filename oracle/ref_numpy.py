@@ -206,7 +206,138 @@ class Adamax:
             var -= (lr_t * m / (u + self.eps)).astype(var.dtype)
 
 
-OPTIMIZERS = {"Adam": Adam, "Adamax": Adamax}  # other calibration.py:17-27 entries: out of scope -> KeyError
+class _SlotOptimizer:
+    """Shared plumbing of the optimizers below: per-variable slot arrays created on first use, iteration count."""
+
+    nslots = 2
+    slot_init = (0.0, 0.0)
+
+    def __init__(self):
+        self.t = 0
+        self.state = {}
+
+    def slots(self, n, var):
+        if n not in self.state:
+            self.state[n] = tuple(np.full_like(var, v) for v in self.slot_init[: self.nslots])
+        return self.state[n]
+
+
+class SGD(_SlotOptimizer):
+    """tf.keras.optimizers.SGD (OptimizerV2, ResourceApplyGradientDescent / ResourceApplyKerasMomentum):
+    momentum == 0: var -= lr g; else accum = momentum accum - lr g, var += accum (nesterov: var += momentum accum - lr g)."""
+
+    nslots = 1
+
+    def __init__(self, learning_rate=0.01, momentum=0.0, nesterov=False):
+        super().__init__()
+        self.lr, self.momentum, self.nesterov = learning_rate, momentum, nesterov
+
+    def apply_gradients(self, grads_and_vars):
+        self.t += 1
+        for n, (g, var) in enumerate(grads_and_vars):
+            if self.momentum == 0.0:
+                var -= (self.lr * g).astype(var.dtype)
+                continue
+            (accum,) = self.slots(n, var)
+            accum *= self.momentum
+            accum -= self.lr * g
+            var += ((self.momentum * accum - self.lr * g) if self.nesterov else accum).astype(var.dtype)
+
+
+class RMSprop(_SlotOptimizer):
+    """tf.keras.optimizers.RMSprop (OptimizerV2, centered=False): rms = rho rms + (1 - rho) g^2; without momentum
+    var -= lr g / (sqrt(rms) + epsilon); with momentum the fused ResourceApplyRMSProp, whose epsilon sits INSIDE the
+    root: mom = momentum mom + lr g / sqrt(rms + epsilon), var -= mom."""
+
+    def __init__(self, learning_rate=0.001, rho=0.9, momentum=0.0, epsilon=1e-7):
+        super().__init__()
+        self.lr, self.rho, self.momentum, self.eps = learning_rate, rho, momentum, epsilon
+
+    def apply_gradients(self, grads_and_vars):
+        self.t += 1
+        for n, (g, var) in enumerate(grads_and_vars):
+            mom, rms = self.slots(n, var)
+            rms *= self.rho
+            rms += (1.0 - self.rho) * g * g
+            if self.momentum == 0.0:
+                var -= (self.lr * g / (np.sqrt(rms) + self.eps)).astype(var.dtype)
+            else:
+                mom *= self.momentum
+                mom += self.lr * g / np.sqrt(rms + self.eps)
+                var -= mom.astype(var.dtype)
+
+
+class Adagrad(_SlotOptimizer):
+    """tf.keras.optimizers.Adagrad (OptimizerV2, ResourceApplyAdagradV2): accum += g^2 (from initial_accumulator_value),
+    var -= lr g / (sqrt(accum) + epsilon)."""
+
+    def __init__(self, learning_rate=0.001, initial_accumulator_value=0.1, epsilon=1e-7):
+        super().__init__()
+        self.lr, self.eps = learning_rate, epsilon
+        self.slot_init = (0.0, initial_accumulator_value)
+
+    def apply_gradients(self, grads_and_vars):
+        self.t += 1
+        for n, (g, var) in enumerate(grads_and_vars):
+            _, accum = self.slots(n, var)
+            accum += g * g
+            var -= (self.lr * g / (np.sqrt(accum) + self.eps)).astype(var.dtype)
+
+
+class Adadelta(_SlotOptimizer):
+    """tf.keras.optimizers.Adadelta (OptimizerV2, ResourceApplyAdadelta): accum = rho accum + (1 - rho) g^2;
+    update = sqrt(accum_update + epsilon) / sqrt(accum + epsilon) g; var -= lr update;
+    accum_update = rho accum_update + (1 - rho) update^2."""
+
+    def __init__(self, learning_rate=0.001, rho=0.95, epsilon=1e-7):
+        super().__init__()
+        self.lr, self.rho, self.eps = learning_rate, rho, epsilon
+
+    def apply_gradients(self, grads_and_vars):
+        self.t += 1
+        for n, (g, var) in enumerate(grads_and_vars):
+            accum_update, accum = self.slots(n, var)
+            accum *= self.rho
+            accum += (1.0 - self.rho) * g * g
+            update = np.sqrt(accum_update + self.eps) / np.sqrt(accum + self.eps) * g
+            var -= (self.lr * update).astype(var.dtype)
+            accum_update *= self.rho
+            accum_update += (1.0 - self.rho) * update * update
+
+
+class Nadam(_SlotOptimizer):
+    """tf.keras.optimizers.Nadam (OptimizerV2): momentum schedule mu_t = beta_1 (1 - 0.5 * 0.96^(0.004 t)), the running
+    product of the mu's as bias correction of the first moment:
+    g' = g / (1 - prod_t); m = beta_1 m + (1 - beta_1) g; m' = m / (1 - prod_t mu_{t+1}); v = beta_2 v + (1 - beta_2) g^2;
+    v' = v / (1 - beta_2^t); var -= lr ((1 - mu_t) g' + mu_{t+1} m') / (sqrt(v') + epsilon)."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        super().__init__()
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta_1, beta_2, epsilon
+        self.m_schedule = 1.0
+
+    def apply_gradients(self, grads_and_vars):
+        self.t += 1
+        t = self.t
+        mu_t = self.b1 * (1.0 - 0.5 * 0.96 ** (0.004 * t))
+        mu_t1 = self.b1 * (1.0 - 0.5 * 0.96 ** (0.004 * (t + 1)))
+        sched_new = self.m_schedule * mu_t
+        sched_next = sched_new * mu_t1
+        self.m_schedule = sched_new
+        for n, (g, var) in enumerate(grads_and_vars):
+            m, v = self.slots(n, var)
+            g_prime = g / (1.0 - sched_new)
+            m *= self.b1
+            m += (1.0 - self.b1) * g
+            m_prime = m / (1.0 - sched_next)
+            v *= self.b2
+            v += (1.0 - self.b2) * g * g
+            v_prime = v / (1.0 - self.b2 ** t)
+            var -= (self.lr * ((1.0 - mu_t) * g_prime + mu_t1 * m_prime) / (np.sqrt(v_prime) + self.eps)).astype(var.dtype)
+
+
+# calibration.py:17-27 without Ftrl and the tensorflow-addons LAMB (KeyError, like any unknown name at :571)
+OPTIMIZERS = {"Adam": Adam, "Adamax": Adamax, "SGD": SGD, "RMSprop": RMSprop, "Adagrad": Adagrad, "Adadelta": Adadelta, "Nadam": Nadam}
 
 
 # --------------------------------------------------------------------------------------------------

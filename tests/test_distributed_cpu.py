@@ -1,6 +1,7 @@
-"""N > 1 path on CPU (gloo, world_size 2): the baseline partition, the exchange payload and the replicated gain update,
-with the oracle as the per-rank compute engine (test infrastructure only).  The GPU library performs the same exchange
-with one RCCL all-reduce per step (calamity_hip.hip: enqueue_pass)."""
+"""N > 1 path on CPU (gloo, world_size 2): the baseline partition, the exchange payload -- exactly what the library sends:
+one exchange per step of the gain-gradient parts (one, or three with the "sum" regulariser) and four double scalars -- and the
+replicated gain update, with the oracle as the per-rank compute engine (test infrastructure only).  The same algebra on the
+real kernels, two ranks on one GPU: tests/test_gpu_exchange_hook.py."""
 import os
 import socket
 
@@ -51,26 +52,44 @@ def _rank_main(rank, world, port, nsteps, reg, out_q):
             gg = buf[:-4].reshape(p.nants, p.nfreqs, 2)
             gg_r, gg_i, loss = gg[..., 0].copy(), gg[..., 1].copy(), buf[-4]
         else:
-            # the regulariser couples the shards through S = sum w m: first the local sums, then gradients with the
-            # GLOBAL alpha (the GPU gets the same result from one all-reduce of three linear parts)
+            # The regulariser couples the shards through S = sum w m, but every adjoint is LINEAR in e = e0 + alpha w with
+            # alpha = 2 (S - P) known only after the reduction.  The library therefore sends, in ONE exchange, three gain-gradient
+            # parts r0 | r1 | r2 (gradient = r0 + alpha r1 + conj(alpha) r2) and the scalars (chi^2, S_r, S_i, spare), and folds
+            # them afterwards (calamity_hip.hip: enqueue_pass, combine_gain_kernel / combine_coeff_kernel).  Modelled here with
+            # the oracle: its regularised gradient at three local priors gives the parts.
             m = [R.data_model(g_r, g_i, fg_r[c], fg_i[c], ch["fg_comps"][c], a0[c], a1[c]) for c in range(len(fg_r))]
-            s_loc = torch.tensor([sum(np.sum(mr * w) for (mr, _), w in zip(m, ch["wgts"])), sum(np.sum(mi * w) for (_, mi), w in zip(m, ch["wgts"]))])
-            dist.all_reduce(s_loc)
-            s_r, s_i = s_loc.numpy()
-            # shift the local prior so that (S_local - P_local) equals the global (S - P)
             s_r_loc = sum(np.sum(mr * w) for (mr, _), w in zip(m, ch["wgts"]))
             s_i_loc = sum(np.sum(mi * w) for (_, mi), w in zip(m, ch["wgts"]))
-            loss, gg_r, gg_i, gf_r, gf_i = R.loss_and_grads(
-                g_r, g_i, fg_r, fg_i, ch["fg_comps"], ch["data_r"], ch["data_i"], ch["wgts"], a0, a1,
-                s_r_loc - (s_r - priors[0]), s_i_loc - (s_i - priors[1]),
-            )
-            chi2 = loss - (s_r - priors[0]) ** 2 - (s_i - priors[1]) ** 2
-            buf = torch.from_numpy(np.concatenate([np.stack([gg_r, gg_i], axis=-1).ravel(), [chi2, 0.0, 0.0, 0.0]]))
-            dist.all_reduce(buf)
+
+            def grads_at(alpha_r, alpha_i):  # local gradient with alpha forced: prior = S_local - alpha / 2
+                out = R.loss_and_grads(g_r, g_i, fg_r, fg_i, ch["fg_comps"], ch["data_r"], ch["data_i"], ch["wgts"], a0, a1,
+                                       s_r_loc - alpha_r / 2.0, s_i_loc - alpha_i / 2.0)
+                gg = out[1] + 1j * out[2]
+                gf = [a + 1j * b for a, b in zip(out[3], out[4])]
+                return out[0] - (alpha_r / 2.0) ** 2 - (alpha_i / 2.0) ** 2, gg, gf
+
+            chi2, gg0, gf0 = grads_at(0.0, 0.0)
+            _, gga, gfa = grads_at(1.0, 0.0)
+            _, ggb, gfb = grads_at(0.0, 1.0)
+            ga, gb = gga - gg0, ggb - gg0                      # d grad / d alpha_r, d grad / d alpha_i
+            r1, r2 = (ga - 1j * gb) / 2.0, (ga + 1j * gb) / 2.0  # alpha r1 + conj(alpha) r2 = alpha_r ga + alpha_i gb
+            gf1 = [a - z for a, z in zip(gfa, gf0)]
+            for one, other, z in zip(gf1, gfb, gf0):             # coefficients need ONE complex part: d/d alpha_i = i d/d alpha_r
+                np.testing.assert_allclose(other - z, 1j * one, rtol=1e-9, atol=1e-14)
+            parts = np.concatenate([np.stack([x.real, x.imag], axis=-1).ravel() for x in (gg0, r1, r2)])
+            assert parts.size == spec["gain_grad_reals"]
+            buf = torch.from_numpy(np.concatenate([parts, [chi2, s_r_loc, s_i_loc, 0.0]]))
+            assert buf.numel() == spec["gain_grad_reals"] + spec["scalars_f64"]
+            dist.all_reduce(buf)  # the one exchange of the step
             buf = buf.numpy()
-            gg = buf[:-4].reshape(p.nants, p.nfreqs, 2)
-            gg_r, gg_i = gg[..., 0].copy(), gg[..., 1].copy()
-            loss = buf[-4] + (s_r - priors[0]) ** 2 + (s_i - priors[1]) ** 2
+            q = buf[:-4].reshape(3, p.nants, p.nfreqs, 2)
+            q = q[..., 0] + 1j * q[..., 1]
+            alpha = 2.0 * ((buf[-3] - priors[0]) + 1j * (buf[-2] - priors[1]))
+            gg = q[0] + alpha * q[1] + np.conj(alpha) * q[2]
+            gg_r, gg_i = gg.real.copy(), gg.imag.copy()
+            gf = [z + alpha * one for z, one in zip(gf0, gf1)]   # local: a group's coefficients live on one rank
+            gf_r, gf_i = [x.real.copy() for x in gf], [x.imag.copy() for x in gf]
+            loss = buf[-4] + (buf[-3] - priors[0]) ** 2 + (buf[-2] - priors[1]) ** 2
         losses.append(loss)
         opt_g.apply_gradients([(gg_r, g_r), (gg_i, g_i)])
         opt_c.apply_gradients(list(zip(gf_r, fg_r)) + list(zip(gf_i, fg_i)))

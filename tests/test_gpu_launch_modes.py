@@ -123,3 +123,62 @@ def test_resume_from_parameters_and_moments(optimizer, mode, dtype):
     np.testing.assert_array_equal(np.concatenate([l5, l5b]), l10)
     for x, y in zip(got, want):
         np.testing.assert_array_equal(x, y)
+
+
+OPT_CASES = [
+    ("SGD", dict(learning_rate=0.5)),
+    ("SGD", dict(learning_rate=0.2, momentum=0.8)),
+    ("SGD", dict(learning_rate=0.2, momentum=0.8, nesterov=True)),
+    ("RMSprop", dict(learning_rate=1e-3)),
+    ("RMSprop", dict(learning_rate=1e-3, rho=0.8, momentum=0.5)),
+    ("Adagrad", dict(learning_rate=5e-2)),
+    ("Adagrad", dict(learning_rate=5e-2, initial_accumulator_value=0.0)),
+    ("Adadelta", dict(learning_rate=1.0, rho=0.9)),
+    ("Nadam", dict(learning_rate=1e-2)),
+]
+
+
+@pytest.mark.parametrize("optimizer,kw", OPT_CASES, ids=[f"{n}-{'-'.join(sorted(k))}" for n, k in OPT_CASES])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_other_keras_optimizers_follow_the_oracle(optimizer, kw, dtype):
+    """The remaining OPTIMIZERS entries (calibration.py:17-27; Keras OptimizerV2 semantics) against the oracle's classes over the
+    reference loop (one unrecorded update, then 25 recorded ones), and the same numbers from every launch form."""
+    from calamity_amd import problem
+    from oracle import ref_numpy as R
+    from test_gpu_parity import TOL, oracle_inputs, relnorm
+
+    p, start = make_case(seed=31, with_sky=True)
+    ch, fg_r, fg_i = oracle_inputs(p, start)
+    ref = R.fit_gains_and_foregrounds(start["g_r"], start["g_i"], fg_r, fg_i, ch["data_r"], ch["data_i"], ch["wgts"], ch["fg_comps"],
+                                      ch["corr_inds"], maxsteps=25, tol=0.0, optimizer=optimizer, sky_model_r=ch["sky_model_r"],
+                                      sky_model_i=ch["sky_model_i"], model_regularization="sum", **kw)
+    outs = []
+    for mode in ("kernels", "graph"):
+        s = make_solver(p, start, dtype, reg=True)
+        s.set_launch_mode(mode)
+        s.set_optimizer(optimizer, **kw)
+        s.run(1, record=False)
+        losses, _, nupd = s.run(25, record=True, tol=0.0)
+        outs.append((losses, s.get_params()))
+        s.close()
+        assert nupd == 25
+    tol = TOL[dtype]["traj"]
+    losses, (g_r, g_i, c_r, c_i) = outs[0]
+    np.testing.assert_allclose(losses, np.asarray(ref[4]["loss"], dtype=np.float64), rtol=tol)
+    assert relnorm(g_r.astype(np.float64) + 1j * g_i, ref[0] + 1j * ref[1]) <= tol
+    assert relnorm(c_r, problem.coeffs_from_chunks(p, ref[2])) <= tol and relnorm(c_i, problem.coeffs_from_chunks(p, ref[3])) <= tol
+    np.testing.assert_array_equal(outs[1][0], losses)
+    for x, y in zip(outs[1][1], outs[0][1]):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_optimizer_arguments_are_checked_like_keras():
+    p, start = make_case(seed=1)
+    s = make_solver(p, start, np.float32)
+    with pytest.raises(KeyError):
+        s.set_optimizer("Ftrl")
+    with pytest.raises(TypeError):
+        s.set_optimizer("SGD", beta_1=0.9)  # not an argument of tf.keras.optimizers.SGD
+    with pytest.raises(TypeError):
+        s.set_optimizer("Adam", momentum=0.9)
+    s.close()

@@ -132,6 +132,71 @@ def test_optimizer_first_steps_known_answer():
         R.OPTIMIZERS["NotAnOptimizer"]
 
 
+def test_other_keras_optimizers_known_answers():
+    """Two hand-computed steps of the remaining OPTIMIZERS entries (calibration.py:17-27) on x = 0 with gradients g1, g2
+    (tf.keras.optimizers.* OptimizerV2 formulae, written out here independently of the oracle's classes)."""
+    g1, g2 = np.array([0.5, -2.0]), np.array([0.25, 1.0])
+
+    def two_steps(name, **kw):
+        x = np.zeros(2)
+        opt = R.OPTIMIZERS[name](**kw)
+        opt.apply_gradients([(g1, x)])
+        first = x.copy()
+        opt.apply_gradients([(g2, x)])
+        return first, x
+
+    lr = 0.1
+    # SGD: plain, momentum, nesterov
+    a, b = two_steps("SGD", learning_rate=lr)
+    np.testing.assert_allclose(a, -lr * g1, rtol=1e-15)
+    np.testing.assert_allclose(b, -lr * (g1 + g2), rtol=1e-15)
+    a, b = two_steps("SGD", learning_rate=lr, momentum=0.9)
+    v1 = -lr * g1
+    v2 = 0.9 * v1 - lr * g2
+    np.testing.assert_allclose(a, v1, rtol=1e-15)
+    np.testing.assert_allclose(b, v1 + v2, rtol=1e-15)
+    a, b = two_steps("SGD", learning_rate=lr, momentum=0.9, nesterov=True)
+    np.testing.assert_allclose(a, 0.9 * v1 - lr * g1, rtol=1e-15)
+    np.testing.assert_allclose(b, (0.9 * v1 - lr * g1) + (0.9 * v2 - lr * g2), rtol=1e-15)
+    # RMSprop: epsilon outside the root without momentum, inside with it
+    a, b = two_steps("RMSprop", learning_rate=lr)
+    r1 = 0.1 * g1**2
+    r2 = 0.9 * r1 + 0.1 * g2**2
+    np.testing.assert_allclose(a, -lr * g1 / (np.sqrt(r1) + 1e-7), rtol=1e-15)
+    np.testing.assert_allclose(b, a - lr * g2 / (np.sqrt(r2) + 1e-7), rtol=1e-15)
+    a, b = two_steps("RMSprop", learning_rate=lr, momentum=0.5)
+    m1 = lr * g1 / np.sqrt(r1 + 1e-7)
+    m2 = 0.5 * m1 + lr * g2 / np.sqrt(r2 + 1e-7)
+    np.testing.assert_allclose(a, -m1, rtol=1e-15)
+    np.testing.assert_allclose(b, -m1 - m2, rtol=1e-15)
+    # Adagrad: accumulator starts at 0.1
+    a, b = two_steps("Adagrad", learning_rate=lr)
+    np.testing.assert_allclose(a, -lr * g1 / (np.sqrt(0.1 + g1**2) + 1e-7), rtol=1e-15)
+    np.testing.assert_allclose(b, a - lr * g2 / (np.sqrt(0.1 + g1**2 + g2**2) + 1e-7), rtol=1e-15)
+    # Adadelta
+    a, b = two_steps("Adadelta", learning_rate=lr)
+    acc1 = 0.05 * g1**2
+    u1 = np.sqrt(1e-7) / np.sqrt(acc1 + 1e-7) * g1
+    accu1 = 0.05 * u1**2
+    acc2 = 0.95 * acc1 + 0.05 * g2**2
+    u2 = np.sqrt(accu1 + 1e-7) / np.sqrt(acc2 + 1e-7) * g2
+    np.testing.assert_allclose(a, -lr * u1, rtol=1e-14)
+    np.testing.assert_allclose(b, -lr * (u1 + u2), rtol=1e-14)
+    # Nadam: momentum schedule mu_t = b1 (1 - 0.5 * 0.96^(0.004 t))
+    a, b = two_steps("Nadam", learning_rate=lr)
+    mu = [0.9 * (1 - 0.5 * 0.96 ** (0.004 * t)) for t in (1, 2, 3)]
+    m1 = 0.1 * g1
+    v1 = 0.001 * g1**2
+    s1 = mu[0]
+    step1 = ((1 - mu[0]) * g1 / (1 - s1) + mu[1] * m1 / (1 - s1 * mu[1])) / (np.sqrt(v1 / (1 - 0.999)) + 1e-7)
+    np.testing.assert_allclose(a, -lr * step1, rtol=1e-14)
+    m2 = 0.9 * m1 + 0.1 * g2
+    v2 = 0.999 * v1 + 0.001 * g2**2
+    s2 = s1 * mu[1]
+    step2 = ((1 - mu[1]) * g2 / (1 - s2) + mu[2] * m2 / (1 - s2 * mu[2])) / (np.sqrt(v2 / (1 - 0.999**2)) + 1e-7)
+    np.testing.assert_allclose(b, a - lr * step2, rtol=1e-14)
+
+
 def test_loop_semantics():
     p, ch, g_r, g_i, fg_r, fg_i = _setup(seed=2)
     kw = dict(data_r=ch["data_r"], data_i=ch["data_i"], wgts=ch["wgts"], fg_comps=ch["fg_comps"], corr_inds=ch["corr_inds"], optimizer="Adam", learning_rate=1e-2)

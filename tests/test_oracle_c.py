@@ -80,3 +80,27 @@ def test_fp32_build_close_to_fp64():
     assert abs(l32 - l64) <= 1e-5 * abs(l64)
     for a, b in zip(g32, g64):
         assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
+
+
+def test_c_restatement_is_clean_under_sanitizers():
+    """oracle/ref_c.c built with -fsanitize=address,undefined (oracle/Makefile: libref_c_san.so) and driven through the same
+    comparisons in a child process that preloads the sanitizer runtime: any out-of-bounds access, use of uninitialised
+    stack, signed overflow or misaligned access in the restatement aborts the child (sanitizers on the
+    CPU build only -- the GPU pool offers none)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    odir = os.path.join(os.path.dirname(here), "oracle")
+    build = subprocess.run(["make", "-C", odir, "libref_c_san.so"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stdout + build.stderr
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("gcc has no libasan here")
+    env = dict(os.environ, LD_PRELOAD=asan, ORACLE_REF_C_LIB=os.path.join(odir, "libref_c_san.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", OMP_NUM_THREADS="3")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                          "-k", "not sanitizers"], env=env, capture_output=True, text=True, cwd=os.path.dirname(here), timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "passed" in res.stdout
