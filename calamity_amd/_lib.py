@@ -37,6 +37,7 @@ class ProblemDesc(C.Structure):
         ("bl_rowblk", C.c_void_p),
         ("layout", C.c_int32),
         ("kernel_path", C.c_int32),
+        ("bl_alias", C.c_void_p),
     ]
 
 

@@ -166,6 +166,9 @@ struct SolverT final : cal_solver {
   DevBuf scal;                                 // 4 doubles: loss, s_r, s_i
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
+  DevBuf members, heads;                       // baselines that share tiles (bl_alias): member lists of the head items, head item indices
+  int nheads = 0;
+  size_t lds_multi_bytes = 0;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
@@ -250,6 +253,14 @@ struct SolverT final : cal_solver {
     if (fb == M / 4) return group_lds_bytes<T, M / 4>();
     if (fb == M / 8) return group_lds_bytes<T, M / 8>();
     return group_lds_bytes<T, M / 16>();
+  }
+  static size_t multi_lds_for(int fb) {
+    constexpr int M = FbSet<T>::fb_max;
+    if (fb == M) return multi_lds_bytes<T, M>();
+    if (fb == M / 2) return multi_lds_bytes<T, M / 2>();
+    if (fb == M / 4) return multi_lds_bytes<T, M / 4>();
+    if (fb == M / 8) return multi_lds_bytes<T, M / 8>();
+    return multi_lds_bytes<T, M / 16>();
   }
   static size_t lds_for(int fb) {
     constexpr int M = FbSet<T>::fb_max;
@@ -368,6 +379,26 @@ struct SolverT final : cal_solver {
       }
     }
     ncoef = h_grp_coff[ngrps];
+    // ---- baselines that read another baseline's tiles (STREAM layout): the same physical baseline in several time slices
+    std::vector<int> alias_root(nbls, -1);  // -1: owns its tiles
+    if (d->bl_alias && layout == CAL_LAYOUT_STREAM) {
+      for (int b = 0; b < nbls; ++b) {
+        const int r = d->bl_alias[b];
+        if (r < 0 || r == b) continue;
+        if (r >= nbls || d->bl_alias[r] >= 0 && d->bl_alias[r] != r)
+          return fail(CAL_ERR_INVALID, "set_problem: bl_alias[%d] = %d must name a baseline that owns its tiles", b, r);
+        const int g = grp_of_bl[b], gr = grp_of_bl[r];
+        if (d->grp_basis[g] != d->grp_basis[gr] || (d->bl_rowblk ? d->bl_rowblk[b] != d->bl_rowblk[r] : false))
+          return fail(CAL_ERR_INVALID, "set_problem: bl_alias[%d] = %d: the two baselines use different basis rows", b, r);
+        if (d->grp_bl_start[g + 1] - d->grp_bl_start[g] != 1 || d->grp_bl_start[gr + 1] - d->grp_bl_start[gr] != 1)
+          return fail(CAL_ERR_INVALID, "set_problem: bl_alias is for single-baseline fitting groups (baseline %d)", b);
+        alias_root[b] = r;
+      }
+    }
+    std::vector<char> in_alias_set(nbls, 0);
+    const bool multi_ok = (long long)(nbls + 1) * fpad < (1LL << 31) && (long long)nants * fpad < (1LL << 31);  // the multi kernel's 32-bit sample offsets
+    for (int b = 0; b < nbls; ++b)
+      if (alias_root[b] >= 0 && multi_ok) in_alias_set[b] = in_alias_set[alias_root[b]] = 1;
 
     // ---- unique basis blocks -> tile-major device layout
     const long long raw_elems = d->basis_offset[nbasis];
@@ -411,10 +442,13 @@ struct SolverT final : cal_solver {
           h_bl_tile[b] = h_bl_tile[b - 1];
           continue;
         }
+        if (alias_root[b] >= 0) continue;  // filled in below, once its owner's offset is known (the owner may come later)
         jobs.push_back(CopyJob{uoff[u] + (long long)rb * n, off, n});
         h_bl_tile[b] = off;
         off += n;
       }
+      for (int b = 0; b < nbls; ++b)
+        if (alias_root[b] >= 0) h_bl_tile[b] = h_bl_tile[alias_root[b]];
       CAL_TRY(tiles.alloc((size_t)off * sizeof(T), false));
       DevBuf djobs;
       CAL_TRY(djobs.alloc(jobs.size() * sizeof(CopyJob), false));
@@ -593,7 +627,8 @@ struct SolverT final : cal_solver {
       it.pad = g;
       if (d->grp_bl_start[g + 1] - d->grp_bl_start[g] == 1) {
         const long long nt = ntpb;
-        const int nparts = (int)std::max<long long>(1, (nt + tiles_per_item - 1) / tiles_per_item);
+        // (a baseline that shares tiles stays ONE item: the multi kernel writes the whole coefficient gradient of its group)
+        const int nparts = in_alias_set[d->grp_bl_start[g]] ? 1 : (int)std::max<long long>(1, (nt + tiles_per_item - 1) / tiles_per_item);
         if (nparts > 1) gc_direct = false;
         for (int p = 0; p < nparts; ++p) {
           it.bl0 = d->grp_bl_start[g];
@@ -661,7 +696,56 @@ struct SolverT final : cal_solver {
     for (int q = 0; q < nitems; ++q) {
       sorted[q] = h_items[order[q]];
       sorted[q].goff = h_item_goff[order[q]];
+      sorted[q].role_n = 0;
+      sorted[q].member0 = 0;
       sorted[q].pad = 0;
+    }
+    // ---- sets of baselines that share tiles -> head items with member lists (at most MultiCfg<T>::nb_max baselines each)
+    nheads = 0;
+    lds_multi_bytes = 0;
+    {
+      std::vector<int> item_of_bl(nbls, -1);
+      for (int q = 0; q < nitems; ++q)
+        if (!h_item_multi[order[q]]) item_of_bl[sorted[q].bl0] = q;
+      std::vector<std::vector<int>> sets(nbls);
+      for (int b = 0; b < nbls; ++b)
+        if (in_alias_set[b]) sets[alias_root[b] >= 0 ? alias_root[b] : b].push_back(b);
+      std::vector<Member> h_members;
+      std::vector<int> h_heads;
+      constexpr int NBM = MultiCfg<T>::nb_max;
+      for (int r = 0; r < nbls; ++r) {
+        for (size_t i = 0; i < sets[r].size(); i += NBM) {
+          const int n = (int)std::min<size_t>(NBM, sets[r].size() - i);
+          if (n < 2) continue;  // a lone baseline runs as an ordinary item
+          const int head = item_of_bl[sets[r][i]];
+          sorted[head].role_n = (n << 2) | 1;
+          sorted[head].member0 = (int)h_members.size();
+          h_heads.push_back(head);
+          lds_multi_bytes = std::max(lds_multi_bytes, multi_lds_for(1 << sorted[head].fb_log2));
+          for (int k = 0; k < n; ++k) {
+            const int b = sets[r][i + k], q = item_of_bl[b];
+            if (k > 0) sorted[q].role_n = 2;
+            Member m{};
+            m.bl = b;
+            m.coff = sorted[q].coff;
+            m.goff = sorted[q].goff;
+            m.ant0 = d->bl_ant0[b];
+            m.ant1 = d->bl_ant1[b];
+            h_members.push_back(m);
+          }
+        }
+      }
+      nheads = (int)h_heads.size();
+      members.release();
+      heads.release();
+      if (nheads > 0) {
+        CAL_TRY(members.alloc(h_members.size() * sizeof(Member), false));
+        HIP_TRY(hipMemcpy(members.p, h_members.data(), h_members.size() * sizeof(Member), hipMemcpyHostToDevice));
+        CAL_TRY(heads.alloc(h_heads.size() * sizeof(int), false));
+        HIP_TRY(hipMemcpy(heads.p, h_heads.data(), h_heads.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_LOSS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+      }
     }
     CAL_TRY(items.alloc(nitems * sizeof(Item), false));
     HIP_TRY(hipMemcpy(items.p, sorted.data(), nitems * sizeof(Item), hipMemcpyHostToDevice));
@@ -863,6 +947,8 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipSetDevice(device));
     if (!has_problem) return fail(CAL_ERR_STATE, "set_regularization before set_problem");
     if (mode != CAL_REG_NONE && mode != CAL_REG_SUM) return fail(CAL_ERR_INVALID, "set_regularization: unknown mode %d", mode);
+    if (mode != reg && nheads > 0) HIP_TRY(hipMemsetAsync(part.p, 0, part.bytes, stream));  // member items write their slot only in the regularised form
+    if (mode != reg) drop_graph();
     reg = mode;
     prior_r = pr;
     prior_i = pi;
@@ -1015,6 +1101,8 @@ struct SolverT final : cal_solver {
     a.runs = runs.as<int2>();
     a.item_base = 0;
     a.stream_once = layout == CAL_LAYOUT_STREAM ? 1 : 0;
+    a.members = members.as<Member>();
+    a.heads = nheads > 0 ? heads.as<int>() : nullptr;
     return a;
   }
   // LDS buffer of gbar_G rows (MODE_GRAD); the narrowest tiles have the longest offset table
@@ -1028,6 +1116,10 @@ struct SolverT final : cal_solver {
         hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems_simple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax2 : 0), stream, a);
       else
         hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems_simple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
+    }
+    if constexpr (MODE == MODE_LOSS || MODE == MODE_GRAD) {
+      // baselines that share tiles (skipped by the launch above): one workgroup per set
+      if (nheads > 0 && !with_reg) hipLaunchKernelGGL((fused_multi_kernel<T, MODE>), dim3(nheads), dim3(kThreads), lds_multi_bytes, stream, a);
     }
     if (nitems > nitems_simple) {
       a.item_base = nitems_simple;
@@ -1485,7 +1577,7 @@ struct SolverT final : cal_solver {
     const DevBuf* all[] = {&tiles, &bl_tile, &bl_ant, &items, &ant_ptr, &ant_ent, &coef_grp, &grp_coff, &grp_item_ptr, &item_goff,
                            &data_r, &data_i, &wgts, &gains, &gains_alt, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
                            &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf,
-                           &mf_ops, &mf_panels, &mf_map};
+                           &mf_ops, &mf_panels, &mf_map, &members, &heads};
     int64_t n = 0;
     for (auto* d : all) n += (int64_t)d->bytes;
     *b = n;

@@ -75,12 +75,26 @@ struct Item {        // one workgroup's share of a fitting group
   int coff;          // offset of the group's coefficients in the flat coefficient planes
   int goff;          // offset of this item's partial coefficient gradient
   int fb_log2;       // log2 of the channel-block width of this group's tiles
-  int pad;
+  int role_n;        // baselines that read the SAME tiles (cal_problem_desc::bl_alias): 0 = an ordinary item; (n << 2) | 1 = head of a
+                     // set of n such baselines, processed by fused_multi_kernel; 2 = member covered by a head.  Heads and members
+                     // stay complete single-baseline items: the passes without a multi form (model, initial coefficients, the
+                     // two-adjoint-set regulariser) run them one by one
   // single-baseline groups: tile offset and antenna pair of the baseline the item starts with (bl_tile / bl_ant of it), so
   // that the item's first tile loads do not wait for a lookup of their own
   long long tile_first;
   int2 ant_first;
+  int member0;       // head: its first entry in FusedArgs::members
+  int pad;
 };
+
+struct Member {      // one baseline of a set that shares tiles
+  int bl;            // row of its samples
+  int coff;          // its group's coefficients
+  int goff;          // where its coefficient gradient goes (its own item's slot)
+  int ant0, ant1;
+  int pad[3];
+};
+template <typename T> struct MultiCfg { static constexpr int nb_max = sizeof(T) == 4 ? 8 : 4; };  // baselines per multi item (gradient accumulators live in registers)
 
 template <typename T>
 struct FusedArgs {
@@ -106,6 +120,8 @@ struct FusedArgs {
   int stream_once;           // CAL_LAYOUT_STREAM: every tile is read once per pass
   const int2* runs;          // group kernel: [nruns] (first baseline, one past the last) of baselines that share a row block
   int item_base;             // index of this launch's first item in `items` / `part`
+  const Member* members;     // multi kernel: the baselines of every head item
+  const int* heads;          // multi kernel: [grid] item index of each head
 };
 
 enum { MODE_LOSS = 0, MODE_GRAD = 1, MODE_MODEL = 2, MODE_INIT = 3 };  // INIT: c = A^T (src * [w != 0]), calibration.py:875-902
@@ -470,6 +486,214 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Several single-baseline groups that read the SAME tiles: the same physical baseline in the time slices a rank fits
+// together (cal_problem_desc::bl_alias, STREAM layout; the reference loops over times, calibration.py:1160-1167, and SURVEY
+// section 8e "Multiple times" asks for A to be read once for all of them).  The tile is loaded ONCE into the registers of
+// process_item's layout and serves the forward product, the per-channel stage and the adjoint of every member: per tile one
+// load, two barriers and 2 NB products instead of NB loads and 2 NB barriers -- an item of 8 slices moves an eighth of the
+// bytes of 8 single items.  Coefficients of all members sit in LDS, their gradient accumulators in registers (NB <= 8 in
+// float32, 4 in float64), gbar_G goes straight to HBM (the pass is no longer bound by the tile stream that a store would delay).
+template <typename T, int FB>
+constexpr size_t multi_lds_bytes() {
+  constexpr int NB = MultiCfg<T>::nb_max;
+  return ((size_t)NB * TileCfg<T, FB>::MAXK + (size_t)NB * kWaves * FB + (size_t)NB * FB) * 2 * sizeof(T) + NB * sizeof(Member) + 64;
+}
+template <typename T, int FB, int MODE>
+__device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const Item it, unsigned char* smem, int item_idx) {
+  using C = TileCfg<T, FB>;
+  using T2 = vec2_t<T>;
+  constexpr int VEC = C::VEC;
+  constexpr int LPR = C::LPR;
+  constexpr int NS = C::NS;
+  constexpr int L = kMaxLoads;
+  constexpr int NBMAX = MultiCfg<T>::nb_max;
+  constexpr int R = (NBMAX * FB + kThreads - 1) / kThreads;  // (member, channel) pairs of the per-channel stage per thread
+  constexpr bool GRAD = MODE == MODE_GRAD;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int fq = tid % LPR;
+  const int ks = tid / LPR;
+  const int f0 = fq * VEC;
+  const int nvec = it.nvec;
+  const int NB = it.role_n >> 2;
+  const int ntpb = A.fpad / FB;
+  const int tile_elems = nvec * FB;
+
+  T2* s_c = reinterpret_cast<T2*>(smem);            // [NBMAX][MAXK] coefficients of every member
+  T2* s_pv = s_c + NBMAX * C::MAXK;                 // [NBMAX][kWaves][FB] forward partials of the four waves
+  T2* s_gv = s_pv + NBMAX * kWaves * FB;            // [NBMAX][FB] gbar_v
+  Member* s_mem = reinterpret_cast<Member*>(s_gv + NBMAX * FB);
+  typedef T stage_t __attribute__((ext_vector_type(16 / sizeof(T))));
+
+  if (tid < NB * (int)(sizeof(Member) / 4)) reinterpret_cast<int*>(s_mem)[tid] = reinterpret_cast<const int*>(A.members + it.member0)[tid];
+  __syncthreads();
+  for (int n = tid; n < NB * C::MAXK; n += kThreads) {
+    const int m = n / C::MAXK, k = n - m * C::MAXK;
+    T2 c;
+    c.x = k < nvec ? A.c_r[s_mem[m].coff + k] : (T)0;
+    c.y = k < nvec ? A.c_i[s_mem[m].coff + k] : (T)0;
+    s_c[n] = c;
+  }
+  unsigned voff[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) voff[l] = (unsigned)((min(l * NS + ks, nvec - 1) * FB + f0) * (int)sizeof(T));
+  T2 acc[NBMAX][L];
+#pragma unroll
+  for (int m = 0; m < NBMAX; ++m)
+#pragma unroll
+    for (int l = 0; l < L; ++l) acc[m][l].x = acc[m][l].y = 0;
+  double loss_acc = 0.0;
+  // this thread's (member, channel) pairs of the per-channel stage: pair p = r * 256 + tid -> member p / FB, channel p % FB
+  int pm[R], pch[R];
+  unsigned prow[R];    // sample row of the member: bl * fpad (32-bit element offsets: the host checks (nbls + 1) * fpad < 2^31)
+  unsigned pg0[R], pg1[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int p = r * kThreads + tid;
+    pm[r] = p / FB;
+    pch[r] = p % FB;
+    const int mm = min(pm[r], NB - 1);  // pairs past the last member are computed on it and discarded
+    prow[r] = (unsigned)s_mem[mm].bl * (unsigned)A.fpad + (unsigned)pch[r];
+    pg0[r] = (unsigned)s_mem[mm].ant0 * (unsigned)A.fpad + (unsigned)pch[r];
+    pg1[r] = (unsigned)s_mem[mm].ant1 * (unsigned)A.fpad + (unsigned)pch[r];
+  }
+  __syncthreads();  // s_c complete
+
+  for (int fbk = 0; fbk < ntpb; ++fbk) {
+    // ---- issue: the per-channel operands of this thread's pairs, then the tile (once for all members)
+    T d_r[R], d_i[R], w[R];
+    T2 g0[R], g1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned o = prow[r] + (unsigned)(fbk * FB);
+      d_r[r] = __builtin_nontemporal_load(A.data_r + o);
+      d_i[r] = __builtin_nontemporal_load(A.data_i + o);
+      w[r] = __builtin_nontemporal_load(A.wgts + o);
+      g0[r] = A.gains[pg0[r] + (unsigned)(fbk * FB)];
+      g1[r] = A.gains[pg1[r] + (unsigned)(fbk * FB)];
+    }
+    const char* src = reinterpret_cast<const char*>(A.tiles + it.tile_first + (long long)fbk * tile_elems);
+    stage_t stage[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) stage[l] = __builtin_nontemporal_load(reinterpret_cast<const stage_t*>(src + voff[l]));
+
+    // ---- forward, one member after the other, from the same registers
+#pragma unroll
+    for (int m = 0; m < NBMAX; ++m) {
+      if (m < NB) {
+        T2 pv[VEC];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) pv[u].x = pv[u].y = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) fma_rows(pv, stage[l], s_c[m * C::MAXK + l * NS + ks]);
+#pragma unroll
+        for (int sft = LPR; sft < 64; sft <<= 1) {
+#pragma unroll
+          for (int u = 0; u < VEC; ++u) {
+            pv[u].x += __shfl_xor(pv[u].x, sft, 64);
+            pv[u].y += __shfl_xor(pv[u].y, sft, 64);
+          }
+        }
+        if (lane < LPR) {
+#pragma unroll
+          for (int u = 0; u < VEC; ++u) s_pv[(m * kWaves + wave) * FB + f0 + u] = pv[u];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- per-channel stage of every (member, channel) pair
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int m = pm[r], ch = pch[r];
+      if (m < NB) {
+        T vr = 0, vi = 0;
+#pragma unroll
+        for (int wv = 0; wv < kWaves; ++wv) {
+          const T2 p = s_pv[(m * kWaves + wv) * FB + ch];
+          vr += p.x;
+          vi += p.y;
+        }
+        // G = g0 conj(g1)   (calibration.py:1598-1601: grgr + gigi, gigr - grgi)
+        const T G_r = g0[r].x * g1[r].x + g0[r].y * g1[r].y;
+        const T G_i = g0[r].y * g1[r].x - g0[r].x * g1[r].y;
+        const T m_r = G_r * vr - G_i * vi;
+        const T m_i = G_i * vr + G_r * vi;
+        const T r_r = d_r[r] - m_r;
+        const T r_i = d_i[r] - m_i;
+        loss_acc += (double)(w[r] * (r_r * r_r + r_i * r_i));
+        if (GRAD) {
+          const T e_r = (T)-2 * w[r] * r_r;
+          const T e_i = (T)-2 * w[r] * r_i;
+          T2 gv;  // gbar_v = conj(G) e
+          gv.x = G_r * e_r + G_i * e_i;
+          gv.y = G_r * e_i - G_i * e_r;
+          s_gv[m * FB + ch] = gv;
+          T2 q;   // gbar_G = conj(v) e
+          q.x = vr * e_r + vi * e_i;
+          q.y = vr * e_i - vi * e_r;
+          A.q0[prow[r] + (unsigned)(fbk * FB)] = q;
+        }
+      }
+    }
+    if (GRAD) {
+      __syncthreads();
+      // ---- adjoint of every member: this thread's channels of its gbar_v against its rows of the tile
+#pragma unroll
+      for (int m = 0; m < NBMAX; ++m) {
+        if (m < NB) {
+          T2 gv[VEC];
+#pragma unroll
+          for (int u = 0; u < VEC; ++u) gv[u] = s_gv[m * FB + f0 + u];
+#pragma unroll
+          for (int l = 0; l < L; ++l) fma_cols(acc[m][l], stage[l], gv);
+        }
+      }
+    } else {
+      __syncthreads();  // the next tile's forward partials overwrite s_pv
+    }
+    // GRAD needs no barrier here: s_pv is rewritten before the next first barrier, which no wave reaches before it has left
+    // this tile's per-channel stage (it sits behind the second barrier); s_gv is rewritten behind the next first barrier
+  }
+
+  // ---- epilogue: loss partial of the item (all members), coefficient gradients of every member
+  __syncthreads();
+  double* s_red = reinterpret_cast<double*>(s_pv);
+  const double ls = ldsum(loss_acc);
+  if (lane == 0) s_red[wave] = ls;
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0;
+    for (int wv = 0; wv < kWaves; ++wv) a += s_red[wv];
+    A.part[(size_t)item_idx * 4 + 0] = a;
+    A.part[(size_t)item_idx * 4 + 1] = 0.0;
+    A.part[(size_t)item_idx * 4 + 2] = 0.0;
+  }
+  if (GRAD) {
+#pragma unroll
+    for (int m = 0; m < NBMAX; ++m) {
+      if (m < NB) {
+        const int goff = s_mem[m].goff;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+#pragma unroll
+          for (int sft = 1; sft < LPR; sft <<= 1) {
+            acc[m][l].x += __shfl_xor(acc[m][l].x, sft, 64);
+            acc[m][l].y += __shfl_xor(acc[m][l].y, sft, 64);
+          }
+          const int k = l * NS + ks;
+          if (fq == 0 && k < nvec) {
+            A.gcp0_r[goff + k] = acc[m][l].x;
+            A.gcp0_i[goff + k] = acc[m][l].y;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- streaming-peak probes (cal_device_stream_peak): what the memory system delivers to the simplest possible kernel
 typedef float f4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void stream_read_kernel(const f4_t* __restrict__ src, size_t n, float* __restrict__ sink) {
@@ -797,6 +1021,8 @@ void fused_basis_kernel(const FusedArgs<T> A) {
   const int idx = A.item_base + blockIdx.x;
   const Item it = A.items[idx];  // requested together with the stop flags: one round trip, not two
   if (A.state->done | A.state->done_after) return;
+  // baselines that share tiles are processed together by fused_multi_kernel in the passes that have such a form
+  if (!REG && (MODE == MODE_LOSS || MODE == MODE_GRAD) && (it.role_n & 3) != 0 && A.heads != nullptr) return;
   constexpr int FBM = FbSet<T>::fb_max;
   const int fb = 1 << it.fb_log2;
   if (fb == FBM) process_item<T, FBM, MODE, REG>(A, it, smem, idx);
@@ -804,6 +1030,21 @@ void fused_basis_kernel(const FusedArgs<T> A) {
   else if (fb == FBM / 4) process_item<T, FBM / 4, MODE, REG>(A, it, smem, idx);
   else if (fb == FBM / 8) process_item<T, FBM / 8, MODE, REG>(A, it, smem, idx);
   else process_item<T, FBM / 16, MODE, REG>(A, it, smem, idx);
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kThreads, 2) void fused_multi_kernel(const FusedArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int idx = A.heads[blockIdx.x];
+  const Item it = A.items[idx];
+  if (A.state->done | A.state->done_after) return;
+  constexpr int FBM = FbSet<T>::fb_max;
+  const int fb = 1 << it.fb_log2;
+  if (fb == FBM) process_multi_item<T, FBM, MODE>(A, it, smem, idx);
+  else if (fb == FBM / 2) process_multi_item<T, FBM / 2, MODE>(A, it, smem, idx);
+  else if (fb == FBM / 4) process_multi_item<T, FBM / 4, MODE>(A, it, smem, idx);
+  else if (fb == FBM / 8) process_multi_item<T, FBM / 8, MODE>(A, it, smem, idx);
+  else process_multi_item<T, FBM / 16, MODE>(A, it, smem, idx);
 }
 
 template <typename T, int MODE, bool REG>
@@ -839,6 +1080,38 @@ __global__ void coeff_partial_reduce_kernel(const T* __restrict__ gcp_r, const T
   }
   gc_r[n] = a;
   gc_i[n] = b;
+}
+
+// Sum of the per-item loss partials (chi^2, S_r, S_i) by one 256-thread block, in a fixed order: thread t takes items
+// t, t + 256, ...; a butterfly over the 64 lanes of each wave; the four waves in order.  Shared by gain_grad_kernel's last
+// block and by every block of step_tail_kernel (the launch forms of a step must agree bit for bit).  x: the caller's loads of
+// item threadIdx.x (issued early so that they travel together with its other loads), valid when threadIdx.x < n.
+// Result in out[0..2] on every thread; sh: 12 doubles of LDS.
+__device__ __forceinline__ void sum_partials(const double* __restrict__ part, int n, const double x[3], double* sh, double out[3]) {
+  const int tid = threadIdx.x;
+  double a = 0, b = 0, c = 0;
+  if (tid < n) {
+    a = x[0];
+    b = x[1];
+    c = x[2];
+  }
+  for (int i = tid + 256; i < n; i += 256) {
+    a += part[(size_t)i * 4 + 0];
+    b += part[(size_t)i * 4 + 1];
+    c += part[(size_t)i * 4 + 2];
+  }
+  a = ldsum(a);
+  b = ldsum(b);
+  c = ldsum(c);
+  if ((tid & 63) == 0) {
+    sh[(tid >> 6) * 3 + 0] = a;
+    sh[(tid >> 6) * 3 + 1] = b;
+    sh[(tid >> 6) * 3 + 2] = c;
+  }
+  __syncthreads();
+  out[0] = ((sh[0] + sh[3]) + sh[6]) + sh[9];
+  out[1] = ((sh[1] + sh[4]) + sh[7]) + sh[10];
+  out[2] = ((sh[2] + sh[5]) + sh[8]) + sh[11];
 }
 
 // The per-antenna reduction shared by gain_grad_kernel and step_tail_kernel (ONE body: the two launch forms of a step must
@@ -938,29 +1211,18 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
   const int nb_main = nants * cblocks;
   if ((int)blockIdx.x >= nb_main) {
     // last block: deterministic sum of the per-item loss partials -> scal[0..2]
-    __shared__ double sh[3][256];
-    double a = 0, b = 0, c = 0;
-    for (int i = threadIdx.x; i < nitems; i += 256) {
-      a += part[(size_t)i * 4 + 0];
-      b += part[(size_t)i * 4 + 1];
-      c += part[(size_t)i * 4 + 2];
+    __shared__ double sh[12];
+    double x[3] = {0, 0, 0}, tot[3];
+    if ((int)threadIdx.x < nitems) {
+      x[0] = part[(size_t)threadIdx.x * 4 + 0];
+      x[1] = part[(size_t)threadIdx.x * 4 + 1];
+      x[2] = part[(size_t)threadIdx.x * 4 + 2];
     }
-    sh[0][threadIdx.x] = a;
-    sh[1][threadIdx.x] = b;
-    sh[2][threadIdx.x] = c;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) {
-        sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
-        sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
-        sh[2][threadIdx.x] += sh[2][threadIdx.x + s];
-      }
-      __syncthreads();
-    }
+    sum_partials(part, nitems, x, sh, tot);
     if (threadIdx.x == 0) {
-      scal[0] = sh[0][0];
-      scal[1] = sh[1][0];
-      scal[2] = sh[2][0];
+      scal[0] = tot[0];
+      scal[1] = tot[1];
+      scal[2] = tot[2];
     }
     return;
   }
@@ -1308,38 +1570,49 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
   using T2 = vec2_t<T>;
   constexpr int CPL = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;
   typedef T vec_t __attribute__((ext_vector_type(2 * CPL)));
-  __shared__ double sh[3][256];
+  __shared__ double sh[12];
   __shared__ double sh_ar, sh_ai;
   __shared__ StepCoef<T> sh_c;
   __shared__ int sh_update, sh_improved;
   __shared__ T s_part[3][3][64][2 * CPL];
   const int tid = threadIdx.x;
-  // ---- loss partial sums: the reduction of gain_grad_kernel's last block, in every block
-  {
-    double a = 0, b = 0, c = 0;
-    for (int i = tid; i < A.nparts; i += 256) {
-      a += A.part[(size_t)i * 4 + 0];
-      b += A.part[(size_t)i * 4 + 1];
-      c += A.part[(size_t)i * 4 + 2];
-    }
-    sh[0][tid] = a;
-    sh[1][tid] = b;
-    sh[2][tid] = c;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if (tid < st) {
-        sh[0][tid] += sh[0][tid + st];
-        sh[1][tid] += sh[1][tid + st];
-        sh[2][tid] += sh[2][tid + st];
-      }
-      __syncthreads();
-    }
+  // A step of such a problem is a chain of dependent memory round trips, about a microsecond each, so everything that does
+  // not depend on the step's decisions is requested first and the chains run side by side: the loss partials and the loop
+  // state (-> decisions), and, in a gain block, antenna list -> gbar_G rows and gains (-> gradient) and the block's own gains
+  // and optimizer slots.  The decisions only gate the final writes.
+  double x[3] = {0, 0, 0};
+  if (tid < A.nparts) {
+    x[0] = A.part[(size_t)tid * 4 + 0];
+    x[1] = A.part[(size_t)tid * 4 + 1];
+    x[2] = A.part[(size_t)tid * 4 + 2];
   }
+  DevState s;
+  if (tid == 0) s = *A.in;
+  const bool gain_block = (int)blockIdx.x < A.nblk_gain;
+  // ---- gain block: gain_grad_kernel's reduction (antenna_sums) for (antenna a, 64 CPL channels)
+  const int cb = gain_block ? blockIdx.x / A.nants : 0;
+  const int a = gain_block ? blockIdx.x - cb * A.nants : 0;
+  const int lane = tid & 63, seg = tid >> 6;
+  const int f = (cb * 64 + lane) * CPL;
+  const long long idx = (long long)a * A.fpad + f;
+  T s0[2 * CPL], s1[2 * CPL], s2[2 * CPL];
+  vec_t pin, mm, vv;
+  bool mine = false;
+  if (gain_block) {
+    if (seg == 0 && f < A.fpad) {
+      pin = *reinterpret_cast<const vec_t*>(A.gains_in + idx);
+      mm = *reinterpret_cast<const vec_t*>(A.gains_m + 2 * idx);
+      vv = *reinterpret_cast<const vec_t*>(A.gains_v + 2 * idx);
+    }
+    mine = antenna_sums<T, REG>(A.q0, A.q1, A.gains_in, A.ant_ptr, A.ant_ent, a, f, A.fpad, s_part, s0, s1, s2);
+  }
+  // ---- loss partial sums (sum_partials: the order of gain_grad_kernel's last block), in every block
+  double tot[3];
+  sum_partials(A.part, A.nparts, x, sh, tot);
   // ---- the step's decisions (advance_state): thread 0 of every block, block 0 records them
   if (tid == 0) {
-    DevState s = *A.in;
     const bool writer = blockIdx.x == 0;
-    const bool upd = advance_state(s, sh[0][0], sh[1][0], sh[2][0], writer, A.losses, A.losses_cap, true);
+    const bool upd = advance_state(s, tot[0], tot[1], tot[2], writer, A.losses, A.losses_cap, true);
     if (writer) *A.out = s;
     sh_update = upd ? 1 : 0;
     sh_improved = s.improved;
@@ -1352,38 +1625,28 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
   const StepCoef<T> sc = sh_c;
   const T ar = (T)sh_ar, ai = (T)sh_ai;
   const bool improved = sh_improved != 0;
-  if ((int)blockIdx.x < A.nblk_gain) {
-    // ---- gain block: gain_grad_kernel's reduction, then the update of these gains.  A step that does not update (loop
-    // ended, non-finite loss) still copies its gains to the other buffer: the host swaps the buffers after every step
-    const int cb = blockIdx.x / A.nants;
-    const int a = blockIdx.x - cb * A.nants;
-    const int lane = tid & 63, seg = tid >> 6;
-    const int f = (cb * 64 + lane) * CPL;
-    const bool ok = f < A.fpad;
-    const long long idx = (long long)a * A.fpad + f;
-    if (!update) {
-      if (seg == 0 && ok) *reinterpret_cast<vec_t*>(A.gains_out + idx) = *reinterpret_cast<const vec_t*>(A.gains_in + idx);
-      return;
-    }
-    T s0[2 * CPL], s1[2 * CPL], s2[2 * CPL];
-    if (antenna_sums<T, REG>(A.q0, A.q1, A.gains_in, A.ant_ptr, A.ant_ent, a, f, A.fpad, s_part, s0, s1, s2)) {
-      if (REG) {
+  if (gain_block) {
+    // the update of exactly these gains.  A step that does not update (loop ended, non-finite loss) still copies them to the
+    // other buffer: the host swaps the buffers after every step
+    if (mine) {
+      vec_t pout = pin;
+      if (update) {
+        if (REG) {
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) fold_gain(s0[2 * c], s0[2 * c + 1], s1[2 * c], s1[2 * c + 1], s2[2 * c], s2[2 * c + 1], ar, ai);
-      }
-      const vec_t pin = *reinterpret_cast<const vec_t*>(A.gains_in + idx);
-      vec_t mm = *reinterpret_cast<const vec_t*>(A.gains_m + 2 * idx), vv = *reinterpret_cast<const vec_t*>(A.gains_v + 2 * idx), pout;
+          for (int c = 0; c < CPL; ++c) fold_gain(s0[2 * c], s0[2 * c + 1], s1[2 * c], s1[2 * c + 1], s2[2 * c], s2[2 * c + 1], ar, ai);
+        }
 #pragma unroll
-      for (int c = 0; c < 2 * CPL; ++c) {
-        T mi = mm[c], vi = vv[c];
-        pout[c] = optimizer_step<T>(pin[c], s0[c], mi, vi, sc);
-        mm[c] = mi;
-        vv[c] = vi;
+        for (int c = 0; c < 2 * CPL; ++c) {
+          T mi = mm[c], vi = vv[c];
+          pout[c] = optimizer_step<T>(pin[c], s0[c], mi, vi, sc);
+          mm[c] = mi;
+          vv[c] = vi;
+        }
+        *reinterpret_cast<vec_t*>(A.gains_m + 2 * idx) = mm;
+        *reinterpret_cast<vec_t*>(A.gains_v + 2 * idx) = vv;
+        if (improved) *reinterpret_cast<vec_t*>(A.gains_snap + 2 * idx) = pout;
       }
-      *reinterpret_cast<vec_t*>(A.gains_m + 2 * idx) = mm;
-      *reinterpret_cast<vec_t*>(A.gains_v + 2 * idx) = vv;
       *reinterpret_cast<vec_t*>(A.gains_out + idx) = pout;
-      if (improved) *reinterpret_cast<vec_t*>(A.gains_snap + 2 * idx) = pout;
     }
     return;
   }

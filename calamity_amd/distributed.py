@@ -78,7 +78,15 @@ def batch_time_slices(parts):
     ``parts``: list of (FitProblem, start) with identical nants / nfreqs.  Returns (FitProblem, start)."""
     nants, nfreqs = parts[0][0].nants, parts[0][0].nfreqs
     basis, key = [], {}
-    grp_basis, grp_bl_start, a0, a1, rb = [], [0], [], [], []
+    grp_basis, grp_bl_start, a0, a1, rb, alias = [], [0], [], [], [], []
+    # slices that hold the same baselines in the same order (the sharded multi-time job: every slice is the same share of the
+    # array) share basis tiles: baseline b of slice t > 0 reads the tiles of baseline b of slice 0 (cal_problem_desc::bl_alias)
+    same_bls = all(
+        p.nbls == parts[0][0].nbls and np.array_equal(p.bl_ant0, parts[0][0].bl_ant0) and np.array_equal(p.bl_ant1, parts[0][0].bl_ant1)
+        and np.array_equal(p.bl_rowblk, parts[0][0].bl_rowblk) and np.all(np.diff(p.grp_bl_start) == 1)
+        and all(a is b for a, b in zip([p.basis[u] for u in p.grp_basis], [parts[0][0].basis[u] for u in parts[0][0].grp_basis]))
+        for p, _ in parts
+    )
     for t, (p, s) in enumerate(parts):
         assert p.nants == nants and p.nfreqs == nfreqs
         for u, blk in enumerate(p.basis):
@@ -90,6 +98,7 @@ def batch_time_slices(parts):
         a0.append(p.bl_ant0 + t * nants)
         a1.append(p.bl_ant1 + t * nants)
         rb.append(p.bl_rowblk)
+        alias.append(np.full(p.nbls, -1, dtype=np.int32) if t == 0 else np.arange(p.nbls, dtype=np.int32))
     cat = lambda name: np.concatenate([getattr(p, name) for p, _ in parts])  # noqa: E731
     has_sky = parts[0][0].sky_r is not None
     out = FitProblem(
@@ -106,6 +115,7 @@ def batch_time_slices(parts):
         wgts=cat("wgts"),
         sky_r=cat("sky_r") if has_sky else None,
         sky_i=cat("sky_i") if has_sky else None,
+        bl_alias=np.concatenate(alias) if same_bls and len(parts) > 1 else None,
     )
     start = dict(
         g_r=np.concatenate([s["g_r"] for _, s in parts]),

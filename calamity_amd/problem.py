@@ -34,6 +34,9 @@ class FitProblem:
     chunk_of_grp: Optional[np.ndarray] = None
     pos_in_chunk: Optional[np.ndarray] = None
     chunk_shapes: List[tuple] = field(default_factory=list)  # (nvecs, ngrps, nbls) per chunk
+    # (nbls,) int32 or None: baseline b reads the basis tiles of baseline bl_alias[b] (-1: its own) -- the same physical
+    # baseline in several time slices fitted by one solver (distributed.batch_time_slices); cal_problem_desc::bl_alias
+    bl_alias: Optional[np.ndarray] = None
 
     @property
     def ngrps(self):

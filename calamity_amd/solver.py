@@ -78,12 +78,13 @@ class HipFitSolver:
             np.ascontiguousarray(prob.bl_ant0, dtype=np.int32),
             np.ascontiguousarray(prob.bl_ant1, dtype=np.int32),
             np.ascontiguousarray(prob.bl_rowblk, dtype=np.int32),
+            None if getattr(prob, "bl_alias", None) is None else np.ascontiguousarray(prob.bl_alias, dtype=np.int32),
         ]
         d = _lib.ProblemDesc(
             nants=prob.nants, nfreqs=prob.nfreqs, ngrps=prob.ngrps, nbls=prob.nbls, nbasis=len(basis),
             basis_offset=_ptr(offs), basis_nvec=_ptr(nvec), basis_nrowblk=_ptr(nrb), basis_data=_ptr(flat),
             grp_basis=_ptr(keep[4]), grp_bl_start=_ptr(keep[5]), bl_ant0=_ptr(keep[6]), bl_ant1=_ptr(keep[7]),
-            bl_rowblk=_ptr(keep[8]),
+            bl_rowblk=_ptr(keep[8]), bl_alias=_ptr(keep[9]),
             layout={"stream": _lib.CAL_LAYOUT_STREAM, "shared": _lib.CAL_LAYOUT_SHARED}[layout],
             kernel_path={"auto": _lib.CAL_PATH_AUTO, "general": _lib.CAL_PATH_GENERAL, "dense": _lib.CAL_PATH_DENSE}[kernel_path],
         )

@@ -93,6 +93,11 @@ typedef struct cal_problem_desc {
   const int32_t* bl_rowblk;      /* [nbls] */
   int32_t layout;                /* cal_layout */
   int32_t kernel_path;           /* cal_kernel_path; with a communicator attached the ranks agree on one path */
+  const int32_t* bl_alias;       /* [nbls] or NULL.  STREAM layout: baseline b reads the basis tiles of baseline bl_alias[b] (which
+                                    owns its tiles: bl_alias of it is -1 or itself) instead of holding a copy -- the same physical
+                                    baseline in the time slices one solver fits together (calibration.py:1160-1167 fits them one after
+                                    another).  Both must be single-baseline groups on the same basis rows.  Such baselines are
+                                    processed together: their tiles are read ONCE per pass for all of them. */
 } cal_problem_desc;
 
 typedef struct cal_optimizer_desc { /* **opt_kwargs -> tf.optimizers.X(...), calibration.py:571; semantics: Keras OptimizerV2

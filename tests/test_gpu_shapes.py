@@ -133,3 +133,50 @@ def test_model_and_init_on_multi_baseline_groups(dtype):
                 got = c_r[coff[g]:coff[g + 1]] + 1j * c_i[coff[g]:coff[g + 1]]
                 assert np.linalg.norm(got - acc) <= tol * np.linalg.norm(acc)
             s.close()
+
+
+@pytest.mark.parametrize("nslices", [3, 10])
+def test_time_slices_that_share_tiles(nslices):
+    """cal_problem_desc::bl_alias: the same baselines in several time slices fitted by one solver read ONE copy of their basis
+    tiles, and fused_multi_kernel processes a baseline's slices together (SURVEY.md section 8e "Multiple times";
+    calibration.py:1160-1167 loops over times).  Every tile width, sets larger than a multi item holds (10 slices: 8 + 2 in
+    float32, 4 + 4 + 2 in float64), loss / gradients against the C restatement of the batched problem, the regularised form
+    (which runs the baselines one by one), model evaluation and initial coefficients, and a short trajectory against the one
+    of the same problem WITHOUT the alias table (every baseline streaming its own copy; the loss partials are summed in another
+    order, so equal to rounding, not to the bit)."""
+    from calamity_amd import distributed as D
+    from calamity_amd.solver import HipFitSolver
+
+    nvecs = [5, 56, 57, 112, 113, 224, 230]  # FB 128 | 64 | 32 | 16 in float32
+    base, _ = random_problem(nvecs, [1] * len(nvecs), nants=8, nfreqs=200, seed=40)
+    parts = []
+    for t in range(nslices):
+        p, st = random_problem(nvecs, [1] * len(nvecs), nants=8, nfreqs=200, seed=41 + t)
+        p.basis, p.grp_basis = base.basis, base.grp_basis          # the same blocks ...
+        p.bl_ant0, p.bl_ant1, p.bl_rowblk = base.bl_ant0, base.bl_ant1, base.bl_rowblk  # ... and baselines in every slice
+        p.wgts = p.wgts / nslices
+        parts.append((p, st))
+    prob, start = D.batch_time_slices(parts)
+    assert prob.bl_alias is not None and np.all(prob.bl_alias[: base.nbls] == -1) and np.all(prob.bl_alias[base.nbls :] >= 0)
+    prob.sky_r, prob.sky_i = np.concatenate([p.sky_r for p, _ in parts]), np.concatenate([p.sky_i for p, _ in parts])
+    check(prob, start, layouts=("stream",))
+    plain = D.batch_time_slices(parts)[0]
+    plain.bl_alias = None
+    for dtype in (np.float64, np.float32):
+        outs = []
+        for pr in (prob, plain):
+            s = HipFitSolver(dtype=dtype)
+            s.set_problem(pr, layout="stream")
+            mem = s.memory_bytes()
+            s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+            s.set_optimizer("Adam", learning_rate=1e-2)
+            losses, _, _ = s.run(7, record=True, tol=0.0)
+            model = s.model()
+            s.init_coeffs(pr.data_r, pr.data_i)
+            outs.append((losses, s.get_params(), model, mem))
+            s.close()
+        tol = 1e-11 if dtype == np.float64 else 2e-5
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=tol)
+        for x, y in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+            assert np.linalg.norm(np.asarray(x, np.float64) - y) <= 10 * tol * np.linalg.norm(y)
+        assert outs[0][3] < outs[1][3]  # one tile copy per baseline instead of one per (slice, baseline)
