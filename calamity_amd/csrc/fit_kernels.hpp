@@ -187,6 +187,61 @@ __device__ __forceinline__ void fma_cols(double2& acc, const double __attribute_
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// x + (x of lane ^ SFT) without the LDS crossbar: ds_bpermute, which __shfl_xor compiles to, occupies the CU's LDS pipe,
+// and the forward product of every tile ends in such a reduction over the lanes that hold the other rows (2116 ds_bpermute
+// in the multi-slice kernel).  gfx950 swaps lane halves / rows of 16 in the vector ALU (v_permlane32_swap, v_permlane16_swap:
+// with both operands x, result 0 carries the lower partner's x and result 1 the upper partner's on BOTH lanes); a rotation by
+// 8 inside a row of 16 is a DPP modifier.  Smaller strides (tiles of 16 or 8 channels: blocks of more than 224 vectors) keep
+// the shuffle.  Same pairs, same single addition: the sums are bit for bit those of the shuffle form.
+__device__ __forceinline__ float pair_sum32(float x) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  const unsigned a = r[0], b = r[1];
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float pair_sum16(float x) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  const unsigned a = r[0], b = r[1];
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float pair_sum8(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, true);  // row_ror:8
+  return x + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ double pair_sum32(double x) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const unsigned long long v = __builtin_bit_cast(unsigned long long, x);
+  const u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  const u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)(v >> 32), (unsigned)(v >> 32), false, false);
+  const unsigned l0 = lo[0], l1 = lo[1], h0 = hi[0], h1 = hi[1];
+  return __builtin_bit_cast(double, ((unsigned long long)h0 << 32) | l0) + __builtin_bit_cast(double, ((unsigned long long)h1 << 32) | l1);
+}
+__device__ __forceinline__ double pair_sum16(double x) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const unsigned long long v = __builtin_bit_cast(unsigned long long, x);
+  const u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  const u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)(v >> 32), (unsigned)(v >> 32), false, false);
+  const unsigned l0 = lo[0], l1 = lo[1], h0 = hi[0], h1 = hi[1];
+  return __builtin_bit_cast(double, ((unsigned long long)h0 << 32) | l0) + __builtin_bit_cast(double, ((unsigned long long)h1 << 32) | l1);
+}
+__device__ __forceinline__ double pair_sum8(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x128, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x128, 0xf, 0xf, true);
+  return x + __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// sum over the 64 / LPR lanes {lane ^ k LPR}: the rows of a tile held by the other lanes of the wave (ascending strides)
+template <int LPR, typename T> __device__ __forceinline__ T sum_row_lanes(T x) {
+  if constexpr (LPR <= 1) x += __shfl_xor(x, 1, 64);
+  if constexpr (LPR <= 2) x += __shfl_xor(x, 2, 64);
+  if constexpr (LPR <= 4) x += __shfl_xor(x, 4, 64);
+  if constexpr (LPR <= 8) x = pair_sum8(x);
+  if constexpr (LPR <= 16) x = pair_sum16(x);
+  if constexpr (LPR <= 32) x = pair_sum32(x);
+  return x;
+}
+
 template <typename T> __device__ __forceinline__ T ldsum(T v) {
   // full-wave butterfly sum
 #pragma unroll
@@ -335,12 +390,9 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
       }
       // rows held by the other lanes of this wave
 #pragma unroll
-      for (int sft = LPR; sft < 64; sft <<= 1) {
-#pragma unroll
-        for (int u = 0; u < VEC; ++u) {
-          pv[u].x += __shfl_xor(pv[u].x, sft, 64);
-          pv[u].y += __shfl_xor(pv[u].y, sft, 64);
-        }
+      for (int u = 0; u < VEC; ++u) {
+        pv[u].x = sum_row_lanes<LPR>(pv[u].x);
+        pv[u].y = sum_row_lanes<LPR>(pv[u].y);
       }
       if (lane < LPR) {
 #pragma unroll
@@ -589,12 +641,9 @@ __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const 
 #pragma unroll
         for (int l = 0; l < L; ++l) fma_rows(pv, stage[l], s_c[m * C::MAXK + l * NS + ks]);
 #pragma unroll
-        for (int sft = LPR; sft < 64; sft <<= 1) {
-#pragma unroll
-          for (int u = 0; u < VEC; ++u) {
-            pv[u].x += __shfl_xor(pv[u].x, sft, 64);
-            pv[u].y += __shfl_xor(pv[u].y, sft, 64);
-          }
+        for (int u = 0; u < VEC; ++u) {
+          pv[u].x = sum_row_lanes<LPR>(pv[u].x);
+          pv[u].y = sum_row_lanes<LPR>(pv[u].y);
         }
         if (lane < LPR) {
 #pragma unroll
@@ -824,12 +873,9 @@ __device__ __forceinline__ void process_group_item(const FusedArgs<T>& A, const 
 #pragma unroll
       for (int l = 0; l < L; ++l) fma_rows(pv, stage[l], s_c[l * NS + ks]);
 #pragma unroll
-      for (int sft = LPR; sft < 64; sft <<= 1) {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          pv[k].x += __shfl_xor(pv[k].x, sft, 64);
-          pv[k].y += __shfl_xor(pv[k].y, sft, 64);
-        }
+      for (int k = 0; k < VEC; ++k) {
+        pv[k].x = sum_row_lanes<LPR>(pv[k].x);
+        pv[k].y = sum_row_lanes<LPR>(pv[k].y);
       }
       if (lane < LPR) {
 #pragma unroll
