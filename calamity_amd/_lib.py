@@ -78,7 +78,7 @@ class KernelTiming(C.Structure):
         ("basis_bytes_per_launch", C.c_double),
         ("flops_per_launch", C.c_double),
         ("kernel_path", C.c_int32),
-        ("reserved", C.c_int32),
+        ("dense_wg_per_cu", C.c_int32),
     ]
 
 

@@ -7,6 +7,7 @@ import copy
 import numpy as np
 
 from . import uvcompat
+from .utils import for_row_chunks
 
 
 def _new_uvcal(uvdata):
@@ -71,15 +72,28 @@ def apply_gains(uvdata, gains, inverse=False):
     tind = np.asarray([np.where(np.isclose(gtimes, t, rtol=0.0, atol=1e-7))[0][0] for t in np.unique(calibrated.time_array)])
     tmap = dict(zip(np.unique(calibrated.time_array).tolist(), tind.tolist()))
     gt = np.asarray([tmap[t] for t in calibrated.time_array.tolist()])
+    data, flags = uvcompat.vis3(calibrated.data_array), uvcompat.vis3(calibrated.flag_array)
+    garr, gflags = uvcompat.gain4(gains.gain_array), uvcompat.gain4(gains.flag_array)
     for pnum, pol in enumerate(uvdata.get_pols()):
         gindp = np.where(np.asarray(gains.jones_array) == uvcompat.polstr2num(pol, x_orientation=gains.x_orientation))[0][0]
-        g0 = uvcompat.gain4(gains.gain_array)[a0, :, gt, gindp]  # (Nblts, Nfreqs)
-        g1 = uvcompat.gain4(gains.gain_array)[a1, :, gt, gindp]
-        gg = g0 * np.conj(g1)
-        data, flags, gflags = uvcompat.vis3(calibrated.data_array), uvcompat.vis3(calibrated.flag_array), uvcompat.gain4(gains.flag_array)
-        if not inverse:
-            data[:, :, pnum] = data[:, :, pnum] / gg
-        else:
-            data[:, :, pnum] = data[:, :, pnum] * gg
-        flags[:, :, pnum] = flags[:, :, pnum] | (gflags[a0, :, gt, gindp] | gflags[a1, :, gt, gindp])
+
+        for t in np.unique(gt):
+            # one (Nants, Nfreqs) gain plane per time: row gathers from a contiguous plane are an order of magnitude faster than
+            # indexing the 4-D gain array with two index arrays and a slice between them
+            gplane = np.ascontiguousarray(garr[:, :, t, gindp])
+            fplane = np.ascontiguousarray(gflags[:, :, t, gindp])
+            sel = np.where(gt == t)[0]
+            contiguous = len(sel) == sel[-1] - sel[0] + 1
+
+            def rows(lo, hi, pnum=pnum, sel=sel, gplane=gplane, fplane=fplane, contiguous=contiguous):
+                r = slice(sel[0] + lo, sel[0] + hi) if contiguous else sel[lo:hi]
+                gg = np.take(gplane, a0[r], axis=0)  # (np.take: fancy indexing of complex rows is 20x slower in NumPy 2.2)
+                gg *= np.conj(np.take(gplane, a1[r], axis=0))
+                if not inverse:
+                    data[r, :, pnum] /= gg
+                else:
+                    data[r, :, pnum] *= gg
+                flags[r, :, pnum] |= np.take(fplane, a0[r], axis=0) | np.take(fplane, a1[r], axis=0)
+
+            for_row_chunks(rows, len(sel))
     return calibrated

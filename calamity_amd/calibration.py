@@ -29,7 +29,7 @@ from . import cal_utils, modeling, utils
 from .problem import FitProblem, coeffs_from_chunks, coeffs_to_chunks, problem_from_chunks
 from .solver import OPTIMIZERS, HipFitSolver
 from .utils import PBARS, echo
-from .uvcompat import freqs_1d, gain4, is_uvcal, is_uvdata, polstr2num, vis3
+from .uvcompat import gain4, is_uvcal, is_uvdata, polstr2num, vis3
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -188,22 +188,45 @@ def tensorize_data(
         any_conj = bool(conj.any())
         if any_conj and len(pind_conj) == 0:
             raise KeyError(f"polarization {polarization}: the conjugate product is not in the data")
-        pcol = np.where(conj, int(pind_conj[0]) if len(pind_conj) else pind, pind)
-        data = vis3(np.asarray(uvdata.data_array))[rows, :, pcol] / data_scale_factor
-        iflags = ~vis3(np.asarray(uvdata.flag_array))[rows, :, pcol]
-        if any_conj:
-            data = np.where(conj[:, None], np.conj(data), data)
-        if weights is None:
-            w = iflags.astype(dtype)
-        else:
-            w = vis3(np.asarray(weights.weights_array))[wrows, :, wpol].astype(dtype) * iflags
-        if nsamples_in_weights:
-            w = w * vis3(np.asarray(uvdata.nsample_array))[rows, :, pcol]
-        w = np.ascontiguousarray(w, dtype=dtype).reshape(ngrps, nbls, uvdata.Nfreqs)
-        wgtsum += float(np.sum(w, dtype=np.float64))
-        data_r.append(np.ascontiguousarray(data.real, dtype=dtype).reshape(ngrps, nbls, uvdata.Nfreqs))
-        data_i.append(np.ascontiguousarray(data.imag, dtype=dtype).reshape(ngrps, nbls, uvdata.Nfreqs))
-        wgts.append(w)
+        nf = uvdata.Nfreqs
+        d_r = np.empty((ngrps * nbls, nf), dtype=dtype)
+        d_i = np.empty((ngrps * nbls, nf), dtype=dtype)
+        w = np.empty((ngrps * nbls, nf), dtype=dtype)
+        vis, flg = vis3(np.asarray(uvdata.data_array)), vis3(np.asarray(uvdata.flag_array))
+        nsm = vis3(np.asarray(uvdata.nsample_array)) if nsamples_in_weights else None
+        wts = vis3(np.asarray(weights.weights_array)) if weights is not None else None
+        sums = []
+
+        def rows_chunk(lo, hi):
+            # gather + scale + split of a run of baselines (memory-bound NumPy passes: one thread per run, utils.for_row_chunks)
+            r, cj = rows[lo:hi], conj[lo:hi]
+            # (row gathers with np.take from the polarization's plane: NumPy's fancy indexing with two index arrays around a
+            # slice is an order of magnitude slower on complex data)
+            data = np.take(vis[:, :, pind], r, axis=0)
+            keep = ~np.take(flg[:, :, pind], r, axis=0)
+            ns = np.take(nsm[:, :, pind], r, axis=0) if nsm is not None else None
+            if any_conj and cj.any():  # pairs held in the reversed order: the conjugate product's column, conjugated
+                pc = int(pind_conj[0])
+                data[cj] = np.take(vis[:, :, pc], r[cj], axis=0)
+                keep[cj] = ~np.take(flg[:, :, pc], r[cj], axis=0)
+                if ns is not None:
+                    ns[cj] = np.take(nsm[:, :, pc], r[cj], axis=0)
+            data /= data_scale_factor
+            d_r[lo:hi] = data.real
+            d_i[lo:hi] = data.imag
+            if any_conj:
+                d_i[lo:hi][cj] *= -1
+            ww = keep.astype(dtype) if wts is None else np.take(wts[:, :, wpol], wrows[lo:hi], axis=0).astype(dtype) * keep
+            if ns is not None:
+                ww = ww * ns
+            w[lo:hi] = ww
+            sums.append(float(np.sum(w[lo:hi], dtype=np.float64)))
+
+        utils.for_row_chunks(rows_chunk, ngrps * nbls)
+        wgtsum += float(np.sum(sums))
+        data_r.append(d_r.reshape(ngrps, nbls, nf))
+        data_i.append(d_i.reshape(ngrps, nbls, nf))
+        wgts.append(w.reshape(ngrps, nbls, nf))
     wgts = [(w / wgtsum).astype(dtype) for w in wgts]
     return data_r, data_i, wgts
 
@@ -531,11 +554,12 @@ def calibrate_and_model_tensor(
     antpairs_data = uvdata.get_antpairs()
     if not include_autos:
         antpairs_data = set([ap for ap in antpairs_data if ap[0] != ap[1]])
-    uvdata = uvdata.select(inplace=False, bls=[ap for ap in antpairs_data])
+    if len(antpairs_data) != len(uvdata.get_antpairs()):
+        uvdata = uvdata.select(inplace=False, bls=[ap for ap in antpairs_data])
+    # (with nothing to drop the input object itself is used: it is only read from here on, and the reference's
+    # select(inplace=False) copy of a gigabyte of visibilities bought nothing but that guarantee)
     resid = copy.deepcopy(uvdata)
-    model = copy.deepcopy(uvdata)
-    model.data_array[:] = 0.0
-    model.flag_array[:] = False
+    model = _blank_copy(uvdata)
     red_grps = []
     for fit_grp in fg_model_comps_dict.keys():
         for red_grp in fit_grp:
@@ -673,6 +697,20 @@ def calibrate_and_model_tensor(
     if correct_resid:
         resid = cal_utils.apply_gains(resid, gains)
     return model, resid, gains, fit_history
+
+
+def _blank_copy(uvdata):
+    """A copy of ``uvdata`` with all-zero visibilities and no flags (the reference deep-copies, then clears, :1113-1116),
+    without copying the arrays that are about to be overwritten."""
+    data, flags = uvdata.data_array, uvdata.flag_array
+    try:
+        uvdata.data_array = uvdata.flag_array = None
+        out = copy.deepcopy(uvdata)
+    finally:
+        uvdata.data_array, uvdata.flag_array = data, flags
+    out.data_array = np.zeros_like(data)
+    out.flag_array = np.zeros_like(flags)
+    return out
 
 
 def _insert_model_rows(uvdata, time, polarization, ants_map, prob, m_r, m_i, scale_factor):

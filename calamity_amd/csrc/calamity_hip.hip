@@ -1567,9 +1567,13 @@ struct SolverT final : cal_solver {
     out->basis_bytes_per_launch = basis_bytes;
     out->algorithmic_bytes_per_launch =
         basis_bytes + s * (3.0 * nfreqs * nbls + 2.0 * ncoef + 2.0 * nants * nfreqs) + s * (10.0 * ncoef + 10.0 * nants * nfreqs);
-    out->flops_per_launch = 8.0 * nfreqs * (double)ncoef;
+    // forward A c and adjoint A^T gbar_v, complex x real: 4 + 4 flops per (channel, vector); the dense path's regularised step
+    // runs the forward twice (loss-only pass for S, then the gradient pass) inside the timed region
+    out->flops_per_launch = ((mf_ok && reg == CAL_REG_SUM) ? 12.0 : 8.0) * nfreqs * (double)ncoef;
     out->kernel_path = mf_ok ? CAL_PATH_DENSE : CAL_PATH_GENERAL;
-    out->reserved = 0;
+    // the dense kernels are written for two workgroups per CU (160 KB of LDS): a basis block of ~250 vectors needs more than
+    // 80 KB for its coefficient panel + rings and runs one
+    out->dense_wg_per_cu = mf_ok ? (mf_lds_grad[0] * 2 <= 160 * 1024 ? 2 : 1) : 0;
     return CAL_OK;
   }
   int memory_bytes(int64_t* b) override {

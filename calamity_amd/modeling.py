@@ -13,7 +13,7 @@ import numpy as np
 from scipy.signal import windows
 
 from . import simple_cov
-from .utils import PBARS, echo
+from .utils import PBARS, echo, usable_cores
 
 
 def _lapack_dstemr():
@@ -232,7 +232,7 @@ def yield_pbl_dpss_model_comps(
         # a private operator cache per task: the shared dict is only written from this thread, below
         return _dpss_block(dly, freqs, eigenval_cutoff, {})
 
-    workers = max(1, min(len(distinct), _usable_cores()))
+    workers = max(1, min(len(distinct), usable_cores()))
     if workers > 1:
         with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
             blocks = list(PBARS[notebook_progressbar](pool.map(block_of, distinct), total=len(distinct), disable=not verbose))
@@ -240,22 +240,6 @@ def yield_pbl_dpss_model_comps(
         blocks = [block_of(d) for d in PBARS[notebook_progressbar](distinct, disable=not verbose)]
     cache.update(zip(distinct, blocks))
     return {(tuple(grp),): cache[dly] for grp, dly in zip(red_grps, delays)}
-
-
-def _usable_cores():
-    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box hands a one-GPU job
-    16 of the host's 256 cores)."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(round(float(quota) / float(period)))))
-    except (OSError, ValueError):
-        pass
-    return n
 
 
 def _freqs_of(uvdata):

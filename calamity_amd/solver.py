@@ -193,7 +193,8 @@ class HipFitSolver:
         _lib.check(self._lib.cal_solver_timing_get(self._h, C.byref(t)))
         return dict(launches=t.launches, total_ms=t.total_ms, algorithmic_bytes_per_launch=t.algorithmic_bytes_per_launch,
                     basis_bytes_per_launch=t.basis_bytes_per_launch, flops_per_launch=t.flops_per_launch,
-                    kernel_path={_lib.CAL_PATH_GENERAL: "general", _lib.CAL_PATH_DENSE: "dense"}[t.kernel_path])
+                    kernel_path={_lib.CAL_PATH_GENERAL: "general", _lib.CAL_PATH_DENSE: "dense"}[t.kernel_path],
+                    dense_wg_per_cu=t.dense_wg_per_cu)
 
     def memory_bytes(self):
         n = C.c_int64(0)

@@ -100,6 +100,18 @@ class SimpleUVData:
         self.nsample_array = np.ones(shape, dtype=np.float64) if nsamples is None else np.asarray(nsamples, dtype=np.float64).reshape(shape)
         self._refresh()
 
+    def __deepcopy__(self, memo):
+        """Arrays are copied; the (antenna pair -> rows) index is shared: its arrays are never written, and copying 61 075 of
+        them one by one cost more than copying the gigabyte of visibilities."""
+        out = copy.copy(self)
+        for k, v in self.__dict__.items():
+            if isinstance(v, np.ndarray):
+                out.__dict__[k] = v.copy()
+            elif isinstance(v, (list, tuple)):
+                out.__dict__[k] = copy.copy(v)
+        out._ap_index = dict(self._ap_index)
+        return out
+
     def _refresh(self):
         self.baseline_array = np.asarray([antnums_to_baseline(a, b) for a, b in zip(self.ant_1_array, self.ant_2_array)])
         self.Nants_data = len(set(self.ant_1_array).union(set(self.ant_2_array)))

@@ -135,9 +135,10 @@ typedef struct cal_kernel_timing { /* HIP-event timing of the dominant kernel of
   double total_ms;
   double algorithmic_bytes_per_launch; /* SURVEY.md 8(d) B_step figure restated for this problem */
   double basis_bytes_per_launch;
-  double flops_per_launch;             /* 8 F sum nvec: forward A c and adjoint A^T gbar_v, complex x real */
+  double flops_per_launch;             /* 8 F sum nvec: forward A c and adjoint A^T gbar_v, complex x real (12: the dense path's
+                                          regularised step times its loss-only pass too) */
   int32_t kernel_path;                 /* CAL_PATH_GENERAL or CAL_PATH_DENSE: the family the timed launches belong to */
-  int32_t reserved;
+  int32_t dense_wg_per_cu;             /* dense path: workgroups per CU its LDS footprint allows (2 is what the kernels are tuned for) */
 } cal_kernel_timing;
 
 const char* cal_last_error(void);

@@ -5,7 +5,7 @@
 # the CPU baseline, the extras, and the other BASELINE configurations.  Everything under gpurun_out/<tag>/.
 set -e
 tag=${1:-bench}
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 out=gpurun_out/$tag
 mkdir -p $out
 python3 bench.py --steps 20 --warmup 3 > $out/bench.log 2>&1

@@ -2,7 +2,7 @@
 # usage (here, after the gpurun call of tools/prof_round.sh + tools/prof_dense.sh has been merged back): bash tools/collect_profiles.sh <rNN>
 # copies the summaries the judge reads from gpurun_out/ (scratch) into profiles/ (tracked)
 set -e
-r=${1:-r02}
+r=${1:?usage: collect_profiles.sh rNN}
 cd "$(dirname "$0")/.."
 cp gpurun_out/${r}_final/pmc_hera350_f32_stream.json profiles/pmc_hera350_f32_stream.json
 cp gpurun_out/${r}_dense_f32/pmc_hera350_f32_shared.json profiles/

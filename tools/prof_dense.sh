@@ -8,7 +8,7 @@ tag=${1:-dense}
 dt=${2:-f32}
 mops=SQ_INSTS_VALU_MFMA_MOPS_F32
 if [ "$dt" = f64 ]; then mops=SQ_INSTS_VALU_MFMA_MOPS_F64; fi
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out

@@ -2,7 +2,7 @@
 # usage (GPU box, repo root): bash tools/prof_mix.sh <tag>  -- instruction mix and wave-state counters of the dense kernel
 set -e
 tag=${1:-mix}
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
@@ -13,7 +13,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_
 echo "mix2 done"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_IFETCH SQC_ICACHE_MISSES SQC_ICACHE_REQ SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES -d $out/pmc -o mix3 --output-format csv -- $cmd > $out/mix3.log 2>&1
 echo "mix3 done"
-python3 - <<'PY'
+TAG=$tag python3 - <<'PY'
 import csv, glob, collections, os
 out = os.environ.get("OUTDIR", "")
 for f in sorted(glob.glob("gpurun_out/%s/pmc/mix*_counter_collection.csv" % os.environ.get("TAG", "mix"))):

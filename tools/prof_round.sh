@@ -4,7 +4,7 @@
 # the shared layout; everything under gpurun_out/<tag>/ (tools/bench_round.sh makes the bench lines once the summaries are in profiles/)
 set -e
 tag=${1:-prof}
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
