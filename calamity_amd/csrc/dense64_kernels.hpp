@@ -151,13 +151,12 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
   }
   RING_WAIT(kRing - 1);
   r_cur = ring_rd[0];
-#define STREAM_NEXT_INTO(R, RELAXED)                       \
+  // (Unlike the fp32 kernel this one never leaves the sample refill out of the count: its samples are ordinary loads, and a
+  // relaxed wait would rest on hipcc emitting exactly 6 NC of them per block -- ADVICE round 2.  Measured cost of the plain
+  // wait: 1.2 % of the gradient pass.)
+#define STREAM_NEXT_INTO(R, UNUSED)                       \
   __builtin_amdgcn_sched_barrier(0);                       \
-  if (RELAXED) {                                           \
-    RING_WAIT(kRing - 2 + kSmpLoads);                      \
-  } else {                                                 \
-    RING_WAIT(kRing - 2);                                  \
-  }                                                        \
+  RING_WAIT(kRing - 2);                                    \
   R = ring_rd[((cslot + 1) & (kRing - 1)) * 64];           \
   __builtin_amdgcn_sched_barrier(0);
 #define STREAM_REQ()                                                                             \
@@ -192,12 +191,9 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
       }
   };
   // ONE sample buffer, refilled behind the element stage that has just used it: a (current, next) pair carried around the
-  // block loop costs 24 more registers and is copied at the loop edge, behind a wait for the loads.  The refill (6 NC loads)
-  // is younger than the operand requests in flight, so the adjoint phase's first kRing - 1 waits leave it out of the count.
+  // block loop costs 24 more registers and is copied at the loop edge, behind a wait for the loads.
   Samples S_cur;
   load_samples(cb_of(0), S_cur);
-  constexpr int kSmpLoads = 6 * NC;
-  int relax = 0;
 
   for (int nb = 0; nb < nper; ++nb) {
     const int cb = cb_of(nb);
@@ -217,8 +213,7 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
   _Pragma("unroll") for (int c = 0; c < NC; ++c) CN[c] = sc2[(c * (ngk + 1) + gq) * 64];                              \
   __builtin_amdgcn_sched_barrier(0);                                                                                  \
   acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(RC[1], CC[0][1], acc[0], 0, 0, 0);                                    \
-  STREAM_NEXT_INTO(RN, !GRAD && relax > 0)                                                                            \
-  if (!GRAD && relax > 0) --relax;                                                                                    \
+  STREAM_NEXT_INTO(RN, false)                                                                                         \
   if (NC > 1) acc[NC - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(RC[0], CC[NC - 1][0], acc[NC - 1], 0, 0, 0);         \
   STREAM_REQ()                                                                                                        \
   if (NC > 1) acc[NC - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(RC[1], CC[NC - 1][1], acc[NC - 1], 0, 0, 0);         \
@@ -283,7 +278,6 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
     // the next block's samples (the last block loads itself again: the count of loads in flight stays what the waits assume)
     __builtin_amdgcn_sched_barrier(0);
     load_samples(cb_of(nb + 1 < nper ? nb + 1 : nb), S_cur);
-    if (!GRAD) relax = kRing - 1;  // loss-only pass: the waits that skip the refill are the next forward positions
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- B: rows = vectors of tile t, cols = (slot, re | im), K = this block's channels; position = (tile, half v): r = 2 v, 2 v + 1

@@ -148,21 +148,45 @@ def problem_from_chunks(nants, fg_comps, corr_inds, data_r, data_i, wgts, sky_mo
     return prob
 
 
+def _chunk_gather_index(prob):
+    """Per chunk: (flat index into the chunk's (nvecs, ngrps) plane, position in the flat coefficient vector) of every true
+    coefficient, built once per problem: re-chunking is then two fancy-indexed copies instead of a python loop over 61 075
+    groups (0.4 s per call at HERA-350, eight calls per fit)."""
+    cache = prob.__dict__.get("_chunk_index")
+    if cache is not None:
+        return cache
+    if prob.chunk_of_grp is None:
+        raise ValueError("problem was not built from chunk tensors")
+    nvec = prob.grp_nvec.astype(np.int64)
+    coff = prob.grp_coff
+    grp_of_coef = np.repeat(np.arange(prob.ngrps), nvec)
+    k = np.arange(prob.ncoeffs, dtype=np.int64) - coff[grp_of_coef]
+    chunk = np.asarray(prob.chunk_of_grp)[grp_of_coef]
+    pos = np.asarray(prob.pos_in_chunk, dtype=np.int64)[grp_of_coef]
+    cache = []
+    for c, (nvecs, ngrps, nbls) in enumerate(prob.chunk_shapes):
+        sel = np.where(chunk == c)[0]
+        cache.append((k[sel] * ngrps + pos[sel], sel))
+    prob.__dict__["_chunk_index"] = cache
+    return cache
+
+
 def coeffs_from_chunks(prob, fg):
-    """List of ``(nvecs, ngrps, 1, 1)`` chunk coefficient tensors -> flat ragged vector."""
+    """list of (nvecs, ngrps, 1, 1) chunk arrays -> flat ragged vector in group order."""
     out = np.zeros(prob.ncoeffs, dtype=np.float64)
-    coff, nvec = prob.grp_coff, prob.grp_nvec
-    for g in range(prob.ngrps):
-        out[coff[g] : coff[g + 1]] = np.asarray(fg[prob.chunk_of_grp[g]])[: nvec[g], prob.pos_in_chunk[g], 0, 0]
+    for (src, dst), arr in zip(_chunk_gather_index(prob), fg):
+        out[dst] = np.asarray(arr).reshape(np.asarray(arr).shape[0], -1).ravel()[src]
     return out
 
 
 def coeffs_to_chunks(prob, flat, dtype):
-    """Flat ragged coefficient vector -> list of zero-padded ``(nvecs, ngrps, 1, 1)`` chunk tensors."""
-    out = [np.zeros((nv, ng, 1, 1), dtype=dtype) for nv, ng, _ in prob.chunk_shapes]
-    coff, nvec = prob.grp_coff, prob.grp_nvec
-    for g in range(prob.ngrps):
-        out[prob.chunk_of_grp[g]][: nvec[g], prob.pos_in_chunk[g], 0, 0] = flat[coff[g] : coff[g + 1]]
+    """flat ragged vector -> list of zero-padded (nvecs, ngrps, 1, 1) arrays (the reference's fg_r / fg_i layout)."""
+    flat = np.asarray(flat)
+    out = []
+    for (dst, src), (nvecs, ngrps, nbls) in zip(_chunk_gather_index(prob), prob.chunk_shapes):
+        plane = np.zeros(nvecs * ngrps, dtype=dtype)
+        plane[dst] = flat[src]
+        out.append(plane.reshape(nvecs, ngrps, 1, 1))
     return out
 
 
@@ -183,6 +207,7 @@ def chunks_from_problem(prob, dtype=np.float64):
     prob.chunk_of_grp = np.zeros(prob.ngrps, dtype=np.int32)
     prob.pos_in_chunk = np.zeros(prob.ngrps, dtype=np.int32)
     prob.chunk_shapes = []
+    prob.__dict__.pop("_chunk_index", None)  # the re-chunking index of coeffs_to_chunks / coeffs_from_chunks follows the bookkeeping
     F = prob.nfreqs
     for c, nb in enumerate(chunk_keys):
         grps = np.where(nbl_g == nb)[0]
