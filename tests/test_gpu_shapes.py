@@ -180,3 +180,20 @@ def test_time_slices_that_share_tiles(nslices):
         for x, y in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
             assert np.linalg.norm(np.asarray(x, np.float64) - y) <= 10 * tol * np.linalg.norm(y)
         assert outs[0][3] < outs[1][3]  # one tile copy per baseline instead of one per (slice, baseline)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomly_drawn_problems(seed):
+    """Seeded random problems over the corners the fixed cases above do not name: 2 antennas, 1 to 5 channels, channel counts
+    around every padding boundary, single-vector blocks, blocks as wide as the band, groups of 1-4 baselines in any mix --
+    loss and every gradient of both layouts and precisions, with and without the regulariser, against the C restatement."""
+    rng = np.random.default_rng(1000 + seed)
+    nants = int(rng.integers(2, 11))
+    nfreqs = int(rng.choice([1, 2, 5, 8, 9, 31, 64, 65, 127, 128, 129, 200, 257]))
+    ngrps = int(rng.integers(1, 9))
+    nvecs = [int(rng.integers(1, min(max(nfreqs, 1), 260) + 1)) for _ in range(ngrps)]
+    if seed % 3 == 0:
+        nvecs[0] = 1
+    bls = [int(rng.integers(1, 5)) for _ in range(ngrps)]
+    p, start = random_problem(nvecs, bls, nants=nants, nfreqs=nfreqs, seed=2000 + seed, rowblocks=bool(seed % 2))
+    check(p, start)
