@@ -10,7 +10,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -18,6 +20,7 @@
 #include "fit_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "dense64_kernels.hpp"
+#include "multi_mfma_kernels.hpp"
 #include <cstdlib>
 #include <dlfcn.h>
 #include <type_traits>
@@ -54,6 +57,32 @@ int fail(int code, const char* fmt, ...) {
     if (_r != CAL_OK) return _r; \
   } while (0)
 
+// Zero fills of new allocations run on a non-blocking utility stream of the current device, never on the legacy stream: a
+// hipMemset there synchronises with every other stream, and HIP refuses it ("operation would make the legacy stream depend on
+// a capturing ... stream") while ANOTHER thread's solver captures its step graph -- which is what parallel_fits does.
+static hipError_t zero_fill(void* p, size_t n) {
+  static std::mutex mu;
+  static std::map<int, hipStream_t> streams;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  hipStream_t st;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(dev);
+    if (it == streams.end()) {
+      e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+      streams[dev] = st;
+    } else {
+      st = it->second;
+    }
+  }
+  e = hipMemsetAsync(p, 0, n, st);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+
 struct DevBuf {  // owning device allocation
   void* p = nullptr;
   size_t bytes = 0;
@@ -73,11 +102,10 @@ struct DevBuf {  // owning device allocation
     }
     bytes = n;
     if (zero) {
-      // hipMemset runs on the null stream and may still be in flight when it returns; the solver works on a
-      // non-blocking stream, so drain it here or the zero fill can land on top of a later upload
-      e = hipMemset(p, 0, n);
-      if (e == hipSuccess) e = hipDeviceSynchronize();
-      if (e != hipSuccess) return fail(CAL_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+      // complete before this returns: the solver works on its own non-blocking stream, and an unfinished fill could land on top
+      // of a later upload
+      e = zero_fill(p, n);
+      if (e != hipSuccess) return fail(CAL_ERR_HIP, "zero fill of a new allocation failed: %s", hipGetErrorString(e));
     }
     return CAL_OK;
   }
@@ -150,6 +178,7 @@ struct SolverT final : cal_solver {
   // problem
   int nants = 0, nfreqs = 0, fpad = 0, ngrps = 0, nbls = 0, ncoef = 0, nitems = 0, layout = 0;
   int nitems_simple = 0;   // items [0, nitems_simple) are single-baseline groups (fused_basis_kernel), the rest multi-baseline (fused_group_kernel)
+  int nitems_plain = 0;    // items [0, nitems_plain) of those are not covered by a head item of the multi-slice kernels
   size_t lds_group_bytes = 0;
   bool gc_direct = true;
   size_t lds_bytes = 0;
@@ -167,8 +196,9 @@ struct SolverT final : cal_solver {
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
   DevBuf members, heads;                       // baselines that share tiles (bl_alias): member lists of the head items, head item indices
-  int nheads = 0;
-  size_t lds_multi_bytes = 0;
+  int nheads = 0;                              // heads[0 .. nheads_mfma): fused_multi_mfma_kernel (float32, at most kMmMaxVec vectors); the rest: fused_multi_kernel
+  int nheads_mfma = 0;
+  size_t lds_multi_bytes = 0, lds_multi_mfma_bytes = 0;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
@@ -407,7 +437,9 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipMemcpyAsync(raw.p, d->basis_data, (size_t)raw_elems * sizeof(T), hipMemcpyHostToDevice, stream));
     std::vector<long long> uoff(nbasis + 1, 0);
     for (int u = 0; u < nbasis; ++u) uoff[u + 1] = uoff[u] + (long long)d->basis_nrowblk[u] * fpad * d->basis_nvec[u];
-    CAL_TRY(utiles.alloc((size_t)uoff[nbasis] * sizeof(T), false));
+    // (+ a zeroed pad: fused_multi_mfma_kernel reads on past the last rows of a tile, against zero coefficients)
+    CAL_TRY(utiles.alloc(((size_t)uoff[nbasis] + kMmTilePadElems) * sizeof(T), false));
+    HIP_TRY(hipMemsetAsync(utiles.as<T>() + uoff[nbasis], 0, kMmTilePadElems * sizeof(T), stream));
     for (int u = 0; u < nbasis; ++u) {
       const long long n = uoff[u + 1] - uoff[u];
       hipLaunchKernelGGL(retile_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, raw.as<T>() + d->basis_offset[u],
@@ -449,7 +481,8 @@ struct SolverT final : cal_solver {
       }
       for (int b = 0; b < nbls; ++b)
         if (alias_root[b] >= 0) h_bl_tile[b] = h_bl_tile[alias_root[b]];
-      CAL_TRY(tiles.alloc((size_t)off * sizeof(T), false));
+      CAL_TRY(tiles.alloc(((size_t)off + kMmTilePadElems) * sizeof(T), false));
+      HIP_TRY(hipMemsetAsync(tiles.as<T>() + off, 0, kMmTilePadElems * sizeof(T), stream));
       DevBuf djobs;
       CAL_TRY(djobs.alloc(jobs.size() * sizeof(CopyJob), false));
       HIP_TRY(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(CopyJob), hipMemcpyHostToDevice, stream));
@@ -673,14 +706,31 @@ struct SolverT final : cal_solver {
     nitems = (int)h_items.size();
     // single-baseline items first, then the multi-baseline ones (two launches); inside each class heaviest first: the
     // hardware dispatches workgroups in index order, so the tail is made of the lightest items
+    // (among the single-baseline items those that a head item of the multi-slice kernels covers come last: the loss and gradient
+    // passes launch fused_basis_kernel over the plain ones only)
+    std::vector<std::vector<int>> alias_sets(nbls);
+    for (int b = 0; b < nbls; ++b)
+      if (in_alias_set[b]) alias_sets[alias_root[b] >= 0 ? alias_root[b] : b].push_back(b);
+    std::vector<char> bl_covered(nbls, 0);
+    for (int r = 0; r < nbls; ++r)
+      for (size_t i = 0; i < alias_sets[r].size(); i += MultiCfg<T>::nb_max) {
+        const size_t n = std::min<size_t>(MultiCfg<T>::nb_max, alias_sets[r].size() - i);
+        if (n >= 2)
+          for (size_t k = 0; k < n; ++k) bl_covered[alias_sets[r][i + k]] = 1;
+      }
+    auto item_class = [&](int q) { return h_item_multi[q] ? 2 : (bl_covered[h_items[q].bl0] ? 1 : 0); };
     std::vector<int> order(nitems);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      if (h_item_multi[a] != h_item_multi[b]) return h_item_multi[a] < h_item_multi[b];
+      if (item_class(a) != item_class(b)) return item_class(a) < item_class(b);
       return h_item_cost[a] > h_item_cost[b];
     });
     nitems_simple = 0;
-    for (int q = 0; q < nitems; ++q) nitems_simple += h_item_multi[q] ? 0 : 1;
+    nitems_plain = 0;
+    for (int q = 0; q < nitems; ++q) {
+      nitems_simple += h_item_multi[q] ? 0 : 1;
+      nitems_plain += item_class(q) == 0 ? 1 : 0;
+    }
     std::vector<int> h_item_goff(nitems);
     gcp_len = 0;
     if (gc_direct) {
@@ -702,14 +752,14 @@ struct SolverT final : cal_solver {
     }
     // ---- sets of baselines that share tiles -> head items with member lists (at most MultiCfg<T>::nb_max baselines each)
     nheads = 0;
+    nheads_mfma = 0;
     lds_multi_bytes = 0;
+    lds_multi_mfma_bytes = 0;
     {
       std::vector<int> item_of_bl(nbls, -1);
       for (int q = 0; q < nitems; ++q)
         if (!h_item_multi[order[q]]) item_of_bl[sorted[q].bl0] = q;
-      std::vector<std::vector<int>> sets(nbls);
-      for (int b = 0; b < nbls; ++b)
-        if (in_alias_set[b]) sets[alias_root[b] >= 0 ? alias_root[b] : b].push_back(b);
+      const std::vector<std::vector<int>>& sets = alias_sets;
       std::vector<Member> h_members;
       std::vector<int> h_heads;
       constexpr int NBM = MultiCfg<T>::nb_max;
@@ -721,7 +771,6 @@ struct SolverT final : cal_solver {
           sorted[head].role_n = (n << 2) | 1;
           sorted[head].member0 = (int)h_members.size();
           h_heads.push_back(head);
-          lds_multi_bytes = std::max(lds_multi_bytes, multi_lds_for(1 << sorted[head].fb_log2));
           for (int k = 0; k < n; ++k) {
             const int b = sets[r][i + k], q = item_of_bl[b];
             if (k > 0) sorted[q].role_n = 2;
@@ -735,6 +784,21 @@ struct SolverT final : cal_solver {
           }
         }
       }
+      // the matrix-core form first (float32, blocks of at most kMmMaxVec vectors), each list heaviest first
+      auto on_mfma = [&](int head) { return std::is_same<T, float>::value && sorted[head].nvec <= kMmMaxVec && (1 << sorted[head].fb_log2) >= kMmStrip; };
+      std::stable_sort(h_heads.begin(), h_heads.end(), [&](int a, int b) {
+        const bool ma = on_mfma(a), mb = on_mfma(b);
+        if (ma != mb) return ma;
+        return (long long)sorted[a].nvec * (sorted[a].role_n >> 2) > (long long)sorted[b].nvec * (sorted[b].role_n >> 2);
+      });
+      for (int head : h_heads) {
+        if (on_mfma(head)) {
+          ++nheads_mfma;
+          lds_multi_mfma_bytes = std::max(lds_multi_mfma_bytes, multi_mfma_lds_bytes(sorted[head].nvec));
+        } else {
+          lds_multi_bytes = std::max(lds_multi_bytes, multi_lds_for(1 << sorted[head].fb_log2));
+        }
+      }
       nheads = (int)h_heads.size();
       members.release();
       heads.release();
@@ -743,8 +807,14 @@ struct SolverT final : cal_solver {
         HIP_TRY(hipMemcpy(members.p, h_members.data(), h_members.size() * sizeof(Member), hipMemcpyHostToDevice));
         CAL_TRY(heads.alloc(h_heads.size() * sizeof(int), false));
         HIP_TRY(hipMemcpy(heads.p, h_heads.data(), h_heads.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_LOSS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+        if (nheads > nheads_mfma) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_LOSS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+        }
+        if (nheads_mfma > 0) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_LOSS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+        }
       }
     }
     CAL_TRY(items.alloc(nitems * sizeof(Item), false));
@@ -1110,16 +1180,27 @@ struct SolverT final : cal_solver {
   static constexpr size_t kQLdsMax2 = TileCfg<T, FbSet<T>::fb_min>::q_lds_bytes(true);
   template <int MODE> void launch_fused(const FusedArgs<T>& a0, bool with_reg) {
     FusedArgs<T> a = a0;
-    if (nitems_simple > 0) {
+    // the passes with a multi-slice form leave the covered items to it (fused_basis_kernel would return at once for each of them)
+    const int nsimple = ((MODE == MODE_LOSS || MODE == MODE_GRAD) && !with_reg && nheads > 0) ? nitems_plain : nitems_simple;
+    if (nsimple > 0) {
       a.item_base = 0;
       if (with_reg)
-        hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nitems_simple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax2 : 0), stream, a);
+        hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nsimple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax2 : 0), stream, a);
       else
-        hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nitems_simple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
+        hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nsimple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
     }
     if constexpr (MODE == MODE_LOSS || MODE == MODE_GRAD) {
       // baselines that share tiles (skipped by the launch above): one workgroup per set
-      if (nheads > 0 && !with_reg) hipLaunchKernelGGL((fused_multi_kernel<T, MODE>), dim3(nheads), dim3(kThreads), lds_multi_bytes, stream, a);
+      if (nheads > 0 && !with_reg) {
+        if constexpr (std::is_same<T, float>::value) {
+          if (nheads_mfma > 0) hipLaunchKernelGGL((fused_multi_mfma_kernel<MODE>), dim3(nheads_mfma), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
+        }
+        if (nheads > nheads_mfma) {
+          FusedArgs<T> b = a;
+          b.heads = a.heads + nheads_mfma;
+          hipLaunchKernelGGL((fused_multi_kernel<T, MODE>), dim3(nheads - nheads_mfma), dim3(kThreads), lds_multi_bytes, stream, b);
+        }
+      }
     }
     if (nitems > nitems_simple) {
       a.item_base = nitems_simple;

@@ -1,0 +1,324 @@
+// multi_mfma_kernels.hpp -- time slices of one solver that share basis tiles (cal_problem_desc::bl_alias), float32, on the
+// matrix cores: the 8 member baselines of a head item are 16 right-hand sides (re | im) of ONE tile, which makes the skinny
+// complex GEMV of /root/reference/calamity/calibration.py:1587-1590 a real (if narrow) dense contraction --
+// v_mfma_f32_16x16x4_f32 with 16 columns -- while the tile still streams from HBM exactly once per pass (fused_multi_kernel of
+// fit_kernels.hpp does the same job in the vector ALU and is bound by its lane reductions; it keeps fp64 and the wide blocks).
+//
+// One 4-wave workgroup per head item.  Wave w owns the 16-channel strips j = w, w + 4, ... of the item's channels and runs, per
+// strip ("job"), with no data exchanged between waves (one barrier per job only keeps them on neighbouring strips):
+//   F  forward   V^T[col][ch] = sum_k C[k][col] T[k][ch]: M = 16 columns (member, re | im; the coefficient operand, from LDS),
+//                N = the strip's 16 channels, K = basis vectors.  The tile operand of a k-step is ONE dword per lane,
+//                T[4 s + (lane >> 4)][ch0 + (lane & 15)], straight from a buffer load (64-byte row pieces; the four waves of the
+//                workgroup read the four neighbouring pieces); the same register is stored to the wave's LDS strip for the adjoint;
+//   E  element-wise stage in the accumulator registers: lane (ch, q) holds ONE channel and the four columns 4 q + r, i.e. the
+//                real (q < 2) or imaginary parts of four members; v_permlane32_swap hands the lane 32 on the missing parts, so that
+//                each lane evaluates two members at its channel -- all sample / gain loads and the gbar_G store of a member are
+//                16 adjacent lanes on 16 adjacent channels.  (With columns on the lanes -- the layout that lets the accumulator
+//                double as the adjoint's operand, as the dense kernels do -- every lane of a sample load went to another row:
+//                630 L1 accesses per job instead of 120.)  gbar_v goes through a 16 x 16 per-wave LDS buffer to turn it round;
+//   B  adjoint   GC[k][col] += sum_ch T[k][ch] gbar_v[ch][col]: M = 16 basis vectors, K = the strip's channels; the A operand is
+//                the transposed tile, one ds_read_b128 per 16 vectors from the LDS strip (XOR-swizzled by 8-row group: conflict-free
+//                for the 4 x 16-lane groups of that instruction), the B operand one ds_read_b128 of the gbar_v buffer.
+//                Gradient tiles stay in registers for the whole item; the four waves' parts meet in LDS once per item.
+// Every loop over vectors has a compile-time trip count: the item body is instantiated per NT = ceil(nvec / 16) (14 classes, one
+// wave-uniform dispatch per workgroup).  (With run-time counts -- a guard per k-step, or a switch with fall-through -- hipcc
+// kept dozens of lane masks in spilled SGPRs and waited for ALL loads in front of the first k-step.)
+// Rows past nvec: the k-steps run to 16 NT and simply read on into the next tile (finite basis values; the buffer carries a
+// zeroed pad behind its last tile) against zero coefficients; gradient rows past nvec are never stored.
+// Where the time goes (per-rank job of an 8-GPU HERA-350 run, 7 634 baselines x 8 slices, gradient pass 1.33 ms): the pass
+// moves 3.1 GB of tiles, 0.75 GB of samples, 1.0 GB of gain rows (23 MB of distinct data, but 8 slices x 350 antennas do not
+// stay in a 4 MB L2) and writes 0.5 GB of gbar_G: 5.35 GB at 4 TB/s.  Tiles alone: 0.66 ms (4.7 TB/s); matrix pipe busy 27 %.
+#pragma once
+#include "fit_kernels.hpp"
+
+namespace calk {
+
+typedef float mm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mm_f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef CAL_MM_NT
+#define CAL_MM_NT 0  // cache policy of the tile loads (2 = non-temporal: measured 20 % slower -- the two halves of a 128-byte line are read by neighbouring waves, and the second one should still find it in L2)
+#endif
+#ifndef CAL_MM_NT
+#define CAL_MM_NT 0  // cache policy of the tile loads (2 = non-temporal: measured 20 % slower -- the two halves of a 128-byte line are read by neighbouring waves, and the second one should still find it in L2)
+#endif
+constexpr int kMmStrip = 16;               // channels of a wave's job
+constexpr int kMmMaxVec = 224;             // widest block this kernel takes (wider ones: fused_multi_kernel)
+constexpr int kMmTiles = kMmMaxVec / 16;   // gradient tiles of 16 vectors = classes of the item body
+constexpr int kMmGvPitch = 20;             // words per column of the per-wave gbar_v buffer (16 channels + 4: 16-byte aligned, rows on distinct bank groups)
+constexpr int kMmTilePadElems = 2048;      // zeroed elements the tile buffers carry behind their last tile (the read-on of the last k-steps: < 16 rows of 128 channels)
+
+inline size_t multi_mfma_lds_bytes(int nvec_max) {
+  const size_t nt = (nvec_max + 15) / 16;
+  return 256 + 64 + nt * 4 * 64 * 4 + 4 * nt * 16 * 16 * 4 + 4 * 16 * kMmGvPitch * 4;  // members, loss partials, coefficient operand, four strips, four gbar_v buffers
+}
+
+template <int MODE, int NT>
+__device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const Item& it, int item_idx, unsigned char* smem) {
+  constexpr bool GRAD = MODE == MODE_GRAD;
+  constexpr int NS = 4 * NT;   // forward k-steps (four vectors each), run as two interleaved accumulator chains
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15;   // MFMA column: member col & 7, re (col < 8) | im
+  const int kq = lane >> 4;    // the k of a step this lane feeds; the channel quad it holds in the accumulator
+  const int nvec = it.nvec;
+  const int NB = it.role_n >> 2;
+  const int fb_log2 = it.fb_log2;
+  const unsigned FB = 1u << fb_log2;
+
+  Member* s_mem = reinterpret_cast<Member*>(smem);
+  double* s_red = reinterpret_cast<double*>(smem + 256);
+  float* s_c = reinterpret_cast<float*>(smem + 320);                 // [NS steps][64 lanes]: C[4 s + (lane >> 4)][lane & 15]
+  float* s_strips = s_c + NS * 64;                                   // [4 waves][16 NT rows][16 channels], swizzled
+  float* s_strip = s_strips + wave * NT * 256;
+  float* s_gv = s_strips + 4 * NT * 256 + wave * (16 * kMmGvPitch);   // [16 columns][16 channels] gbar_v of the current job, pitch 20 words
+
+  if (tid < NB * (int)(sizeof(Member) / 4)) reinterpret_cast<int*>(s_mem)[tid] = reinterpret_cast<const int*>(A.members + it.member0)[tid];
+  __syncthreads();
+  for (int n = tid; n < NS * 64; n += kThreads) {
+    const int k = n >> 4, j = n & 15, m = j & 7;
+    float v = 0.f;
+    if (k < nvec && m < NB) v = (j < 8 ? A.c_r : A.c_i)[s_mem[m].coff + k];
+    s_c[n] = v;
+  }
+  // E works in the accumulator layout of F (see there): lane (ch = lane & 15, q = lane >> 4) holds, for ONE channel of the strip,
+  // the four columns 4 q .. 4 q + 3 = the real parts (q < 2) or imaginary parts (q >= 2) of members 4 (q & 1) .. + 3.  The partner
+  // 32 lanes on holds the other part of the same four members; of those four the lower lane evaluates the first two, the upper
+  // lane the last two.  Sample rows and antenna pairs of this lane's two members as 32-bit element offsets (+ its channel):
+  const int half = kq >> 1;
+  const int m_a = 4 * (kq & 1) + 2 * half;  // and m_a + 1
+  unsigned so[2], g0o[2], g1o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bool active = m_a + i < NB;
+    const unsigned row = active ? (unsigned)s_mem[m_a + i].bl : (unsigned)A.nbls;  // the spare all-zero row
+    so[i] = row * (unsigned)A.fpad + (unsigned)col;
+    g0o[i] = (active ? (unsigned)s_mem[m_a + i].ant0 : 0u) * (unsigned)A.fpad + (unsigned)col;
+    g1o[i] = (active ? (unsigned)s_mem[m_a + i].ant1 : 0u) * (unsigned)A.fpad + (unsigned)col;
+  }
+  __syncthreads();
+
+  const float* s_cl = s_c + lane;
+  // LDS strip: word address of (row, ch) = row * 16 + (((ch >> 2) ^ (2 * ((row >> 3) & 1))) << 2) + (ch & 3)
+  float* s_w0 = s_strip + kq * 16 + col;                                     // store of step s with (s & 2) == 0: row 4 s + kq, channel col
+  float* s_w1 = s_strip + kq * 16 + ((((col >> 2) ^ 2) << 2) | (col & 3));   // ... with (s & 2) != 0 (rows 8..15 of a 16-row group)
+  const mm_f32x4* s_rd = reinterpret_cast<const mm_f32x4*>(s_strip + col * 16 + ((kq ^ (2 * (col >> 3))) << 2));  // + t * 256 words: row 16 t + col, channels 4 kq ..
+
+  float* s_gw = s_gv + m_a * kMmGvPitch + col;                                                  // E: column m_a (+ i, + 8 + i), channel col
+  const mm_f32x4* s_gr = reinterpret_cast<const mm_f32x4*>(s_gv + col * kMmGvPitch + 4 * kq);   // B: column col, channels 4 kq ..
+
+  const int njobs = A.fpad >> 6;  // strips per wave (fpad is a multiple of 128)
+  // The tile loads are buffer loads: resource = this item's tiles, per-lane offset `lo` (one VGPR for the whole kernel), the
+  // k-step's offset in an SGPR -- no vector-ALU address arithmetic (with flat pointers hipcc spent a 64-bit vector add per load).
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.tiles + it.tile_first), 0, 0x7fffffff, 0x00020000);
+  const unsigned tile_bytes = (unsigned)nvec << (fb_log2 + 2);
+  const unsigned lo = ((unsigned)kq * FB + (unsigned)col) * 4u;  // byte offset of this lane's element inside a k-step
+  const unsigned step_bytes = FB * 16u;                          // four rows
+  // Software pipeline.  A wave keeps about 48 tile loads (12 KB) in flight at all times: the k-step registers form a ring that
+  // is DEPTH jobs deep (2 for blocks of at most 96 vectors, else 1), and F re-issues each register -- for the job DEPTH ahead --
+  // right behind the MFMA that consumed it, so loads are issued in the order they are consumed and the compiler's counted waits
+  // never drain the queue.  The samples of job n + 1 are requested at the START of job n (two register sets, the job loop is
+  // unrolled by two), i.e. ahead of the tile loads F issues: waiting for them in E never waits for younger tile loads.
+  // The loop body has NO branch: behind a conditional prefetch the counted waits must hold for the path that issued nothing,
+  // and every wait for the samples also waited for the whole next tile.  Past the last job the loads therefore still run, with
+  // a zero k-step stride on the last job's first rows (one cached kilobyte), and the last job's samples are requested again.
+  constexpr int DEPTH = NT <= 6 ? 2 : 1;
+  float treg[DEPTH][NS];
+  auto job_off = [&](int n) -> unsigned {
+    const unsigned ch = (unsigned)(wave + 4 * (n < njobs ? n : njobs - 1)) * kMmStrip;
+    return (ch >> fb_log2) * tile_bytes + (ch & (FB - 1)) * 4u;
+  };
+  struct Samples { float dr[2], di[2], w[2]; mm_f32x2 g0[2], g1[2]; };  // this lane's two members at its channel
+  auto issue_samples = [&](int n, Samples& S) {
+    const unsigned ch = (unsigned)(wave + 4 * (n < njobs ? n : njobs - 1)) * kMmStrip;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      S.dr[i] = A.data_r[so[i] + ch];
+      S.di[i] = A.data_i[so[i] + ch];
+      S.w[i] = A.wgts[so[i] + ch];
+      S.g0[i] = *reinterpret_cast<const mm_f32x2*>(A.gains + g0o[i] + ch);
+      S.g1[i] = *reinterpret_cast<const mm_f32x2*>(A.gains + g1o[i] + ch);
+    }
+  };
+
+  mm_f32x4 dC[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) dC[t] = mm_f32x4{0.f, 0.f, 0.f, 0.f};
+  double loss_acc = 0.0;
+
+  // one job: samples S (requested one job ago), ring set D; requests the next job's samples into Sn
+  auto job = [&](int n, float (&tr)[NS], const Samples& S, Samples& Sn) {
+    __syncthreads();  // keeps the four waves on neighbouring strips of the same rows (3-4 % faster than letting them drift)
+    issue_samples(n + 1, Sn);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- F: two accumulator chains (40-cycle dependent latency against a 32-cycle issue); each register goes back out for job n + DEPTH
+    const unsigned nxt_off = job_off(n + DEPTH);
+    const unsigned nxt_step = n + DEPTH < njobs ? step_bytes : 0u;
+    mm_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // One fenced group per pair of k-steps: the coefficient read of the pair after next, two MFMAs, their strip store, the two
+    // re-issued loads.  (Left alone -- also with sched_group_barrier hints -- the scheduler holds the loads back and sends them
+    // in a burst at the end of F: the queue ran down to a third of its depth in every job.)
+    float bq[3][2];
+    bq[0][0] = s_cl[0];
+    bq[0][1] = s_cl[64];
+    if (NS > 2) {
+      bq[1][0] = s_cl[2 * 64];
+      bq[1][1] = s_cl[3 * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS; s += 2) {
+      const int p = s >> 1;
+      if (s + 4 < NS) {
+        bq[(p + 2) % 3][0] = s_cl[(s + 4) * 64];
+        bq[(p + 2) % 3][1] = s_cl[(s + 5) * 64];
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[p % 3][0], tr[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[p % 3][1], tr[s + 1], acc1, 0, 0, 0);
+      if (GRAD) {  // steps s, s + 1 (s even) lie in the same 8-row group
+        float* w = (s & 2) ? s_w1 : s_w0;
+        w[s * 64] = tr[s];
+        w[(s + 1) * 64] = tr[s + 1];
+      }
+      tr[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lo, nxt_off + (unsigned)s * nxt_step, CAL_MM_NT));
+      tr[s + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lo, nxt_off + (unsigned)(s + 1) * nxt_step, CAL_MM_NT));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mm_f32x4 acc = acc0 + acc1;            // acc[r] of lane (ch, q) = v(channel ch) of column 4 q + r
+    // ---- E: v_permlane32_swap hands each lane the missing part of the two members it evaluates (the lower lane's acc[i] and
+    // the upper lane's acc[i + 2] stay, the other two registers cross): (re, im) of member m_a + i on both lanes, no selects
+    const unsigned ch0 = (unsigned)(wave + 4 * n) * kMmStrip;
+    float lossj = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      const float mine_lo = acc[i], mine_hi = acc[i + 2];  // (scalars first: __builtin_bit_cast applied to a vector ELEMENT read element 0)
+      const u2 sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mine_lo), __builtin_bit_cast(unsigned, mine_hi), false, false);
+      const unsigned sw0 = sw[0], sw1 = sw[1];
+      const float vr = __builtin_bit_cast(float, sw0), vi = __builtin_bit_cast(float, sw1);
+      const float g0x = S.g0[i][0], g0y = S.g0[i][1], g1x = S.g1[i][0], g1y = S.g1[i][1];
+      const float d_r = S.dr[i], d_i = S.di[i], w = S.w[i];
+      // G = g0 conj(g1)   (calibration.py:1598-1601: grgr + gigi, gigr - grgi)
+      const float G_r = g0x * g1x + g0y * g1y;
+      const float G_i = g0y * g1x - g0x * g1y;
+      const float m_r = G_r * vr - G_i * vi;
+      const float m_i = G_i * vr + G_r * vi;
+      const float r_r = d_r - m_r, r_i = d_i - m_i;
+      lossj += w * (r_r * r_r + r_i * r_i);
+      if (GRAD) {
+        const float e_r = -2.f * w * r_r, e_i = -2.f * w * r_i;
+        // gbar_v = conj(G) e -> the wave's [column][channel] buffer, from where B takes it as its operand
+        s_gw[i * kMmGvPitch] = G_r * e_r + G_i * e_i;
+        s_gw[(8 + i) * kMmGvPitch] = G_r * e_i - G_i * e_r;
+        mm_f32x2 q;  // gbar_G = conj(v) e; members the set does not have: zeros to the spare row
+        q[0] = vr * e_r + vi * e_i;
+        q[1] = vr * e_i - vi * e_r;
+        *reinterpret_cast<mm_f32x2*>(A.q0 + so[i] + ch0) = q;
+      }
+    }
+    loss_acc += (double)lossj;
+
+    // ---- B: gradient tiles in pairs (independent accumulators back to back)
+    if (GRAD) {
+      __builtin_amdgcn_wave_barrier();
+      const mm_f32x4 gvb = *s_gr;  // lane (column, k): gbar_v of channels 4 k .. 4 k + 3
+#pragma unroll
+      for (int t = 0; t + 1 < NT; t += 2) {
+        const mm_f32x4 a0 = s_rd[t * 64];
+        const mm_f32x4 a1 = s_rd[(t + 1) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], gvb[r], dC[t], 0, 0, 0);
+          dC[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], gvb[r], dC[t + 1], 0, 0, 0);
+        }
+      }
+      if (NT & 1) {
+        const mm_f32x4 a0 = s_rd[(NT - 1) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dC[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], gvb[r], dC[NT - 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+
+  // (the prologue issues in the order of the steady state -- samples, then tiles: at the loop head the compiler's counted waits
+  // must cover the entry path too, and samples requested BEHIND the tiles there made every iteration wait for all but five loads)
+  Samples SA, SB;
+  issue_samples(0, SA);
+  __builtin_amdgcn_sched_barrier(0);  // (the scheduler is free to reorder independent loads: pin the order the waits are counted against)
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const unsigned off = job_off(d);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) treg[d][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lo, off + (unsigned)s * step_bytes, CAL_MM_NT));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  for (int n = 0; n < njobs; n += 2) {  // njobs is even
+    job(n, treg[0], SA, SB);
+    job(n + 1, treg[DEPTH - 1], SB, SA);
+  }
+
+  // ---- epilogue: loss partial of the item (all members), coefficient gradients of every member
+  const double ls = ldsum(loss_acc);
+  if (lane == 0) s_red[wave] = ls;
+  __syncthreads();  // also: every wave has left its strip
+  if (tid == 0) {
+    A.part[(size_t)item_idx * 4 + 0] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    A.part[(size_t)item_idx * 4 + 1] = 0.0;
+    A.part[(size_t)item_idx * 4 + 2] = 0.0;
+  }
+  if (!GRAD) return;
+  // dC[t][r] of lane (col, kq) of wave w = that wave's part of GC[16 t + 4 kq + r][col]; the four parts meet in the strip area:
+  // s_x[((w * NT + t) * 4 + r) * 64 + lane]
+  float* s_x = s_strips;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_x[((wave * NT + t) * 4 + r) * 64 + lane] = dC[t][r];
+  }
+  __syncthreads();
+  // thread (column tid >> 4, vector-in-tile tid & 15) sums the four parts of its 16 consecutive... one vector per tile
+  {
+    const int j = tid >> 4, kk = tid & 15, m = j & 7;
+    if (m < NB) {
+      float* gc = (j < 8 ? A.gcp0_r : A.gcp0_i) + s_mem[m].goff;
+      const int src_lane = j + 16 * (kk >> 2), r = kk & 3;
+      for (int t = 0; t < NT; ++t) {
+        const int k = 16 * t + kk;
+        const float* px = s_x + (t * 4 + r) * 64 + src_lane;
+        const float v = ((px[0] + px[NT * 256]) + px[2 * NT * 256]) + px[3 * NT * 256];
+        if (k < nvec) gc[k] = v;
+      }
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 2) void fused_multi_mfma_kernel(const FusedArgs<float> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int item_idx = A.heads[blockIdx.x];
+  const Item it = A.items[item_idx];
+  if (A.state->done | A.state->done_after) return;
+  switch ((it.nvec + 15) >> 4) {  // wave-uniform
+    case 1: multi_mfma_item<MODE, 1>(A, it, item_idx, smem); break;
+    case 2: multi_mfma_item<MODE, 2>(A, it, item_idx, smem); break;
+    case 3: multi_mfma_item<MODE, 3>(A, it, item_idx, smem); break;
+    case 4: multi_mfma_item<MODE, 4>(A, it, item_idx, smem); break;
+    case 5: multi_mfma_item<MODE, 5>(A, it, item_idx, smem); break;
+    case 6: multi_mfma_item<MODE, 6>(A, it, item_idx, smem); break;
+    case 7: multi_mfma_item<MODE, 7>(A, it, item_idx, smem); break;
+    case 8: multi_mfma_item<MODE, 8>(A, it, item_idx, smem); break;
+    case 9: multi_mfma_item<MODE, 9>(A, it, item_idx, smem); break;
+    case 10: multi_mfma_item<MODE, 10>(A, it, item_idx, smem); break;
+    case 11: multi_mfma_item<MODE, 11>(A, it, item_idx, smem); break;
+    case 12: multi_mfma_item<MODE, 12>(A, it, item_idx, smem); break;
+    case 13: multi_mfma_item<MODE, 13>(A, it, item_idx, smem); break;
+    case 14: multi_mfma_item<MODE, 14>(A, it, item_idx, smem); break;
+    default: break;  // the host gives this kernel no wider block
+  }
+}
+static_assert(kMmTiles == 14, "the dispatch above lists 14 classes");
+
+}  // namespace calk

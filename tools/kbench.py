@@ -20,7 +20,10 @@ def child(args):
     from calamity_amd.solver import HipFitSolver
 
     dtype = np.float64 if args.dtype == "f64" else np.float32
-    if args.cache and os.path.exists(args.cache):
+    if args.slices:
+        import bench
+        prob, start, _ = bench.build_sharded_job(args.config, 0, args.slices, args.slices, max_bls=args.max_bls)
+    elif args.cache and os.path.exists(args.cache):
         import pickle
         prob, start = pickle.load(open(args.cache, "rb"))
     else:
@@ -63,6 +66,7 @@ if __name__ == "__main__":
     ap.add_argument("--layout", default="stream")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--reg", action="store_true")
+    ap.add_argument("--slices", type=int, default=0, help="the per-rank job of an N-GPU run: N time slices x 1/N of the baselines, sharing tiles")
     ap.add_argument("--redundant", action="store_true", help="merge redundant baselines into shared-coefficient groups")
     ap.add_argument("--cache", default="/tmp/kbench_problem.pkl")
     ap.add_argument("--child", action="store_true")
