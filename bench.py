@@ -428,7 +428,10 @@ def main():
         hbm_roofline = {
             "bound": "hbm" if not cache_resident else "launch latency (a {:.0f} MB working set lives in the 256 MB Infinity Cache: 'achieved' is cache "
                      "bandwidth, not an HBM figure; the step is bounded by the launches it takes)".format(tim["algorithmic_bytes_per_launch"] / 1e6),
-            "kernel": "fused_basis_kernel<MODE_GRAD>",
+            "kernel": ("fused_basis_kernel<MODE_GRAD>" if not (sharded and ntimes > 1 and args.layout == "stream") else
+                       ("fused_multi_mfma_kernel<MODE_GRAD> (the slices of a rank share basis tiles: 16 right-hand sides per tile on "
+                        "v_mfma_f32_16x16x4_f32; basis bytes counted once per unique tile)" if dtype == np.float32 else
+                        "fused_multi_kernel<double, MODE_GRAD> (the slices of a rank share basis tiles; basis bytes counted once per unique tile)")),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -135,12 +135,13 @@ def test_model_and_init_on_multi_baseline_groups(dtype):
             s.close()
 
 
-@pytest.mark.parametrize("nslices", [3, 10])
+@pytest.mark.parametrize("nslices", [3, 9, 10])
 def test_time_slices_that_share_tiles(nslices):
     """cal_problem_desc::bl_alias: the same baselines in several time slices fitted by one solver read ONE copy of their basis
-    tiles, and fused_multi_kernel processes a baseline's slices together (SURVEY.md section 8e "Multiple times";
-    calibration.py:1160-1167 loops over times).  Every tile width, sets larger than a multi item holds (10 slices: 8 + 2 in
-    float32, 4 + 4 + 2 in float64), loss / gradients against the C restatement of the batched problem, the regularised form
+    tiles, and fused_multi_mfma_kernel (float32, at most 224 vectors) / fused_multi_kernel process a baseline's slices together
+    (SURVEY.md section 8e "Multiple times"; calibration.py:1160-1167 loops over times).  Every tile width, sets larger than a multi
+    item holds (10 slices: 8 + 2 in float32, 4 + 4 + 2 in float64; 9 slices: the last baseline of a set is left over and runs as an
+    ordinary item), loss / gradients against the C restatement of the batched problem, the regularised form
     (which runs the baselines one by one), model evaluation and initial coefficients, and a short trajectory against the one
     of the same problem WITHOUT the alias table (every baseline streaming its own copy; the loss partials are summed in another
     order, so equal to rounding, not to the bit)."""
@@ -180,6 +181,32 @@ def test_time_slices_that_share_tiles(nslices):
         for x, y in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
             assert np.linalg.norm(np.asarray(x, np.float64) - y) <= 10 * tol * np.linalg.norm(y)
         assert outs[0][3] < outs[1][3]  # one tile copy per baseline instead of one per (slice, baseline)
+
+
+def test_slices_that_share_only_some_tiles():
+    """A solver that holds ordinary baselines beside sets that share tiles: the alias table of a batched problem with every
+    third baseline of the later slices given its own tile copy again (bl_alias = -1), and one whole slice un-aliased.  The
+    ordinary items are launched on fused_basis_kernel, the covered ones on the multi-slice kernels (the host orders covered
+    items last); loss and gradients against the C restatement, which knows nothing of the table."""
+    from calamity_amd import distributed as D
+
+    nvecs = [3, 40, 56, 90, 112, 150, 224, 225, 17, 64]
+    base, _ = random_problem(nvecs, [1] * len(nvecs), nants=9, nfreqs=200, seed=70)
+    parts = []
+    for t in range(6):
+        p, st = random_problem(nvecs, [1] * len(nvecs), nants=9, nfreqs=200, seed=71 + t)
+        p.basis, p.grp_basis = base.basis, base.grp_basis
+        p.bl_ant0, p.bl_ant1, p.bl_rowblk = base.bl_ant0, base.bl_ant1, base.bl_rowblk
+        p.wgts = p.wgts / 6
+        parts.append((p, st))
+    prob, start = D.batch_time_slices(parts)
+    alias = prob.bl_alias.copy()
+    alias[base.nbls + 1::3] = -1                       # every third baseline of the later slices
+    alias[3 * base.nbls: 4 * base.nbls] = -1           # all of slice 3
+    assert np.any(alias >= 0) and np.any(alias[base.nbls:] < 0)
+    prob.bl_alias = alias
+    prob.sky_r, prob.sky_i = np.concatenate([p.sky_r for p, _ in parts]), np.concatenate([p.sky_i for p, _ in parts])
+    check(prob, start, layouts=("stream",))
 
 
 @pytest.mark.parametrize("seed", range(10))
