@@ -363,6 +363,34 @@ def main():
         shared.update(steps_per_s=args.steps / dt2, ms_per_step=dt2 / args.steps * 1e3, device_memory_GB=s2.memory_bytes() / 1e9)
         s2.close()
 
+    # what ONE RANK of the driver's `--gpus 8` run executes per step, without the exchange: 8 time slices x 1/8 of the baselines,
+    # the slices sharing basis tiles (fused_multi_mfma_kernel) -- measured here so that the single-GPU bench line carries it too
+    rank_job = None
+    if (rank == 0 and not sharded and args.layout == "stream" and not args.no_shared and args.reg == "none" and args.config == "hera350"
+            and args.max_bls is None and dtype == np.float32):
+        rp, rstart, _ = build_sharded_job(args.config, 0, 8, 8)
+        s3 = HipFitSolver(dtype=dtype, device=0)
+        s3.set_problem(rp, layout="stream")
+        s3.set_params(rstart["g_r"], rstart["g_i"], rstart["c_r"], rstart["c_i"])
+        s3.set_optimizer(args.optimizer, learning_rate=1e-2)
+        s3.run(max(args.warmup, 1), record=False, tol=0.0)
+        s3.timing_enable(True)
+        s3.synchronize()
+        t3 = time.perf_counter()
+        s3.run(args.steps, record=True, tol=0.0)
+        s3.synchronize()
+        dt3 = time.perf_counter() - t3
+        tim3 = s3.timing_get()
+        k3 = tim3["total_ms"] / max(tim3["launches"], 1)
+        rank_job = {"what": f"one rank's share of an 8-GPU job: 8 time slices x {rp.nbls // 8} baselines (1/8 of each slice, balanced by basis bytes), "
+                            "the slices sharing basis tiles; no exchange (a single process)",
+                    "kernel": "fused_multi_mfma_kernel<MODE_GRAD> (v_mfma_f32_16x16x4_f32, 16 right-hand sides per tile)",
+                    "ms_per_step": dt3 / args.steps * 1e3, "kernel_ms": k3, "slice_steps_per_s": 8 * args.steps / dt3,
+                    "algorithmic_bytes_per_launch": tim3["algorithmic_bytes_per_launch"],
+                    "achieved_GBps": tim3["algorithmic_bytes_per_launch"] / (k3 * 1e-3) / 1e9 if k3 > 0 else None,
+                    "device_memory_GB": s3.memory_bytes() / 1e9}
+        s3.close()
+
     # measured streaming peaks of this box and, for orientation, the only configuration the
     # reference publishes a rate for (tutorial notebook: 15 antennas, 105 baselines x 200 channels, Adamax, 61.77 steps/s
     # on a P100) -- single-GPU runs only, after the solvers above have released their memory
@@ -483,6 +511,7 @@ def main():
                 "setup_s": t_setup,
                 "device_memory_GB": solvers[0].memory_bytes() / 1e9 * len(solvers),
                 "shared_layout": shared,
+                "rank_of_8_job": rank_job,
                 "tutorial_notebook_config": tutorial,
                 "redundant_groups_config": redundant,
             },

@@ -785,7 +785,10 @@ struct SolverT final : cal_solver {
         }
       }
       // the matrix-core form first (float32, blocks of at most kMmMaxVec vectors), each list heaviest first
-      auto on_mfma = [&](int head) { return std::is_same<T, float>::value && sorted[head].nvec <= kMmMaxVec && (1 << sorted[head].fb_log2) >= kMmStrip; };
+      // (rows padded to a multiple of 128 channels -- any band of more than 64: its waves take an even number of 16-channel strips each)
+      auto on_mfma = [&](int head) {
+        return std::is_same<T, float>::value && sorted[head].nvec <= kMmMaxVec && (1 << sorted[head].fb_log2) >= kMmStrip && fpad % 128 == 0;
+      };
       std::stable_sort(h_heads.begin(), h_heads.end(), [&](int a, int b) {
         const bool ma = on_mfma(a), mb = on_mfma(b);
         if (ma != mb) return ma;

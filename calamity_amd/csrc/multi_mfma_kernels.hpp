@@ -53,7 +53,7 @@ inline size_t multi_mfma_lds_bytes(int nvec_max) {
   return 256 + 64 + nt * 4 * 64 * 4 + 4 * nt * 16 * 16 * 4 + 4 * 16 * kMmGvPitch * 4;  // members, loss partials, coefficient operand, four strips, four gbar_v buffers
 }
 
-template <int MODE, int NT>
+template <int MODE, int NT, int DEPTH>
 __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const Item& it, int item_idx, unsigned char* smem) {
   constexpr bool GRAD = MODE == MODE_GRAD;
   constexpr int NS = 4 * NT;   // forward k-steps (four vectors each), run as two interleaved accumulator chains
@@ -100,6 +100,12 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   __syncthreads();
 
   const float* s_cl = s_c + lane;
+  constexpr bool CREG = NT <= 7;  // the coefficient operand of all k-steps in registers
+  float creg[CREG ? NS : 1];
+  if (CREG) {
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) creg[s2] = s_cl[s2 * 64];
+  }
   // LDS strip: word address of (row, ch) = row * 16 + (((ch >> 2) ^ (2 * ((row >> 3) & 1))) << 2) + (ch & 3)
   float* s_w0 = s_strip + kq * 16 + col;                                     // store of step s with (s & 2) == 0: row 4 s + kq, channel col
   float* s_w1 = s_strip + kq * 16 + ((((col >> 2) ^ 2) << 2) | (col & 3));   // ... with (s & 2) != 0 (rows 8..15 of a 16-row group)
@@ -108,7 +114,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   float* s_gw = s_gv + m_a * kMmGvPitch + col;                                                  // E: column m_a (+ i, + 8 + i), channel col
   const mm_f32x4* s_gr = reinterpret_cast<const mm_f32x4*>(s_gv + col * kMmGvPitch + 4 * kq);   // B: column col, channels 4 kq ..
 
-  const int njobs = A.fpad >> 6;  // strips per wave (fpad is a multiple of 128)
+  const int njobs = A.fpad >> 6;  // strips per wave: even, the host gives this kernel only rows padded to a multiple of 128 channels
   // The tile loads are buffer loads: resource = this item's tiles, per-lane offset `lo` (one VGPR for the whole kernel), the
   // k-step's offset in an SGPR -- no vector-ALU address arithmetic (with flat pointers hipcc spent a 64-bit vector add per load).
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.tiles + it.tile_first), 0, 0x7fffffff, 0x00020000);
@@ -116,22 +122,25 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   const unsigned lo = ((unsigned)kq * FB + (unsigned)col) * 4u;  // byte offset of this lane's element inside a k-step
   const unsigned step_bytes = FB * 16u;                          // four rows
   // Software pipeline.  A wave keeps about 48 tile loads (12 KB) in flight at all times: the k-step registers form a ring that
-  // is DEPTH jobs deep (2 for blocks of at most 96 vectors, else 1), and F re-issues each register -- for the job DEPTH ahead --
+  // is DEPTH jobs deep (4 up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads), and F re-issues each register -- for the job DEPTH ahead --
   // right behind the MFMA that consumed it, so loads are issued in the order they are consumed and the compiler's counted waits
   // never drain the queue.  The samples of job n + 1 are requested at the START of job n (two register sets, the job loop is
   // unrolled by two), i.e. ahead of the tile loads F issues: waiting for them in E never waits for younger tile loads.
   // The loop body has NO branch: behind a conditional prefetch the counted waits must hold for the path that issued nothing,
   // and every wait for the samples also waited for the whole next tile.  Past the last job the loads therefore still run, with
   // a zero k-step stride on the last job's first rows (one cached kilobyte), and the last job's samples are requested again.
-  constexpr int DEPTH = NT <= 6 ? 2 : 1;
+  // job n of wave w -> strip w + 4 n: the four waves of the workgroup read the four neighbouring 64-byte pieces of the same rows.
+  // (Giving one wave the two halves of a 128-byte line in consecutive jobs raised the L2 hits from 15 M to 52 M per launch and
+  // changed neither the fabric traffic nor the time for the better: 1.36 against 1.30 ms.)
+  auto strip_of = [&](int n) -> unsigned { return (unsigned)(wave + 4 * n); };
   float treg[DEPTH][NS];
   auto job_off = [&](int n) -> unsigned {
-    const unsigned ch = (unsigned)(wave + 4 * (n < njobs ? n : njobs - 1)) * kMmStrip;
+    const unsigned ch = strip_of(n < njobs ? n : njobs - 1) * kMmStrip;
     return (ch >> fb_log2) * tile_bytes + (ch & (FB - 1)) * 4u;
   };
   struct Samples { float dr[2], di[2], w[2]; mm_f32x2 g0[2], g1[2]; };  // this lane's two members at its channel
   auto issue_samples = [&](int n, Samples& S) {
-    const unsigned ch = (unsigned)(wave + 4 * (n < njobs ? n : njobs - 1)) * kMmStrip;
+    const unsigned ch = strip_of(n < njobs ? n : njobs - 1) * kMmStrip;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       S.dr[i] = A.data_r[so[i] + ch];
@@ -147,35 +156,57 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   for (int t = 0; t < NT; ++t) dC[t] = mm_f32x4{0.f, 0.f, 0.f, 0.f};
   double loss_acc = 0.0;
 
+#ifdef CAL_MM_STAMP
+  long long t_bar = 0, t_f = 0, t_e = 0, t_b = 0, t_prev = 0;
+#define MM_STAMP(ACC) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); ACC += t_now - t_prev; t_prev = t_now; }
+#else
+#define MM_STAMP(ACC)
+#endif
   // one job: samples S (requested one job ago), ring set D; requests the next job's samples into Sn
   auto job = [&](int n, float (&tr)[NS], const Samples& S, Samples& Sn) {
+    MM_STAMP(t_b)
     __syncthreads();  // keeps the four waves on neighbouring strips of the same rows (3-4 % faster than letting them drift)
+    MM_STAMP(t_bar)
     issue_samples(n + 1, Sn);
     __builtin_amdgcn_sched_barrier(0);
     // ---- F: two accumulator chains (40-cycle dependent latency against a 32-cycle issue); each register goes back out for job n + DEPTH
     const unsigned nxt_off = job_off(n + DEPTH);
     const unsigned nxt_step = n + DEPTH < njobs ? step_bytes : 0u;
     mm_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // One fenced group per pair of k-steps: the coefficient read of the pair after next, two MFMAs, their strip store, the two
-    // re-issued loads.  (Left alone -- also with sched_group_barrier hints -- the scheduler holds the loads back and sends them
-    // in a burst at the end of F: the queue ran down to a third of its depth in every job.)
-    float bq[3][2];
-    bq[0][0] = s_cl[0];
-    bq[0][1] = s_cl[64];
-    if (NS > 2) {
-      bq[1][0] = s_cl[2 * 64];
-      bq[1][1] = s_cl[3 * 64];
+    // One fenced group per pair of k-steps: two MFMAs, their strip store, the two re-issued loads.  (Left alone -- also with
+    // sched_group_barrier hints -- the scheduler holds the loads back and sends them in a burst at the end of F: the queue ran
+    // down to a third of its depth in every job.)  The coefficient operand is the same for all jobs of an item: up to 112
+    // vectors it lives in registers (creg); wider blocks read it from LDS four groups ahead -- LDS operations complete in order,
+    // so a wait for the read of group p also waits for the strip stores and reads issued since, and a two-group lead left about
+    // a hundred cycles of LDS latency exposed in every group.
+    constexpr int kLead = 4;
+    float bq[kLead + 1][2];
+    if (!CREG) {
+#pragma unroll
+      for (int g = 0; g < kLead; ++g)
+        if (2 * g < NS) {
+          bq[g][0] = s_cl[(2 * g) * 64];
+          bq[g][1] = s_cl[(2 * g + 1) * 64];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < NS; s += 2) {
       const int p = s >> 1;
-      if (s + 4 < NS) {
-        bq[(p + 2) % 3][0] = s_cl[(s + 4) * 64];
-        bq[(p + 2) % 3][1] = s_cl[(s + 5) * 64];
+      float c0, c1;
+      if (CREG) {
+        c0 = creg[s];
+        c1 = creg[s + 1];
+      } else {
+        if (s + 2 * kLead < NS) {
+          bq[(p + kLead) % (kLead + 1)][0] = s_cl[(s + 2 * kLead) * 64];
+          bq[(p + kLead) % (kLead + 1)][1] = s_cl[(s + 2 * kLead + 1) * 64];
+        }
+        c0 = bq[p % (kLead + 1)][0];
+        c1 = bq[p % (kLead + 1)][1];
       }
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[p % 3][0], tr[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[p % 3][1], tr[s + 1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0, tr[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1, tr[s + 1], acc1, 0, 0, 0);
       if (GRAD) {  // steps s, s + 1 (s even) lie in the same 8-row group
         float* w = (s & 2) ? s_w1 : s_w0;
         w[s * 64] = tr[s];
@@ -187,9 +218,10 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
     }
     __builtin_amdgcn_sched_barrier(0);
     mm_f32x4 acc = acc0 + acc1;            // acc[r] of lane (ch, q) = v(channel ch) of column 4 q + r
+    MM_STAMP(t_f)
     // ---- E: v_permlane32_swap hands each lane the missing part of the two members it evaluates (the lower lane's acc[i] and
     // the upper lane's acc[i + 2] stay, the other two registers cross): (re, im) of member m_a + i on both lanes, no selects
-    const unsigned ch0 = (unsigned)(wave + 4 * n) * kMmStrip;
+    const unsigned ch0 = strip_of(n) * kMmStrip;
     float lossj = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -219,6 +251,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
       }
     }
     loss_acc += (double)lossj;
+    MM_STAMP(t_e)
 
     // ---- B: gradient tiles in pairs (independent accumulators back to back)
     if (GRAD) {
@@ -255,11 +288,30 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
     for (int s = 0; s < NS; ++s) treg[d][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lo, off + (unsigned)s * step_bytes, CAL_MM_NT));
   }
   __builtin_amdgcn_sched_barrier(0);
-  for (int n = 0; n < njobs; n += 2) {  // njobs is even
-    job(n, treg[0], SA, SB);
-    job(n + 1, treg[DEPTH - 1], SB, SA);
+#ifdef CAL_MM_STAMP
+  t_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  if (DEPTH == 4) {
+    for (int n = 0; n < njobs; n += 4) {  // njobs is a multiple of 4 (the dispatch picks DEPTH 2 otherwise)
+      job(n, treg[0], SA, SB);
+      job(n + 1, treg[1 % DEPTH], SB, SA);
+      job(n + 2, treg[2 % DEPTH], SA, SB);
+      job(n + 3, treg[3 % DEPTH], SB, SA);
+    }
+  } else {
+    for (int n = 0; n < njobs; n += 2) {  // njobs is even
+      job(n, treg[0], SA, SB);
+      job(n + 1, treg[DEPTH - 1], SB, SA);
+    }
   }
 
+#ifdef CAL_MM_STAMP
+  {
+    MM_STAMP(t_b)
+    if (GRAD && (blockIdx.x % 997) == 13 && lane == 0)
+      printf("stamp item %d NT %d wave %d jobs %d: barrier %lld F %lld E %lld B %lld (s_memtime ticks, 100 MHz)\n", item_idx, NT, wave, njobs, t_bar, t_f, t_e, t_b);
+  }
+#endif
   // ---- epilogue: loss partial of the item (all members), coefficient gradients of every member
   const double ls = ldsum(loss_acc);
   if (lane == 0) s_red[wave] = ls;
@@ -301,21 +353,23 @@ __global__ __launch_bounds__(kThreads, 2) void fused_multi_mfma_kernel(const Fus
   const int item_idx = A.heads[blockIdx.x];
   const Item it = A.items[item_idx];
   if (A.state->done | A.state->done_after) return;
+  // the ring of tile registers is 4 jobs deep up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads (7 to 14 KB) in flight per wave
+  const bool quad = ((A.fpad >> 6) & 3) == 0;  // a wave's jobs come in fours
   switch ((it.nvec + 15) >> 4) {  // wave-uniform
-    case 1: multi_mfma_item<MODE, 1>(A, it, item_idx, smem); break;
-    case 2: multi_mfma_item<MODE, 2>(A, it, item_idx, smem); break;
-    case 3: multi_mfma_item<MODE, 3>(A, it, item_idx, smem); break;
-    case 4: multi_mfma_item<MODE, 4>(A, it, item_idx, smem); break;
-    case 5: multi_mfma_item<MODE, 5>(A, it, item_idx, smem); break;
-    case 6: multi_mfma_item<MODE, 6>(A, it, item_idx, smem); break;
-    case 7: multi_mfma_item<MODE, 7>(A, it, item_idx, smem); break;
-    case 8: multi_mfma_item<MODE, 8>(A, it, item_idx, smem); break;
-    case 9: multi_mfma_item<MODE, 9>(A, it, item_idx, smem); break;
-    case 10: multi_mfma_item<MODE, 10>(A, it, item_idx, smem); break;
-    case 11: multi_mfma_item<MODE, 11>(A, it, item_idx, smem); break;
-    case 12: multi_mfma_item<MODE, 12>(A, it, item_idx, smem); break;
-    case 13: multi_mfma_item<MODE, 13>(A, it, item_idx, smem); break;
-    case 14: multi_mfma_item<MODE, 14>(A, it, item_idx, smem); break;
+    case 1: if (quad) multi_mfma_item<MODE, 1, 4>(A, it, item_idx, smem); else multi_mfma_item<MODE, 1, 2>(A, it, item_idx, smem); break;
+    case 2: if (quad) multi_mfma_item<MODE, 2, 4>(A, it, item_idx, smem); else multi_mfma_item<MODE, 2, 2>(A, it, item_idx, smem); break;
+    case 3: if (quad) multi_mfma_item<MODE, 3, 4>(A, it, item_idx, smem); else multi_mfma_item<MODE, 3, 2>(A, it, item_idx, smem); break;
+    case 4: multi_mfma_item<MODE, 4, 2>(A, it, item_idx, smem); break;
+    case 5: multi_mfma_item<MODE, 5, 2>(A, it, item_idx, smem); break;
+    case 6: multi_mfma_item<MODE, 6, 2>(A, it, item_idx, smem); break;
+    case 7: multi_mfma_item<MODE, 7, 2>(A, it, item_idx, smem); break;
+    case 8: multi_mfma_item<MODE, 8, 1>(A, it, item_idx, smem); break;
+    case 9: multi_mfma_item<MODE, 9, 1>(A, it, item_idx, smem); break;
+    case 10: multi_mfma_item<MODE, 10, 1>(A, it, item_idx, smem); break;
+    case 11: multi_mfma_item<MODE, 11, 1>(A, it, item_idx, smem); break;
+    case 12: multi_mfma_item<MODE, 12, 1>(A, it, item_idx, smem); break;
+    case 13: multi_mfma_item<MODE, 13, 1>(A, it, item_idx, smem); break;
+    case 14: multi_mfma_item<MODE, 14, 1>(A, it, item_idx, smem); break;
     default: break;  // the host gives this kernel no wider block
   }
 }

@@ -209,6 +209,26 @@ def test_slices_that_share_only_some_tiles():
     check(prob, start, layouts=("stream",))
 
 
+@pytest.mark.parametrize("nfreqs", [24, 64, 65])
+def test_slices_that_share_tiles_of_a_narrow_band(nfreqs):
+    """Bands of at most 64 channels are padded to 8 ... 64 channels, not to a multiple of 128: the matrix-core multi-slice kernel
+    (whose waves take 16-channel strips in pairs) must leave them to fused_multi_kernel; 65 channels are the first it takes."""
+    from calamity_amd import distributed as D
+
+    nvecs = [3, 20, min(nfreqs, 50)]
+    base, _ = random_problem(nvecs, [1] * len(nvecs), nants=6, nfreqs=nfreqs, seed=80)
+    parts = []
+    for t in range(5):
+        p, st = random_problem(nvecs, [1] * len(nvecs), nants=6, nfreqs=nfreqs, seed=81 + t)
+        p.basis, p.grp_basis = base.basis, base.grp_basis
+        p.bl_ant0, p.bl_ant1, p.bl_rowblk = base.bl_ant0, base.bl_ant1, base.bl_rowblk
+        p.wgts = p.wgts / 5
+        parts.append((p, st))
+    prob, start = D.batch_time_slices(parts)
+    prob.sky_r, prob.sky_i = np.concatenate([p.sky_r for p, _ in parts]), np.concatenate([p.sky_i for p, _ in parts])
+    check(prob, start, layouts=("stream",), regs=(False,))
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_randomly_drawn_problems(seed):
     """Seeded random problems over the corners the fixed cases above do not name: 2 antennas, 1 to 5 channels, channel counts

@@ -16,3 +16,11 @@ for c in sq tcc fetch write; do
   cp gpurun_out/${r}_dense_f32/pmc/${c}_counter_collection.csv profiles/${r}_dense_f32_pmc_${c}_counter_collection.csv
   cp gpurun_out/${r}_dense_f64/pmc/${c}_counter_collection.csv profiles/${r}_dense_f64_pmc_${c}_counter_collection.csv
 done
+if [ -d gpurun_out/${r}_multi ]; then
+  cp gpurun_out/${r}_multi/trace/multi_kernel_stats.csv profiles/${r}_multi_rank_of_8_kernel_stats.csv
+  for c in sq lds tcc ea fetch write tcp; do
+    [ -f gpurun_out/${r}_multi/pmc/${c}_counter_collection.csv ] && cp gpurun_out/${r}_multi/pmc/${c}_counter_collection.csv profiles/${r}_multi_pmc_${c}_counter_collection.csv
+  done
+  [ -f gpurun_out/${r}_multi/summary.log ] && cp gpurun_out/${r}_multi/summary.log profiles/${r}_multi_rank_of_8_summary.log
+fi
+true

@@ -24,7 +24,7 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $out/pmc -o write --output-forma
 timeout -k 10 200 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum -d $out/pmc -o tcp --output-format csv -- $cmd > $out/pmc_tcp.log 2>&1 || echo "tcp pass failed"
 echo "fetch/write done"
 grep -h "fused_multi\|gain_grad\|adam2" $out/trace/*kernel_stats.csv | cut -c1-200
-python3 - "$out" <<'PY'
+python3 - "$out" <<'PY' | tee $out/summary.log
 import csv, glob, collections, sys, os
 out = sys.argv[1]
 for f in sorted(glob.glob(os.path.join(out, "pmc", "*_counter_collection.csv"))):
