@@ -1,3 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:?}"
-timeout -k 10 900 python3 -m pytest tests/test_gpu_shapes.py tests/test_gpu_config3.py tests/test_gpu_distributed.py tests/test_gpu_exchange_hook.py -q -x > gpurun_out/xt.log 2>&1; rc=$?; echo "tests rc $rc"; tail -3 gpurun_out/xt.log | cut -c1-250
+bash tools/prof_round.sh r03_final > gpurun_out/xa.log 2>&1; echo "prof_round rc $?"; tail -1 gpurun_out/xa.log | cut -c1-300
+bash tools/prof_dense.sh r03_dense_f32 f32 > gpurun_out/xb.log 2>&1; echo "prof_dense f32 rc $?"; tail -1 gpurun_out/xb.log | cut -c1-300
+bash tools/prof_dense.sh r03_dense_f64 f64 > gpurun_out/xc.log 2>&1; echo "prof_dense f64 rc $?"; tail -1 gpurun_out/xc.log | cut -c1-300
+bash tools/prof_multi.sh r03_multi > gpurun_out/xd.log 2>&1; echo "prof_multi rc $?"; tail -3 gpurun_out/xd.log | cut -c1-400
