@@ -89,7 +89,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("fit_kernels.hpp", "dense_kernels.hpp", "dense64_kernels.hpp", "calamity_hip.hip"):
+    for name in ("fit_kernels.hpp", "dense_kernels.hpp", "dense64_kernels.hpp", "multi_mfma_kernels.hpp", "calamity_hip.hip"):
         with open(os.path.join(ROOT, "calamity_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

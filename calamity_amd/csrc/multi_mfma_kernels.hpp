@@ -39,9 +39,6 @@ typedef float mm_f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CAL_MM_NT
 #define CAL_MM_NT 0  // cache policy of the tile loads (2 = non-temporal: measured 20 % slower -- the two halves of a 128-byte line are read by neighbouring waves, and the second one should still find it in L2)
 #endif
-#ifndef CAL_MM_NT
-#define CAL_MM_NT 0  // cache policy of the tile loads (2 = non-temporal: measured 20 % slower -- the two halves of a 128-byte line are read by neighbouring waves, and the second one should still find it in L2)
-#endif
 constexpr int kMmStrip = 16;               // channels of a wave's job
 constexpr int kMmMaxVec = 224;             // widest block this kernel takes (wider ones: fused_multi_kernel)
 constexpr int kMmTiles = kMmMaxVec / 16;   // gradient tiles of 16 vectors = classes of the item body
@@ -60,8 +57,8 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 15;   // MFMA column: member col & 7, re (col < 8) | im
-  const int kq = lane >> 4;    // the k of a step this lane feeds; the channel quad it holds in the accumulator
+  const int col = lane & 15;   // index inside a row of 16 lanes: the CHANNEL of the strip (tile operand, accumulator, E), the MFMA column (coefficient operand, B)
+  const int kq = lane >> 4;    // the k of a step this lane feeds; the quad of columns 4 kq .. 4 kq + 3 it holds in the accumulator
   const int nvec = it.nvec;
   const int NB = it.role_n >> 2;
   const int fb_log2 = it.fb_log2;
@@ -121,7 +118,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   const unsigned tile_bytes = (unsigned)nvec << (fb_log2 + 2);
   const unsigned lo = ((unsigned)kq * FB + (unsigned)col) * 4u;  // byte offset of this lane's element inside a k-step
   const unsigned step_bytes = FB * 16u;                          // four rows
-  // Software pipeline.  A wave keeps about 48 tile loads (12 KB) in flight at all times: the k-step registers form a ring that
+  // Software pipeline.  A wave keeps 28 to 56 tile loads (7 to 14 KB) in flight at all times: the k-step registers form a ring that
   // is DEPTH jobs deep (4 up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads), and F re-issues each register -- for the job DEPTH ahead --
   // right behind the MFMA that consumed it, so loads are issued in the order they are consumed and the compiler's counted waits
   // never drain the queue.  The samples of job n + 1 are requested at the START of job n (two register sets, the job loop is
