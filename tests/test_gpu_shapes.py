@@ -209,6 +209,38 @@ def test_slices_that_share_only_some_tiles():
     check(prob, start, layouts=("stream",))
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_randomly_drawn_slices_that_share_tiles(seed):
+    """Seeded random batches of time slices: 2 to 10 slices, 1 to 224 (and a few more) vectors per block, bands whose padded rows
+    give a wave 2, 4, 6, 8 or 16 strips (the deep tile-register rings need a multiple of 4 and fall back otherwise), a random part
+    of the alias table switched off -- float32 loss and gradients of the matrix-core multi-slice kernel against the C restatement,
+    float64 for the vector-ALU form."""
+    from calamity_amd import distributed as D
+
+    rng = np.random.default_rng(3000 + seed)
+    nslices = int(rng.integers(2, 11))
+    nfreqs = int(rng.choice([65, 128, 200, 256, 300, 384, 500, 1000]))
+    ngrps = int(rng.integers(1, 7))
+    nvecs = [int(rng.integers(1, min(nfreqs, 240) + 1)) for _ in range(ngrps)]
+    nants = int(rng.integers(3, 10))
+    base, _ = random_problem(nvecs, [1] * ngrps, nants=nants, nfreqs=nfreqs, seed=3100 + seed)
+    parts = []
+    for t in range(nslices):
+        p, st = random_problem(nvecs, [1] * ngrps, nants=nants, nfreqs=nfreqs, seed=3200 + 16 * seed + t)
+        p.basis, p.grp_basis = base.basis, base.grp_basis
+        p.bl_ant0, p.bl_ant1, p.bl_rowblk = base.bl_ant0, base.bl_ant1, base.bl_rowblk
+        p.wgts = p.wgts / nslices
+        parts.append((p, st))
+    prob, start = D.batch_time_slices(parts)
+    if seed % 2:
+        alias = prob.bl_alias.copy()
+        off = rng.random(alias.size) < 0.2
+        alias[off] = -1
+        prob.bl_alias = alias
+    prob.sky_r, prob.sky_i = np.concatenate([p.sky_r for p, _ in parts]), np.concatenate([p.sky_i for p, _ in parts])
+    check(prob, start, layouts=("stream",), regs=(False,))
+
+
 @pytest.mark.parametrize("nfreqs", [24, 64, 65])
 def test_slices_that_share_tiles_of_a_narrow_band(nfreqs):
     """Bands of at most 64 channels are padded to 8 ... 64 channels, not to a multiple of 128: the matrix-core multi-slice kernel
