@@ -16,6 +16,7 @@ CAL_LAYOUT_STREAM, CAL_LAYOUT_SHARED = 0, 1
 CAL_PATH_AUTO, CAL_PATH_GENERAL, CAL_PATH_DENSE = 0, 1, 2
 CAL_LAUNCH_AUTO, CAL_LAUNCH_KERNELS, CAL_LAUNCH_ONE_TAIL, CAL_LAUNCH_GRAPH = 0, 1, 2, 3
 CAL_COMM_ID_BYTES = 128
+CAL_MAX_SLICES = 256
 CAL_ERR_NONFINITE = -6
 
 
@@ -38,6 +39,8 @@ class ProblemDesc(C.Structure):
         ("layout", C.c_int32),
         ("kernel_path", C.c_int32),
         ("bl_alias", C.c_void_p),
+        ("nslices", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -67,7 +70,7 @@ class RunDesc(C.Structure):
 
 
 class RunResult(C.Structure):
-    _fields_ = [("nrecorded", C.c_int32), ("stopped", C.c_int32), ("nupdates", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("nrecorded", C.c_int32), ("stopped", C.c_int32), ("nupdates", C.c_int32), ("nonfinite", C.c_int32)]
 
 
 class KernelTiming(C.Structure):
@@ -96,6 +99,7 @@ SYMBOLS = {
     "cal_solver_set_problem": (C.c_int, [_P, C.POINTER(ProblemDesc)]),
     "cal_solver_set_data": (C.c_int, [_P, _P, _P, _P]),
     "cal_solver_set_regularization": (C.c_int, [_P, C.c_int, C.c_double, C.c_double]),
+    "cal_solver_set_regularization_slices": (C.c_int, [_P, C.c_int, _P, _P]),
     "cal_solver_set_optimizer": (C.c_int, [_P, C.POINTER(OptimizerDesc)]),
     "cal_solver_set_params": (C.c_int, [_P, _P, _P, _P, _P]),
     "cal_solver_get_params": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
@@ -103,7 +107,9 @@ SYMBOLS = {
     "cal_solver_set_moments": (C.c_int, [_P] + [_P] * 8 + [C.c_int64]),
     "cal_solver_eval_loss": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "cal_solver_eval_grads": (C.c_int, [_P, C.POINTER(C.c_double), _P, _P, _P, _P]),
+    "cal_solver_get_slice_losses": (C.c_int, [_P, _P]),
     "cal_solver_run": (C.c_int, [_P, C.POINTER(RunDesc), _P, C.POINTER(RunResult)]),
+    "cal_solver_run_slices": (C.c_int, [_P, C.POINTER(RunDesc), _P, C.POINTER(RunResult)]),
     "cal_solver_model": (C.c_int, [_P, _P, _P]),
     "cal_solver_init_coeffs": (C.c_int, [_P, _P, _P]),
     "cal_solver_synchronize": (C.c_int, [_P]),

@@ -195,7 +195,7 @@ def tensorize_data(
         vis, flg = vis3(np.asarray(uvdata.data_array)), vis3(np.asarray(uvdata.flag_array))
         nsm = vis3(np.asarray(uvdata.nsample_array)) if nsamples_in_weights else None
         wts = vis3(np.asarray(weights.weights_array)) if weights is not None else None
-        sums = []
+        row_sums = np.zeros(ngrps * nbls, dtype=np.float64)  # per baseline: the total below does not depend on how the rows are chunked
 
         def rows_chunk(lo, hi):
             # gather + scale + split of a run of baselines (memory-bound NumPy passes: one thread per run, utils.for_row_chunks)
@@ -220,10 +220,10 @@ def tensorize_data(
             if ns is not None:
                 ww = ww * ns
             w[lo:hi] = ww
-            sums.append(float(np.sum(w[lo:hi], dtype=np.float64)))
+            row_sums[lo:hi] = np.sum(w[lo:hi], axis=1, dtype=np.float64)
 
         utils.for_row_chunks(rows_chunk, ngrps * nbls)
-        wgtsum += float(np.sum(sums))
+        wgtsum += float(np.sum(row_sums))
         data_r.append(d_r.reshape(ngrps, nbls, nf))
         data_i.append(d_i.reshape(ngrps, nbls, nf))
         wgts.append(w.reshape(ngrps, nbls, nf))
@@ -290,7 +290,10 @@ def get_solver(fg_model_comps, dtype=np.float32, layout=None, device=None):
     """The HipFitSolver that holds these components on the GPU (created once per component set and dtype)."""
     dtype = np.dtype(dtype)
     cache = fg_model_comps.__dict__.setdefault("_solvers", {})
-    layout = layout or os.environ.get("CALAMITY_AMD_LAYOUT", "shared")
+    # (a caller's explicit choice -- calibrate_and_model_tensor(layout=..., devices=[...]) -- travels with the components)
+    layout = layout or fg_model_comps.__dict__.get("_layout") or os.environ.get("CALAMITY_AMD_LAYOUT", "shared")
+    if device is None:
+        device = fg_model_comps.__dict__.get("_device")
     if device is None:
         device = _DEVICE["index"] if _DEVICE["index"] is not None else int(os.environ.get("CALAMITY_AMD_DEVICE", "0"))
     # one solver per calling thread: a handle is not re-entrant, and concurrent fits of different (pol, time) slices
@@ -540,17 +543,29 @@ def calibrate_and_model_tensor(
     skip_threshold=0.5,
     use_model_snr_weights=False,
     parallel_fits=None,
+    batch_slices=None,
+    devices=None,
+    layout=None,
     **opt_kwargs,
 ):
     """Simultaneous calibration and foreground fitting -- calibration.py:963-1331, same arguments, defaults and
     returns ``(model, resid, gains, fit_history)``.  See SURVEY.md Appendix A for the behaviours kept (the input
     ``uvdata`` is not modified; a supplied ``gains`` object IS modified in place and returned).
 
-    ``parallel_fits`` (not in the reference; default 1, or the environment variable CALAMITY_AMD_PARALLEL_FITS) fits that
-    many (polarization, time) slices concurrently, each on its own solver and HIP stream.  The slices are independent
-    fits unless ``init_guesses_from_previous_time_step`` is set (then this is ignored), every kernel is deterministic, so
-    the results are identical to the sequential loop; small arrays, whose steps are launch-latency bound, gain almost
-    linearly."""
+    Not in the reference (which loops over polarizations and times, one fit after the other on one device, :1160-1167):
+
+    * ``batch_slices`` (default: on whenever the slices are independent, i.e. unless ``init_guesses_from_previous_time_step``):
+      all unskipped (polarization, time) slices of the call -- ``batch_slices=N``: at most N at a time -- are fitted TOGETHER
+      in one solver per device: one pass over the modeling components serves every slice, while each slice keeps its own
+      rms scale, weight normalisation, priors, loss history, tolerance stop and use_min snapshot, exactly as in the loop
+      (``batched.SliceBatchFitter``).  ``fit_history`` and every output equal those of the sequential loop (to rounding:
+      the same kernels in the same order).  ``batch_slices=False`` keeps the loop.
+    * ``devices``: GPUs to fit on (list of device indices; default: every visible device when the call is large enough
+      to pay for an exchange per step, else the device selected for the process).  With several, each device takes a
+      share of the fitting groups of every slice; the caller's process drives them all.
+    * ``layout``: "shared" (default; baselines alias the distinct basis blocks) or "stream" (every baseline owns its tiles).
+    * ``parallel_fits`` (default 1): with ``batch_slices=False``, fits that many slices concurrently, each on its own
+      solver and HIP stream."""
     antpairs_data = uvdata.get_antpairs()
     if not include_autos:
         antpairs_data = set([ap for ap in antpairs_data if ap[0] != ap[1]])
@@ -593,6 +608,24 @@ def calibrate_and_model_tensor(
     if init_guesses_from_previous_time_step:
         parallel_fits = 1
     times = np.unique(uvdata.time_array)
+    if batch_slices is None:
+        batch_slices = parallel_fits <= 1
+    if init_guesses_from_previous_time_step:
+        batch_slices = False  # every time starts from the previous one's result: a chain, not a batch
+    if batch_slices:
+        max_batch = _lib_max_slices() if batch_slices is True else max(1, min(int(batch_slices), _lib_max_slices()))
+        fit_history = _fit_slices_batched(
+            uvdata=uvdata, sky_model=sky_model, gains=gains, resid=resid, model=model, prob=prob, corr_inds=corr_inds, ants_map=ants_map,
+            times=times, weights=weights, nsamples_in_weights=nsamples_in_weights, dtype=dtype, skip_threshold=skip_threshold,
+            use_model_snr_weights=use_model_snr_weights, optimizer=optimizer, use_min=use_min, freeze_model=freeze_model, tol=tol,
+            maxsteps=maxsteps, n_profile_steps=n_profile_steps, profile_log_dir=profile_log_dir, model_regularization=model_regularization,
+            verbose=verbose, max_batch=max_batch, devices=devices, layout=layout, opt_kwargs=opt_kwargs,
+        )
+        return _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, correct_resid)
+    if layout is not None:
+        prob.__dict__["_layout"] = layout
+    if devices is not None:
+        prob.__dict__["_device"] = int(list(devices)[0])  # the loop fits on one device
 
     def fit_slice(polnum, pol, time_index, time, carry):
         """One (polarization, time) slice: calibration.py:1167-1330.  ``carry`` holds the parameters handed from one time
@@ -688,6 +721,11 @@ def calibrate_and_model_tensor(
         fit_history[polnum] = fit_history_p
     if pool is not None:
         pool.shutdown()
+    return _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, correct_resid)
+
+
+def _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, correct_resid):
+    """Residual and model in the requested calibration state -- calibration.py:1322-1331."""
     model_with_gains = cal_utils.apply_gains(model, gains, inverse=True)
     if not correct_model:
         model = model_with_gains
@@ -699,15 +737,186 @@ def calibrate_and_model_tensor(
     return model, resid, gains, fit_history
 
 
+def _lib_max_slices():
+    from . import _lib
+
+    return _lib.CAL_MAX_SLICES
+
+
+def _default_devices(nsamples_per_step):
+    """Devices of a batched fit when the caller names none: every visible GPU once a train step touches enough samples to
+    pay for an exchange per step (about a microsecond of kernel time per 10^4 samples against ~50 us of all-reduce), else the
+    one device selected for the process (read_calibrate_and_model_dpss: calibration.py:1741-1753)."""
+    from . import _lib
+
+    first = _DEVICE["index"] if _DEVICE["index"] is not None else int(os.environ.get("CALAMITY_AMD_DEVICE", "0"))
+    n = _lib.device_count()
+    if n > 1 and _DEVICE["index"] is None and nsamples_per_step >= 2.0e7:
+        return list(range(n))
+    return [first]
+
+
+def _batch_fitter(prob, nt, dtype, layout, devices):
+    """The SliceBatchFitter of ``nt`` slices of these components (kept with them: a second call re-uses the device copy)."""
+    from .batched import SliceBatchFitter
+
+    cache = prob.__dict__.setdefault("_batch_fitters", {})
+    key = (np.dtype(dtype).str, layout, tuple(devices), int(nt), threading.get_ident())
+    if key not in cache:
+        for k in [k for k in cache if k[:3] == key[:3] and k[4] == key[4]]:  # another batch size of the same call: free it first
+            cache.pop(k).close()
+        fitter = SliceBatchFitter(prob, nt, dtype=dtype, layout=layout, devices=devices)
+        limit = _DEVICE["memory_limit_gib"]
+        if limit is not None and fitter.memory_bytes() > limit * 2.0**30:
+            used = fitter.memory_bytes() / 2.0**30
+            fitter.close()
+            raise MemoryError(f"the fit needs {used:.2f} GiB of device memory, gpu_memory_limit is {limit} GiB")
+        cache[key] = fitter
+    return cache[key]
+
+
+def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds, ants_map, times, weights, nsamples_in_weights, dtype,
+                        skip_threshold, use_model_snr_weights, optimizer, use_min, freeze_model, tol, maxsteps, n_profile_steps,
+                        profile_log_dir, model_regularization, verbose, max_batch, devices, layout, opt_kwargs):
+    """The pol x time loop of calibration.py:1160-1320 with the fits of all unskipped slices issued as batches: per slice
+    exactly the host-side steps of the loop body (skip test :1173-1177, rms scale :1178-1182, tensorize :1184-1233, write-back
+    :1271-1300, post-hoc renormalisation :1311-1319), the gradient descent of :1244-1269 for up to ``max_batch`` slices at once
+    with per-slice loop control.  Returns ``fit_history``."""
+    OPTIMIZERS[optimizer]  # unknown optimizer -> KeyError, like calibration.py:571
+    dtype = np.dtype(dtype)
+    layout = layout or os.environ.get("CALAMITY_AMD_LAYOUT", "shared")
+    pols = list(uvdata.get_pols())
+    fit_history = {polnum: {} for polnum in range(len(pols))}
+    todo = []
+    for polnum, pol in enumerate(pols):
+        for time_index, time in enumerate(times):
+            bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
+            unflagged = ~vis3(uvdata.flag_array)[bltsel, :, polnum]
+            frac_unflagged = np.count_nonzero(unflagged) / (uvdata.Nbls * uvdata.Nfreqs)
+            if frac_unflagged < skip_threshold:
+                echo(f"{datetime.datetime.now()}: Only {frac_unflagged * 100}-percent of data unflagged. Skipping...\n", verbose=verbose)
+                flag_poltime(resid, time=time, polarization=pol)
+                flag_poltime(gains, time=time, polarization=pol)
+                flag_poltime(model, time=time, polarization=pol)
+                continue
+            rmsdata = np.sqrt(np.mean(np.abs(vis3(uvdata.data_array)[bltsel, :, polnum][unflagged]) ** 2.0))
+            todo.append(dict(polnum=polnum, pol=pol, time_index=time_index, time=time, rmsdata=rmsdata, bltsel=bltsel))
+    if devices is None:
+        devices = _default_devices(float(min(len(todo), max_batch)) * prob.nbls * prob.nfreqs)
+    for lo in range(0, len(todo), max_batch):
+        batch = todo[lo : lo + max_batch]
+        nt = len(batch)
+        echo(f"{datetime.datetime.now()} Working on {nt} (polarization, time) slices together...\n", verbose=verbose)
+        d_r, d_i, w, s_r, s_i, g_r, g_i = [], [], [], [], [], [], []
+        for sl in batch:
+            data_r, data_i, wgts = tensorize_data(
+                uvdata, corr_inds=corr_inds, ants_map=ants_map, polarization=sl["pol"], time=sl["time"], data_scale_factor=sl["rmsdata"],
+                weights=weights, nsamples_in_weights=nsamples_in_weights, dtype=dtype,
+            )
+            d_r.append(_flatten(data_r, prob))
+            d_i.append(_flatten(data_i, prob))
+            w.append(_flatten(wgts, prob))
+            if sky_model is not None:
+                sky_r, sky_i, _ = tensorize_data(
+                    sky_model, corr_inds=corr_inds, ants_map=ants_map, polarization=sl["pol"], time=sl["time"],
+                    data_scale_factor=sl["rmsdata"], weights=weights, dtype=dtype,
+                )
+                s_r.append(_flatten(sky_r, prob))
+                s_i.append(_flatten(sky_i, prob))
+            a, b = tensorize_gains(gains, dtype=dtype, time=sl["time"], polarization=sl["pol"])
+            g_r.append(a)
+            g_i.append(b)
+        fitter = _batch_fitter(prob, nt, dtype, layout, devices)
+        cat = np.concatenate
+        w_all = cat(w)
+        zeros = np.zeros_like(w_all)
+        # tensorize_fg_coeffs x 2 (calibration.py:1219-1233) for every slice: one device pass gives both components
+        fitter.set_data(zeros, zeros, w_all)
+        del zeros
+        fitter.init_coeffs(cat(s_r), cat(s_i))
+        _, _, c_r, c_i = fitter.get_params()
+        if _gram_factors(prob):
+            c_r, c_i = _gram_solve(prob, c_r, c_i, nt)
+            fitter.set_params(c_r=c_r, c_i=c_i)
+        if use_model_snr_weights:
+            m_r, m_i = fitter.model()
+            w_new = (np.square(m_r.astype(np.float64)) + np.square(m_i.astype(np.float64))) * w_all
+            for t in range(nt):  # renormalised slice by slice (:1235-1242)
+                rows = slice(t * prob.nbls, (t + 1) * prob.nbls)
+                w_new[rows] /= np.sum(w_new[rows])
+            w_all = w_new.astype(dtype)
+        fitter.set_data(cat(d_r), cat(d_i), w_all)
+        fitter.set_params(cat(g_r), cat(g_i), c_r, c_i)
+        if model_regularization == "sum":
+            # priors of calibration.py:619-625, one pair per slice (accumulated in float64 on the host)
+            w64 = w_all.astype(np.float64).reshape(nt, -1)
+            fitter.set_regularization("sum", np.sum(cat(s_r).reshape(nt, -1) * w64, axis=1), np.sum(cat(s_i).reshape(nt, -1) * w64, axis=1))
+        else:
+            fitter.set_regularization(None)
+        fitter.set_optimizer(optimizer, **opt_kwargs)
+        if n_profile_steps > 0:
+            fitter.timing_enable(True)
+            fitter.run_slices(n_profile_steps, record=False, freeze_model=freeze_model)
+            os.makedirs(profile_log_dir, exist_ok=True)
+            with open(os.path.join(profile_log_dir, f"calamity_amd_profile_{datetime.datetime.now():%Y%m%d_%H%M%S_%f}.json"), "w") as f:
+                json.dump(dict(n_profile_steps=n_profile_steps, slices=nt, fused_basis_kernel=fitter.timing_get()), f)
+            fitter.timing_enable(False)
+        fitter.run_slices(1, record=False, freeze_model=freeze_model)  # the unrecorded step of calibration.py:693
+        results = fitter.run_slices(maxsteps, record=True, tol=tol, use_min=use_min, freeze_model=freeze_model)
+        cur = fitter.get_params(0)
+        best = fitter.get_params(1) if use_min and any(len(r[0]) for r in results) else None
+        if freeze_model:
+            cm_r, cm_i = c_r, c_i  # the coefficients the fit was handed (:730-732)
+        else:
+            cm_r, cm_i = np.array(cur[2]), np.array(cur[3])
+        gm_r, gm_i = np.array(cur[0]), np.array(cur[1])
+        for t, res in enumerate(results):
+            if best is not None and len(res[0]):  # the slice's own minimum (:702-710, :724-728)
+                ga, gb = slice(t * prob.nants, (t + 1) * prob.nants), slice(t * prob.ncoeffs, (t + 1) * prob.ncoeffs)
+                gm_r[ga], gm_i[ga] = best[0][ga], best[1][ga]
+                if not freeze_model:
+                    cm_r[gb], cm_i[gb] = best[2][gb], best[3][gb]
+        # yield_fg_model_array x 2 + insert_model_into_uvdata_tensor (:1271-1292) for every slice from one A c pass
+        fitter.set_params(c_r=cm_r, c_i=cm_i)
+        m_r, m_i = fitter.model()
+        for t, (sl, res) in enumerate(zip(batch, results)):
+            rows, ga = slice(t * prob.nbls, (t + 1) * prob.nbls), slice(t * prob.nants, (t + 1) * prob.nants)
+            _insert_model_rows(model, sl["time"], sl["pol"], ants_map, prob, m_r[rows], m_i[rows], scale_factor=sl["rmsdata"])
+            insert_gains_into_uvcal(uvcal=gains, time=sl["time"], polarization=sl["pol"], gains_re=gm_r[ga], gains_im=gm_i[ga])
+            fit_history[sl["polnum"]][sl["time_index"]] = {"loss": [dtype.type(l) for l in res[0]]}
+            if res[1]:
+                echo(f"Tolerance thresshold met for time {sl['time_index']}. Terminating...\n ", verbose=verbose)
+    if not freeze_model and model_regularization == "post_hoc":
+        for polnum, pol in enumerate(pols):
+            for time in times:
+                bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
+                if np.any(~model.flag_array[bltsel]):
+                    renormalize(uvdata_reference_model=sky_model, uvdata_deconv=model, gains=gains, polarization=pol, time=time,
+                                additional_flags=uvdata.flag_array)
+    return fit_history
+
+
+def _gram_solve(prob, c_r, c_i, nt=1):
+    """The per-group Gram solves of _init_coeffs for ``nt`` slices of flat coefficients."""
+    c_r = np.asarray(c_r, dtype=np.float64).copy()
+    c_i = np.asarray(c_i, dtype=np.float64).copy()
+    coff = prob.grp_coff
+    for (u, rbs), (gram, grps) in _gram_factors(prob).items():
+        for t in range(nt):
+            idx = t * prob.ncoeffs + coff[grps][None, :] + np.arange(gram.shape[0])[:, None]
+            c_r[idx] = np.linalg.solve(gram, c_r[idx])
+            c_i[idx] = np.linalg.solve(gram, c_i[idx])
+    return c_r, c_i
+
+
 def _blank_copy(uvdata):
     """A copy of ``uvdata`` with all-zero visibilities and no flags (the reference deep-copies, then clears, :1113-1116),
-    without copying the arrays that are about to be overwritten."""
+    without copying the arrays that are about to be overwritten -- and without touching the input, which other holders of
+    the object may be reading: the deep copy is told that the two big arrays are already copied (the memo maps them to
+    placeholders), then fresh zero arrays are attached."""
     data, flags = uvdata.data_array, uvdata.flag_array
-    try:
-        uvdata.data_array = uvdata.flag_array = None
-        out = copy.deepcopy(uvdata)
-    finally:
-        uvdata.data_array, uvdata.flag_array = data, flags
+    hold_d, hold_f = np.zeros(0, dtype=np.asarray(data).dtype), np.zeros(0, dtype=bool)
+    out = copy.deepcopy(uvdata, {id(data): hold_d, id(flags): hold_f})
     out.data_array = np.zeros_like(data)
     out.flag_array = np.zeros_like(flags)
     return out

@@ -149,7 +149,9 @@ struct cal_solver {
   int dtype = CAL_F32;
   virtual int set_problem(const cal_problem_desc* d) = 0;
   virtual int set_data(const void* dr, const void* di, const void* w) = 0;
-  virtual int set_regularization(int mode, double pr, double pi) = 0;
+  virtual int set_regularization(int mode, const double* pr, const double* pi, bool per_slice) = 0;
+  virtual int slice_count() = 0;
+  virtual int get_slice_losses(double* out) = 0;
   virtual int set_optimizer(const cal_optimizer_desc* d) = 0;
   virtual int set_params(const void* g_r, const void* g_i, const void* c_r, const void* c_i) = 0;
   virtual int get_params(int which, void* g_r, void* g_i, void* c_r, void* c_i) = 0;
@@ -158,7 +160,7 @@ struct cal_solver {
   virtual int set_moments(const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i, const void* cm_r,
                           const void* cm_i, const void* cv_r, const void* cv_i, int64_t t) = 0;
   virtual int eval(bool grads, double* loss, void* gg_r, void* gg_i, void* gc_r, void* gc_i) = 0;
-  virtual int run(const cal_run_desc* r, double* losses_out, cal_run_result* res) = 0;
+  virtual int run(const cal_run_desc* r, double* losses_out, cal_run_result* res, bool per_slice) = 0;
   virtual int model(void* mr, void* mi) = 0;
   virtual int init_coeffs(const void* sr, const void* si) = 0;
   virtual int synchronize() = 0;
@@ -177,6 +179,11 @@ struct SolverT final : cal_solver {
   bool has_problem = false, has_data = false, has_gains = false, has_coef = false, has_opt = false;
   // problem
   int nants = 0, nfreqs = 0, fpad = 0, ngrps = 0, nbls = 0, ncoef = 0, nitems = 0, layout = 0;
+  // time slices (cal_problem_desc::nslices): independent fits held together; slice t owns antennas [t na_slice, (t + 1) na_slice),
+  // a contiguous run of the coefficient planes, its own loop state (state[par][t]), reduced sums (scal[4 t ..]) and loss history
+  int nslices = 1, na_slice = 0;
+  DevBuf slice_coff, slice_ipart_ptr, slice_ipart_idx, slice_ppart_ptr, slice_ppart_idx, slice_cblk;
+  std::vector<int> h_slice_coff, h_slice_cblk;
   int nitems_simple = 0;   // items [0, nitems_simple) are single-baseline groups (fused_basis_kernel), the rest multi-baseline (fused_group_kernel)
   int nitems_plain = 0;    // items [0, nitems_plain) of those are not covered by a head item of the multi-slice kernels
   size_t lds_group_bytes = 0;
@@ -192,7 +199,7 @@ struct SolverT final : cal_solver {
   DevBuf gains_alt;                            // one-launch tail (step_tail_kernel): gains are read from one buffer and written to the other; `gains` is always the current one
   DevBuf coef, coef_m, coef_v, coef_snap;      // [2][ncoef] T (r plane then i plane)
   DevBuf q0, q1, comm;                         // comm: r0 | r1 | r2 (gain gradient parts), contiguous for the all-reduce
-  DevBuf scal;                                 // 4 doubles: loss, s_r, s_i
+  DevBuf scal;                                 // [nslices] x 4 doubles: loss, s_r, s_i, spare
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
   DevBuf members, heads;                       // baselines that share tiles (bl_alias): member lists of the head items, head item indices
@@ -220,14 +227,28 @@ struct SolverT final : cal_solver {
     }
   } graph_key{};
   DevBuf agree_buf;
-  DevState* h_state = nullptr;                 // pinned mirror
-  int st_par = 0;                              // which half of `state` is current
-  DevState* st_cur() { return state.as<DevState>() + st_par; }
-  DevState* st_nxt() { return state.as<DevState>() + (st_par ^ 1); }
+  DevState* h_state = nullptr;                 // pinned mirror: [nslices]
+  int h_state_cap = 0;
+  int st_par = 0;                              // which half of `state` ([2][nslices]) is current
+  DevState* st_cur() { return state.as<DevState>() + (size_t)st_par * nslices; }
+  DevState* st_nxt() { return state.as<DevState>() + (size_t)(st_par ^ 1) * nslices; }
+  std::vector<double> prior_r_t, prior_i_t;    // per slice
+  // which slice every kernel's work belongs to (fit_kernels.hpp: SliceMap); the loss partials are per item (general kernels) or
+  // per panel (dense kernels)
+  SliceMap smap(bool panels) const {
+    SliceMap m{};
+    m.coff = slice_coff.as<int>();
+    m.nslices = nslices;
+    m.na_slice = na_slice;
+    if (nslices > 1) {
+      m.part_ptr = (panels ? slice_ppart_ptr : slice_ipart_ptr).template as<int>();
+      m.part_idx = (panels ? slice_ppart_idx : slice_ipart_idx).template as<int>();
+    }
+    return m;
+  }
   // settings
   cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7, 0.9, 0.0, 0.1, 0, 0};
   int reg = CAL_REG_NONE;
-  double prior_r = 0, prior_i = 0;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -261,11 +282,35 @@ struct SolverT final : cal_solver {
   int init() {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc((void**)&h_state, sizeof(DevState), hipHostMallocDefault));
-    memset(h_state, 0, sizeof(DevState));
-    CAL_TRY(state.alloc(2 * sizeof(DevState)));  // double-buffered: see step_update_kernel
-    CAL_TRY(scal.alloc(4 * sizeof(double)));
+    CAL_TRY(size_state(1));
     return CAL_OK;
+  }
+  // loop state, reduced sums and their host mirror for n time slices (a new problem may change the count)
+  int size_state(int n) {
+    if (n > h_state_cap) {
+      if (h_state) (void)hipHostFree(h_state);
+      h_state = nullptr;
+      h_state_cap = 0;
+      HIP_TRY(hipHostMalloc((void**)&h_state, (size_t)n * sizeof(DevState), hipHostMallocDefault));
+      h_state_cap = n;
+    }
+    memset(h_state, 0, (size_t)n * sizeof(DevState));
+    CAL_TRY(state.alloc(2 * (size_t)n * sizeof(DevState)));  // double-buffered: see step_update_kernel
+    CAL_TRY(scal.alloc(4 * (size_t)n * sizeof(double)));
+    st_par = 0;
+    prior_r_t.assign(n, 0.0);
+    prior_i_t.assign(n, 0.0);
+    for (int t = 0; t < n; ++t) reset_loop_state(h_state[t]);
+    return CAL_OK;
+  }
+  static void reset_loop_state(DevState& h) {  // a new fit begins: loop state of calibration.py:573-574
+    h.t = 0;
+    h.b1t = h.b2t = 1.0;
+    h.nadam_sched = 1.0;
+    h.min_loss = 9e99;
+    h.prev_loss = 0;
+    h.n_recorded_total = 0;
+    h.nonfinite = 0;
   }
 
   static int choose_fb(int nvec, int nfreqs) {
@@ -394,6 +439,32 @@ struct SolverT final : cal_solver {
       if (d->bl_ant0[b] < 0 || d->bl_ant0[b] >= nants || d->bl_ant1[b] < 0 || d->bl_ant1[b] >= nants)
         return fail(CAL_ERR_INVALID, "set_problem: baseline %d has an antenna index outside [0, %d)", b, nants);
     }
+    // ---- time slices: independent fits over disjoint antenna ranges, listed slice by slice
+    const int NSL = d->nslices > 1 ? d->nslices : 1;
+    if (NSL > CAL_MAX_SLICES) return fail(CAL_ERR_UNSUPPORTED, "set_problem: %d time slices; at most %d are supported", NSL, CAL_MAX_SLICES);
+    if (nants % NSL != 0) return fail(CAL_ERR_INVALID, "set_problem: nants = %d is not a multiple of nslices = %d", nants, NSL);
+    const int nas = nants / NSL;
+    std::vector<int> grp_slice(ngrps, 0);
+    if (NSL > 1) {
+      std::vector<char> seen(NSL, 0);
+      for (int g = 0; g < ngrps; ++g) {
+        const int b0 = d->grp_bl_start[g], b1 = d->grp_bl_start[g + 1];
+        if (b0 < 0 || b1 > nbls || b1 <= b0) return fail(CAL_ERR_INVALID, "set_problem: group %d has no baselines", g);
+        const int t = d->bl_ant0[b0] / nas;
+        for (int b = b0; b < b1; ++b)
+          if (d->bl_ant0[b] / nas != t || d->bl_ant1[b] / nas != t)
+            return fail(CAL_ERR_INVALID, "set_problem: baseline %d of group %d leaves time slice %d (antennas %d, %d; %d antennas per slice)", b, g, t,
+                        d->bl_ant0[b], d->bl_ant1[b], nas);
+        if (g > 0 && t < grp_slice[g - 1]) return fail(CAL_ERR_INVALID, "set_problem: fitting groups must be listed slice by slice (group %d)", g);
+        grp_slice[g] = t;
+        seen[t] = 1;
+      }
+      for (int t = 0; t < NSL; ++t)
+        if (!seen[t]) return fail(CAL_ERR_INVALID, "set_problem: time slice %d has no fitting group", t);
+    }
+    nslices = NSL;
+    na_slice = nas;
+    CAL_TRY(size_state(NSL));
     // ---- groups, coefficient offsets
     h_grp_coff.assign(ngrps + 1, 0);
     std::vector<int> grp_of_bl(nbls);
@@ -409,13 +480,19 @@ struct SolverT final : cal_solver {
       }
     }
     ncoef = h_grp_coff[ngrps];
+    h_slice_coff.assign(nslices + 1, ncoef);
+    h_slice_coff[0] = 0;
+    for (int g = ngrps - 1; g >= 0; --g) h_slice_coff[grp_slice[g]] = h_grp_coff[g];  // first group of every slice
+    h_slice_coff[0] = 0;
+    CAL_TRY(slice_coff.alloc((nslices + 1) * sizeof(int), false));
+    HIP_TRY(hipMemcpy(slice_coff.p, h_slice_coff.data(), (nslices + 1) * sizeof(int), hipMemcpyHostToDevice));
     // ---- baselines that read another baseline's tiles (STREAM layout): the same physical baseline in several time slices
     std::vector<int> alias_root(nbls, -1);  // -1: owns its tiles
     if (d->bl_alias && layout == CAL_LAYOUT_STREAM) {
       for (int b = 0; b < nbls; ++b) {
         const int r = d->bl_alias[b];
         if (r < 0 || r == b) continue;
-        if (r >= nbls || d->bl_alias[r] >= 0 && d->bl_alias[r] != r)
+        if (r >= nbls || (d->bl_alias[r] >= 0 && d->bl_alias[r] != r))
           return fail(CAL_ERR_INVALID, "set_problem: bl_alias[%d] = %d must name a baseline that owns its tiles", b, r);
         const int g = grp_of_bl[b], gr = grp_of_bl[r];
         if (d->grp_basis[g] != d->grp_basis[gr] || (d->bl_rowblk ? d->bl_rowblk[b] != d->bl_rowblk[r] : false))
@@ -428,7 +505,7 @@ struct SolverT final : cal_solver {
     std::vector<char> in_alias_set(nbls, 0);
     const bool multi_ok = (long long)(nbls + 1) * fpad < (1LL << 31) && (long long)nants * fpad < (1LL << 31);  // the multi kernel's 32-bit sample offsets
     for (int b = 0; b < nbls; ++b)
-      if (alias_root[b] >= 0 && multi_ok) in_alias_set[b] = in_alias_set[alias_root[b]] = 1;
+      if (alias_root[b] >= 0 && multi_ok) in_alias_set[b] = in_alias_set[alias_root[b]] = 1;  // (slices_share_heads: see below)
 
     // ---- unique basis blocks -> tile-major device layout
     const long long raw_elems = d->basis_offset[nbasis];
@@ -509,11 +586,12 @@ struct SolverT final : cal_solver {
                              raw.as<float>() + d->basis_offset[u], mf_ops.as<float>() + okf4[u], nfreqs, fpad, d->basis_nvec[u], nvp32[u]);
         HIP_TRY(hipGetLastError());
         // panels of kPanel baselines with the same basis, heaviest first
-        std::vector<std::vector<int>> by_u(nbasis);
-        for (int b = 0; b < nbls; ++b) by_u[d->grp_basis[grp_of_bl[b]]].push_back(b);
-        std::vector<int> uorder(nbasis);
+        // (a panel never mixes time slices: one loop state, one alpha per panel)
+        std::vector<std::vector<int>> by_u((size_t)nbasis * nslices);
+        for (int b = 0; b < nbls; ++b) by_u[(size_t)d->grp_basis[grp_of_bl[b]] * nslices + grp_slice[grp_of_bl[b]]].push_back(b);
+        std::vector<int> uorder((size_t)nbasis * nslices);
         std::iota(uorder.begin(), uorder.end(), 0);
-        std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
+        std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a / nslices] > d->basis_nvec[b / nslices]; });
         // Panels of more than four vector tiles first, then the rest (two bodies of ONE launch); inside a class the
         // heaviest panels come first (the hardware dispatches workgroups in index order, so the tail is made of the lightest).
         // Per-XCD panel lists (all panels of a basis block on one XCD, its packed operands L2-resident there: the L2 hit
@@ -521,11 +599,13 @@ struct SolverT final : cal_solver {
         // kernel: panels of one block then walk the same lines in step.
         std::vector<PanelItem> h_panels;
         std::vector<double> h_cost;
-        for (int u : uorder) {
-          for (size_t i = 0; i < by_u[u].size(); i += kPanel) {
+        for (int us : uorder) {
+          const int u = us / nslices;
+          for (size_t i = 0; i < by_u[us].size(); i += kPanel) {
             PanelItem pi{};
+            pi.slice = us % nslices;
             for (int k = 0; k < kPanel; ++k) {
-              const int b = i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+              const int b = i + k < by_u[us].size() ? by_u[us][i + k] : -1;
               pi.bl[k] = b;
               pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
               pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
@@ -562,19 +642,21 @@ struct SolverT final : cal_solver {
           hipLaunchKernelGGL(mfma_pack64_kernel, dim3(grid_for(okf[u + 1] - okf[u])), dim3(256), 0, stream,
                              raw.as<double>() + d->basis_offset[u], mf_ops.as<double>() + okf[u], nfreqs, fpad, d->basis_nvec[u]);
         HIP_TRY(hipGetLastError());
-        std::vector<std::vector<int>> by_u(nbasis);
-        for (int b = 0; b < nbls; ++b) by_u[d->grp_basis[grp_of_bl[b]]].push_back(b);
-        std::vector<int> uorder(nbasis);
+        std::vector<std::vector<int>> by_u((size_t)nbasis * nslices);
+        for (int b = 0; b < nbls; ++b) by_u[(size_t)d->grp_basis[grp_of_bl[b]] * nslices + grp_slice[grp_of_bl[b]]].push_back(b);
+        std::vector<int> uorder((size_t)nbasis * nslices);
         std::iota(uorder.begin(), uorder.end(), 0);
-        std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a] > d->basis_nvec[b]; });
+        std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a / nslices] > d->basis_nvec[b / nslices]; });
         std::vector<PanelItem> h_panels;
         std::vector<double> h_cost;
-        for (int u : uorder) {
+        for (int us : uorder) {
+          const int u = us / nslices;
           const int width = d->basis_nvec[u] > 128 ? 8 : 16;
-          for (size_t i = 0; i < by_u[u].size(); i += width) {
+          for (size_t i = 0; i < by_u[us].size(); i += width) {
             PanelItem pi{};
+            pi.slice = us % nslices;
             for (int k = 0; k < kPanel; ++k) {
-              const int b = k < width && i + k < by_u[u].size() ? by_u[u][i + k] : -1;
+              const int b = k < width && i + k < by_u[us].size() ? by_u[us][i + k] : -1;
               pi.bl[k] = b;
               pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
               pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
@@ -657,7 +739,7 @@ struct SolverT final : cal_solver {
       it.nvec = d->basis_nvec[u];
       it.coff = h_grp_coff[g];
       it.fb_log2 = fl;
-      it.pad = g;
+      it.slice = grp_slice[g];
       if (d->grp_bl_start[g + 1] - d->grp_bl_start[g] == 1) {
         const long long nt = ntpb;
         // (a baseline that shares tiles stays ONE item: the multi kernel writes the whole coefficient gradient of its group)
@@ -748,7 +830,28 @@ struct SolverT final : cal_solver {
       sorted[q].goff = h_item_goff[order[q]];
       sorted[q].role_n = 0;
       sorted[q].member0 = 0;
-      sorted[q].pad = 0;
+    }
+    // the loss partials (one per item) of every time slice, in item order
+    if (nslices > 1) {
+      std::vector<int> ptr(nslices + 1, 0), idx(nitems);
+      for (int q = 0; q < nitems; ++q) ptr[sorted[q].slice + 1]++;
+      for (int t = 0; t < nslices; ++t) ptr[t + 1] += ptr[t];
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+      for (int q = 0; q < nitems; ++q) idx[fill[sorted[q].slice]++] = q;
+      CAL_TRY(slice_ipart_ptr.alloc(ptr.size() * sizeof(int), false));
+      HIP_TRY(hipMemcpy(slice_ipart_ptr.p, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+      CAL_TRY(slice_ipart_idx.alloc(idx.size() * sizeof(int), false));
+      HIP_TRY(hipMemcpy(slice_ipart_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    // coefficient blocks of step_tail_kernel: every slice gets its own (a block works for ONE slice's decisions)
+    h_slice_cblk.assign(nslices + 1, 0);
+    for (int t = 0; t < nslices; ++t) {
+      const long long nb = (2LL * (h_slice_coff[t + 1] - h_slice_coff[t]) + 255) / 256;
+      h_slice_cblk[t + 1] = h_slice_cblk[t] + (int)std::max<long long>(1, std::min<long long>(nb, std::max(1, 4096 / nslices)));
+    }
+    if (nslices > 1) {
+      CAL_TRY(slice_cblk.alloc((nslices + 1) * sizeof(int), false));
+      HIP_TRY(hipMemcpy(slice_cblk.p, h_slice_cblk.data(), (nslices + 1) * sizeof(int), hipMemcpyHostToDevice));
     }
     // ---- sets of baselines that share tiles -> head items with member lists (at most MultiCfg<T>::nb_max baselines each)
     nheads = 0;
@@ -780,6 +883,8 @@ struct SolverT final : cal_solver {
             m.goff = sorted[q].goff;
             m.ant0 = d->bl_ant0[b];
             m.ant1 = d->bl_ant1[b];
+            m.slice = sorted[q].slice;
+            m.item = q;
             h_members.push_back(m);
           }
         }
@@ -925,6 +1030,18 @@ struct SolverT final : cal_solver {
       for (size_t j = 0; j < lists[x].size(); ++j) h_map[j * 8 + x] = lists[x][j];
     mf_npanels = n;
     mf_grid = (int)h_map.size();
+    if (nslices > 1) {  // the loss partials (one per panel) of every time slice, in panel order
+      std::vector<int> ptr(nslices + 1, 0), idx(n);
+      for (int i = 0; i < n; ++i) ptr[panels[i].slice + 1]++;
+      for (int t = 0; t < nslices; ++t) ptr[t + 1] += ptr[t];
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+      for (int i = 0; i < n; ++i) idx[fill[panels[i].slice]++] = i;
+      CAL_TRY(slice_ppart_ptr.alloc(ptr.size() * sizeof(int), false));
+      HIP_TRY(hipMemcpyAsync(slice_ppart_ptr.p, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+      CAL_TRY(slice_ppart_idx.alloc(idx.size() * sizeof(int), false));
+      HIP_TRY(hipMemcpyAsync(slice_ppart_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipStreamSynchronize(stream));  // (the vectors leave scope)
+    }
     CAL_TRY(mf_panels.alloc((size_t)n * sizeof(PanelItem), false));
     HIP_TRY(hipMemcpyAsync(mf_panels.p, panels.data(), (size_t)n * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
     CAL_TRY(mf_map.alloc(h_map.size() * sizeof(int), false));
@@ -1016,20 +1133,30 @@ struct SolverT final : cal_solver {
     return CAL_OK;
   }
 
-  int set_regularization(int mode, double pr, double pi) override {
+  int set_regularization(int mode, const double* pr, const double* pi, bool per_slice) override {
     HIP_TRY(hipSetDevice(device));
     if (!has_problem) return fail(CAL_ERR_STATE, "set_regularization before set_problem");
     if (mode != CAL_REG_NONE && mode != CAL_REG_SUM) return fail(CAL_ERR_INVALID, "set_regularization: unknown mode %d", mode);
+    if (!pr || !pi) return fail(CAL_ERR_INVALID, "set_regularization: null priors");
     if (mode != reg && nheads > 0) HIP_TRY(hipMemsetAsync(part.p, 0, part.bytes, stream));  // member items write their slot only in the regularised form
     if (mode != reg) drop_graph();
     reg = mode;
-    prior_r = pr;
-    prior_i = pi;
+    for (int t = 0; t < nslices; ++t) {
+      prior_r_t[t] = pr[per_slice ? t : 0];
+      prior_i_t[t] = pi[per_slice ? t : 0];
+    }
     if (reg == CAL_REG_SUM) {
       if (!q1.p) CAL_TRY(q1.alloc((size_t)(nbls + 1) * fpad * sizeof(T2)));
       if (!gcp1.p) CAL_TRY(gcp1.alloc(2 * (size_t)gcp_len * sizeof(T)));
       if (!gc_direct && !gc1.p) CAL_TRY(gc1.alloc(2 * (size_t)ncoef * sizeof(T)));
     }
+    return CAL_OK;
+  }
+  int slice_count() override { return nslices; }
+  int get_slice_losses(double* out) override {
+    if (!has_problem) return fail(CAL_ERR_STATE, "get_slice_losses before set_problem");
+    if (!out) return fail(CAL_ERR_INVALID, "get_slice_losses: null");
+    for (int t = 0; t < nslices; ++t) out[t] = h_state[t].loss;
     return CAL_OK;
   }
 
@@ -1054,14 +1181,7 @@ struct SolverT final : cal_solver {
       HIP_TRY(hipMemsetAsync(coef_v.p, 0, coef_v.bytes, stream));
     }
     drop_graph();
-    // a new fit begins: loop state of calibration.py:573-574
-    h_state->t = 0;
-    h_state->b1t = h_state->b2t = 1.0;
-    h_state->nadam_sched = 1.0;
-    h_state->min_loss = 9e99;
-    h_state->prev_loss = 0;
-    h_state->n_recorded_total = 0;
-    h_state->nonfinite = 0;
+    for (int t = 0; t < nslices; ++t) reset_loop_state(h_state[t]);  // a new fit begins
     has_opt = true;
     HIP_TRY(hipStreamSynchronize(stream));
     return CAL_OK;
@@ -1133,16 +1253,18 @@ struct SolverT final : cal_solver {
     if (cv_i) HIP_TRY(hipMemcpy(coef_v.as<T>() + ncoef, cv_i, cb, hipMemcpyHostToDevice));
     // beta^t as the device keeps it: a running product, one factor per update (pow() differs from it in the last bits, and a
     // resumed fit must continue bit for bit).  Uses the betas of the optimizer set so far: set_optimizer comes first.
-    h_state->t = t;
     double b1t = 1.0, b2t = 1.0, sched = 1.0;
     for (int64_t k = 0; k < t; ++k) {
       b1t *= opt.beta_1;
       b2t *= opt.beta_2;
       sched *= opt.beta_1 * (1.0 - 0.5 * std::pow(0.96, 0.004 * (double)(k + 1)));  // Nadam's momentum schedule (advance_state)
     }
-    h_state->b1t = b1t;
-    h_state->b2t = b2t;
-    h_state->nadam_sched = sched;
+    for (int sl = 0; sl < nslices; ++sl) {
+      h_state[sl].t = t;
+      h_state[sl].b1t = b1t;
+      h_state[sl].b2t = b2t;
+      h_state[sl].nadam_sched = sched;
+    }
     return CAL_OK;
   }
 
@@ -1169,6 +1291,7 @@ struct SolverT final : cal_solver {
     a.model_r = nullptr;
     a.model_i = nullptr;
     a.state = st_cur();
+    a.nslices = nslices;
     a.fpad = fpad;
     a.nbls = nbls;
     a.runs = runs.as<int2>();
@@ -1265,16 +1388,17 @@ struct SolverT final : cal_solver {
         m.gc_i = grad_c0() + ncoef;
         m.part = part.as<double>();
         m.state = st;
+        m.nslices = nslices;
         m.fpad = fpad;
         m.nbls = nbls;
         m.use_alpha = 0;
         if (two_pass) {
           launch_dense<false>(m);
-          hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
+          hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(nslices), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                              ant_ptr.as<int>(), ant_ent.as<int2>(), comm.as<T2>(), comm.as<T2>(), comm.as<T2>(), 0, fpad, part.as<double>(),
-                             mf_npanels, scal.as<double>(), st);
-          if (comm_on()) CAL_TRY(all_reduce(scal.p, 4, CAL_XCHG_F64, CAL_XCHG_SUM));
-          hipLaunchKernelGGL(alpha_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>());
+                             mf_npanels, scal.as<double>(), st, smap(true));
+          if (comm_on()) CAL_TRY(all_reduce(scal.p, 4 * (size_t)nslices, CAL_XCHG_F64, CAL_XCHG_SUM));
+          hipLaunchKernelGGL(alpha_kernel, dim3((nslices + 63) / 64), dim3(64), 0, stream, st, scal.as<double>(), nslices);
           m.use_alpha = 1;
         }
         if (grads) launch_dense<true>(m); else launch_dense<false>(m);
@@ -1283,6 +1407,7 @@ struct SolverT final : cal_solver {
       if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
     }
     const int n_parts = use_mfma ? mf_npanels : nitems;
+    const SliceMap sm = smap(use_mfma);
     if (timing) HIP_TRY(hipEventRecord(e1, stream));
     if (one_launch_tail) {
       HIP_TRY(hipGetLastError());
@@ -1297,26 +1422,26 @@ struct SolverT final : cal_solver {
       if (!gc_direct && !use_mfma && !fused_tail) {
         hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
                            gcp0.as<T>() + gcp_len, gc0.as<T>(), gc0.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
-                           grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
+                           grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st, sm);
         if (Rk)
           hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp1.as<T>(),
                              gcp1.as<T>() + gcp_len, gc1.as<T>(), gc1.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
-                             grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st);
+                             grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st, sm);
       }
       const int cpl = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;
-      const int nb = nants * ((fpad + 64 * cpl - 1) / (64 * cpl)) + 1;
+      const int nb = nants * ((fpad + 64 * cpl - 1) / (64 * cpl)) + nslices;  // + one block per slice: its loss partial sums
       if (Rk)
         hipLaunchKernelGGL((gain_grad_kernel<T, true>), dim3(nb), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                            ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), n_parts,
-                           scal.as<double>(), st);
+                           scal.as<double>(), st, sm);
       else
         hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(nb), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
                            ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, nants, fpad, part.as<double>(), n_parts,
-                           scal.as<double>(), st);
+                           scal.as<double>(), st, sm);
     } else {
-      // loss only: just the partial-sum block of the gain kernel (nants = 0 -> no antenna work)
-      hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(1), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
-                         ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, 0, fpad, part.as<double>(), n_parts, scal.as<double>(), st);
+      // loss only: just the partial-sum blocks of the gain kernel (nants = 0 -> no antenna work)
+      hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(nslices), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
+                         ant_ptr.as<int>(), ant_ent.as<int2>(), r0, r1, r2, 0, fpad, part.as<double>(), n_parts, scal.as<double>(), st, sm);
     }
     if (comm_on()) {
       // the one exchange step of the sharded fit: sum gain-gradient parts and loss scalars over ranks
@@ -1325,17 +1450,17 @@ struct SolverT final : cal_solver {
       if (nccl) NCCL_TRY(ncclGroupStart());
       int rc = CAL_OK;
       if (grads) rc = all_reduce(r0, (size_t)(Rk ? 3 : 1) * gn * 2, gdt, CAL_XCHG_SUM);
-      if (rc == CAL_OK) rc = all_reduce(scal.p, 4, CAL_XCHG_F64, CAL_XCHG_SUM);
+      if (rc == CAL_OK) rc = all_reduce(scal.p, 4 * (size_t)nslices, CAL_XCHG_F64, CAL_XCHG_SUM);
       if (nccl) NCCL_TRY(ncclGroupEnd());
       CAL_TRY(rc);
     }
     if (!fused_tail)
-      hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1), 0, stream, st, scal.as<double>(), losses.as<double>(), losses_cap,
-                         apply_update ? 1 : 0);
+      hipLaunchKernelGGL(finalize_kernel, dim3((nslices + 63) / 64), dim3(64), 0, stream, st, scal.as<double>(), losses.as<double>(), losses_cap,
+                         apply_update ? 1 : 0, nslices);
     if (grads && Rk) {
-      hipLaunchKernelGGL(combine_gain_kernel<T>, dim3((int)((gn + 255) / 256)), dim3(256), 0, stream, r0, r1, r2, (int)gn, st);
+      hipLaunchKernelGGL(combine_gain_kernel<T>, dim3((int)((gn + 255) / 256)), dim3(256), 0, stream, r0, r1, r2, (int)gn, st, sm, fpad);
       hipLaunchKernelGGL(combine_coeff_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, grad_c0(), grad_c0() + ncoef,
-                         grad_c1(), grad_c1() + ncoef, ncoef, st);
+                         grad_c1(), grad_c1() + ncoef, ncoef, st, sm);
     }
     HIP_TRY(hipGetLastError());
     return CAL_OK;
@@ -1344,7 +1469,8 @@ struct SolverT final : cal_solver {
   // Small problems (a step of tens of microseconds: HERA-37, the tutorial) gain from one launch instead of three for the
   // tail of a step; with millions of parameters the per-block decision prologue of the fused kernel costs more than the two
   // kernel boundaries it saves (HERA-350: 105 us against 5 + 56 us), so those keep finalize_kernel + adam2_kernel.
-  bool tail_fits_one_launch() const { return 2LL * nants * fpad + 2LL * ncoef <= (1LL << 20); }
+  // (CAL_LAUNCH_KERNELS keeps every kernel its own launch: finalize_kernel + adam2_kernel at any size)
+  bool tail_fits_one_launch() const { return 2LL * nants * fpad + 2LL * ncoef <= (1LL << 20) && launch_mode != CAL_LAUNCH_KERNELS; }
   // Problems whose step is tens of microseconds: the whole tail as ONE launch (step_tail_kernel) -- no communicator (the
   // exchange sits between the reduction and the update), general kernels, and not when every kernel is asked to be its own launch
   bool one_launch_tail() const { return !comm_on() && !mf_ok && tail_fits_one_launch() && launch_mode != CAL_LAUNCH_KERNELS; }
@@ -1383,7 +1509,10 @@ struct SolverT final : cal_solver {
     a.out = st_nxt();
     a.losses = losses.as<double>();
     a.losses_cap = losses_cap;
-    const long long nblk_c = freeze_model ? 0 : std::min<long long>((2LL * ncoef + 255) / 256, 4096);
+    a.M = smap(false);
+    a.cblk_ptr = nslices > 1 ? slice_cblk.as<int>() : nullptr;
+    a.ncoef = ncoef;
+    const long long nblk_c = freeze_model ? 0 : h_slice_cblk[nslices];
     const unsigned grid = (unsigned)(a.nblk_gain + nblk_c);
     launch_tail(a, grid, R);
     st_par ^= 1;
@@ -1407,13 +1536,13 @@ struct SolverT final : cal_solver {
         ps = PartialSum<T>{gcp0.as<T>(), gcp0.as<T>() + gcp_len, coef_grp.as<int>(), grp_coff.as<int>(), grp_item_ptr.as<int>(),
                            item_goff.as<int>(), ncoef};
       const unsigned nb = (unsigned)std::max(1, std::min(nblk_a + nblk_b, 16384));
-      hipLaunchKernelGGL((step_update_kernel<T>), dim3(nb), dim3(256), 0, stream, ga, ca, ps, st, st_nxt(), scal.as<double>(),
-                         losses.as<double>(), losses_cap);
+      hipLaunchKernelGGL((step_update_kernel<T>), dim3(nb), dim3(256), (size_t)nslices * sizeof(SliceStep<T>), stream, ga, ca, ps, st, st_nxt(),
+                         scal.as<double>(), losses.as<double>(), losses_cap, smap(mf_ok), fpad, ncoef);
       st_par ^= 1;
       HIP_TRY(hipGetLastError());
       return CAL_OK;
     }
-    hipLaunchKernelGGL((adam2_kernel<T>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st);
+    hipLaunchKernelGGL((adam2_kernel<T>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st, smap(mf_ok), fpad, ncoef);
     HIP_TRY(hipGetLastError());
     return CAL_OK;
   }
@@ -1463,25 +1592,31 @@ struct SolverT final : cal_solver {
   }
 
   int push_state() {
-    h_state->lr = opt.learning_rate;
-    h_state->beta1 = opt.beta_1;
-    h_state->beta2 = opt.beta_2;
-    h_state->eps = opt.epsilon;
-    h_state->opt = opt.optimizer;
-    h_state->nesterov = opt.nesterov;
-    h_state->momentum = opt.momentum;
-    h_state->rho = opt.rho;
-    h_state->reg = reg == CAL_REG_SUM;
-    h_state->f32 = std::is_same<T, float>::value ? 1 : 0;
-    h_state->prior_r = prior_r;
-    h_state->prior_i = prior_i;
-    HIP_TRY(hipMemcpyAsync(st_cur(), h_state, sizeof(DevState), hipMemcpyHostToDevice, stream));
+    for (int t = 0; t < nslices; ++t) {
+      DevState& h = h_state[t];
+      h.lr = opt.learning_rate;
+      h.beta1 = opt.beta_1;
+      h.beta2 = opt.beta_2;
+      h.eps = opt.epsilon;
+      h.opt = opt.optimizer;
+      h.nesterov = opt.nesterov;
+      h.momentum = opt.momentum;
+      h.rho = opt.rho;
+      h.reg = reg == CAL_REG_SUM;
+      h.f32 = std::is_same<T, float>::value ? 1 : 0;
+      h.prior_r = prior_r_t[t];
+      h.prior_i = prior_i_t[t];
+    }
+    HIP_TRY(hipMemcpyAsync(st_cur(), h_state, (size_t)nslices * sizeof(DevState), hipMemcpyHostToDevice, stream));
     return CAL_OK;
   }
   int pull_state() {
-    HIP_TRY(hipMemcpyAsync(h_state, st_cur(), sizeof(DevState), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_state, st_cur(), (size_t)nslices * sizeof(DevState), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return CAL_OK;
+  }
+  void begin_pass_state() {  // a one-off pass (loss, gradients, model, initial coefficients): no slice is stopped
+    for (int t = 0; t < nslices; ++t) h_state[t].done = h_state[t].done_after = 0;
   }
   int collect_timing() {
     for (size_t i = 0; i < ev_used; ++i) {
@@ -1503,12 +1638,16 @@ struct SolverT final : cal_solver {
   int eval(bool grads, double* loss, void* gg_r, void* gg_i, void* gc_r, void* gc_i) override {
     HIP_TRY(hipSetDevice(device));
     CAL_TRY(ready());
-    h_state->done = h_state->done_after = 0;
+    begin_pass_state();
     CAL_TRY(push_state());
     CAL_TRY(enqueue_pass(grads, false, 0));
     CAL_TRY(pull_state());
     if (timing) CAL_TRY(collect_timing());
-    if (loss) *loss = h_state->loss;
+    if (loss) {  // several time slices: the sum of their losses (cal_solver_get_slice_losses has each)
+      double tot = 0;
+      for (int t = 0; t < nslices; ++t) tot += h_state[t].loss;
+      *loss = tot;
+    }
     if (grads) {
       if (gg_r) CAL_TRY(download_rows(gg_r, comm.as<T>(), nants, 2, 0));
       if (gg_i) CAL_TRY(download_rows(gg_i, comm.as<T>(), nants, 2, 1));
@@ -1518,29 +1657,37 @@ struct SolverT final : cal_solver {
     return CAL_OK;
   }
 
-  int run(const cal_run_desc* r, double* losses_out, cal_run_result* res) override {
+  int run(const cal_run_desc* r, double* losses_out, cal_run_result* res, bool per_slice) override {
     HIP_TRY(hipSetDevice(device));
     CAL_TRY(ready());
     if (!has_opt) return fail(CAL_ERR_STATE, "no optimizer set (cal_solver_set_optimizer)");
     if (!r || r->nsteps < 0) return fail(CAL_ERR_INVALID, "run: bad run description");
-    if (res) memset(res, 0, sizeof(*res));
+    if (!per_slice && nslices > 1)
+      return fail(CAL_ERR_STATE, "run: the solver holds %d time slices, each with its own losses and stopping test: use cal_solver_run_slices", nslices);
+    const int nres = per_slice ? nslices : 1;
+    if (res) memset(res, 0, sizeof(*res) * nres);
     if (r->nsteps == 0) return CAL_OK;
     if (r->use_min && !gains_snap.p) {
       CAL_TRY(gains_snap.alloc(gains.bytes));
       CAL_TRY(coef_snap.alloc(coef.bytes));
     }
-    if (r->record && losses.bytes < (size_t)r->nsteps * sizeof(double)) CAL_TRY(losses.alloc((size_t)r->nsteps * sizeof(double)));
-    if (!losses.p) CAL_TRY(losses.alloc(sizeof(double)));
-    h_state->done = h_state->done_after = 0;
-    h_state->n_recorded = 0;
-    h_state->nupdates = 0;
-    h_state->improved = 0;
-    h_state->record = r->record ? 1 : 0;
-    h_state->use_min = r->use_min ? 1 : 0;
-    h_state->tol = r->tol;
+    const size_t lbytes = (size_t)nslices * r->nsteps * sizeof(double);
+    if (r->record && losses.bytes < lbytes) CAL_TRY(losses.alloc(lbytes));
+    if (!losses.p) CAL_TRY(losses.alloc((size_t)nslices * sizeof(double)));
+    for (int t = 0; t < nslices; ++t) {
+      DevState& h = h_state[t];
+      h.done = h.done_after = 0;
+      h.n_recorded = 0;
+      h.nupdates = 0;
+      h.improved = 0;
+      h.nonfinite = 0;
+      h.record = r->record ? 1 : 0;
+      h.use_min = r->use_min ? 1 : 0;
+      h.tol = r->tol;
+    }
     CAL_TRY(push_state());
-    // steps are enqueued in chunks; the device decides when the loop ends (finalize_kernel) and later steps of a
-    // chunk fall through at once, so the host only synchronises once per chunk instead of once per step (:701)
+    // steps are enqueued in chunks; the device decides when the loop of a slice ends (finalize_kernel) and later steps of a
+    // chunk fall through at once for it, so the host only synchronises once per chunk instead of once per step (:701)
     const int chunk = steps_per_sync;
     const int cap = r->record ? r->nsteps : 0;
     const bool tail1 = one_launch_tail();
@@ -1570,16 +1717,28 @@ struct SolverT final : cal_solver {
       if (mark) roctx().pop();
       CAL_TRY(prc);
       if (timing) CAL_TRY(collect_timing());
-      if (h_state->done || h_state->done_after || h_state->nonfinite) break;
+      bool all_over = true;
+      for (int t = 0; t < nslices; ++t) all_over = all_over && (h_state[t].done || h_state[t].done_after || h_state[t].nonfinite);
+      if (all_over) break;
     }
-    if (res) {
-      res->nrecorded = h_state->n_recorded;
-      res->stopped = (h_state->done || h_state->done_after) && !h_state->nonfinite ? 1 : 0;
-      res->nupdates = h_state->nupdates;
+    int bad = -1;
+    for (int t = 0; t < nslices; ++t) {
+      const DevState& h = h_state[t];
+      if (res && t < nres) {
+        res[t].nrecorded = h.n_recorded;
+        res[t].stopped = (h.done || h.done_after) && !h.nonfinite ? 1 : 0;
+        res[t].nupdates = h.nupdates;
+        res[t].nonfinite = h.nonfinite ? 1 : 0;
+      }
+      if (r->record && losses_out && h.n_recorded > 0)
+        HIP_TRY(hipMemcpy(losses_out + (size_t)t * r->nsteps, losses.as<double>() + (size_t)t * cap,
+                          (size_t)std::min(h.n_recorded, r->nsteps) * sizeof(double), hipMemcpyDeviceToHost));
+      if (h.nonfinite && bad < 0) bad = t;
     }
-    if (r->record && losses_out && h_state->n_recorded > 0)
-      HIP_TRY(hipMemcpy(losses_out, losses.p, (size_t)std::min(h_state->n_recorded, r->nsteps) * sizeof(double), hipMemcpyDeviceToHost));
-    if (h_state->nonfinite) return fail(CAL_ERR_NONFINITE, "loss became non-finite after %d updates", h_state->nupdates);
+    if (bad >= 0) {
+      if (nslices > 1) return fail(CAL_ERR_NONFINITE, "loss of time slice %d became non-finite after %d updates", bad, h_state[bad].nupdates);
+      return fail(CAL_ERR_NONFINITE, "loss became non-finite after %d updates", h_state[bad].nupdates);
+    }
     return CAL_OK;
   }
 
@@ -1589,7 +1748,7 @@ struct SolverT final : cal_solver {
     if (!mr || !mi) return fail(CAL_ERR_INVALID, "model: null output");
     const size_t rowbytes = (size_t)nbls * fpad * sizeof(T);
     if (model_buf.bytes < 2 * rowbytes) CAL_TRY(model_buf.alloc(2 * rowbytes));
-    h_state->done = h_state->done_after = 0;
+    begin_pass_state();
     CAL_TRY(push_state());
     FusedArgs<T> a = fused_args();
     a.model_r = model_buf.as<T>();
@@ -1611,7 +1770,7 @@ struct SolverT final : cal_solver {
     T* s_i = s_r + (size_t)nbls * fpad;
     CAL_TRY(upload_rows(sr, s_r, nbls, 1, 0));
     CAL_TRY(upload_rows(si, s_i, nbls, 1, 0));
-    h_state->done = h_state->done_after = 0;
+    begin_pass_state();
     CAL_TRY(push_state());
     FusedArgs<T> a = fused_args();
     a.data_r = s_r;
@@ -1620,7 +1779,7 @@ struct SolverT final : cal_solver {
     if (!gc_direct)
       hipLaunchKernelGGL(coeff_partial_reduce_kernel<T>, dim3((ncoef + 255) / 256), dim3(256), 0, stream, gcp0.as<T>(),
                          gcp0.as<T>() + gcp_len, gc0.as<T>(), gc0.as<T>() + ncoef, coef_grp.as<int>(), grp_coff.as<int>(),
-                         grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st_cur());
+                         grp_item_ptr.as<int>(), item_goff.as<int>(), ncoef, st_cur(), smap(false));
     HIP_TRY(hipGetLastError());
     // A^T b becomes the coefficient vector (orthonormal-column bases; the host applies the Gram solve otherwise)
     HIP_TRY(hipMemcpyAsync(coef.p, grad_c0(), 2 * (size_t)ncoef * sizeof(T), hipMemcpyDeviceToDevice, stream));
@@ -1665,7 +1824,8 @@ struct SolverT final : cal_solver {
     const DevBuf* all[] = {&tiles, &bl_tile, &bl_ant, &items, &ant_ptr, &ant_ent, &coef_grp, &grp_coff, &grp_item_ptr, &item_goff,
                            &data_r, &data_i, &wgts, &gains, &gains_alt, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
                            &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf,
-                           &mf_ops, &mf_panels, &mf_map, &members, &heads};
+                           &mf_ops, &mf_panels, &mf_map, &members, &heads, &slice_coff, &slice_ipart_ptr, &slice_ipart_idx,
+                           &slice_ppart_ptr, &slice_ppart_idx, &slice_cblk};
     int64_t n = 0;
     for (auto* d : all) n += (int64_t)d->bytes;
     *b = n;
@@ -1849,7 +2009,9 @@ int cal_solver_destroy(cal_solver* s) {
 
 int cal_solver_set_problem(cal_solver* s, const cal_problem_desc* d) { NEED(s); return s->set_problem(d); }
 int cal_solver_set_data(cal_solver* s, const void* dr, const void* di, const void* w) { NEED(s); return s->set_data(dr, di, w); }
-int cal_solver_set_regularization(cal_solver* s, int mode, double pr, double pi) { NEED(s); return s->set_regularization(mode, pr, pi); }
+int cal_solver_set_regularization(cal_solver* s, int mode, double pr, double pi) { NEED(s); return s->set_regularization(mode, &pr, &pi, false); }
+int cal_solver_set_regularization_slices(cal_solver* s, int mode, const double* pr, const double* pi) { NEED(s); return s->set_regularization(mode, pr, pi, true); }
+int cal_solver_get_slice_losses(cal_solver* s, double* losses) { NEED(s); return s->get_slice_losses(losses); }
 int cal_solver_set_optimizer(cal_solver* s, const cal_optimizer_desc* d) { NEED(s); return s->set_optimizer(d); }
 int cal_solver_set_params(cal_solver* s, const void* g_r, const void* g_i, const void* c_r, const void* c_i) {
   NEED(s);
@@ -1874,7 +2036,8 @@ int cal_solver_eval_grads(cal_solver* s, double* loss, void* gg_r, void* gg_i, v
   NEED(s);
   return s->eval(true, loss, gg_r, gg_i, gc_r, gc_i);
 }
-int cal_solver_run(cal_solver* s, const cal_run_desc* r, double* losses_out, cal_run_result* res) { NEED(s); return s->run(r, losses_out, res); }
+int cal_solver_run(cal_solver* s, const cal_run_desc* r, double* losses_out, cal_run_result* res) { NEED(s); return s->run(r, losses_out, res, false); }
+int cal_solver_run_slices(cal_solver* s, const cal_run_desc* r, double* losses_out, cal_run_result* res) { NEED(s); return s->run(r, losses_out, res, true); }
 int cal_solver_model(cal_solver* s, void* mr, void* mi) { NEED(s); return s->model(mr, mi); }
 int cal_solver_init_coeffs(cal_solver* s, const void* sr, const void* si) { NEED(s); return s->init_coeffs(sr, si); }
 int cal_solver_synchronize(cal_solver* s) { NEED(s); return s->synchronize(); }

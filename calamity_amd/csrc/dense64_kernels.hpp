@@ -38,7 +38,8 @@ struct Dense64Args {
   double* gc_r;
   double* gc_i;
   double* part;                // [npanels][4]
-  const DevState* state;
+  const DevState* state;       // [nslices]
+  int nslices;
   int fpad;
   int use_alpha;
   int nbls;
@@ -58,7 +59,9 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
   constexpr int kRing = GRAD ? 8 : 4;  // powers of two (slot index by mask)
   const int panel_idx = A.slot_map[blockIdx.x];  // never negative here: the kernel returns for empty slots
   const PanelItem& P = A.panels[panel_idx];
-  const int stopped = A.state->done | A.state->done_after;
+  const DevState* sst = A.state;
+  if (A.nslices > 1) sst += P.slice;
+  const int stopped = sst->done | sst->done_after;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,7 +175,7 @@ __device__ __forceinline__ void dense64_panel(const Dense64Args& A, unsigned cha
 #pragma unroll
     for (int t = 0; t < NTMAX; ++t) dC[c][t] = f64x4{0.0, 0.0, 0.0, 0.0};
   double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
-  const double al_r = A.use_alpha ? A.state->alpha_r : 0.0, al_i = A.use_alpha ? A.state->alpha_i : 0.0;
+  const double al_r = A.use_alpha ? sst->alpha_r : 0.0, al_i = A.use_alpha ? sst->alpha_i : 0.0;
   const char* p_dr = reinterpret_cast<const char*>(A.data_r);
   const char* p_di = reinterpret_cast<const char*>(A.data_i);
   const char* p_w = reinterpret_cast<const char*>(A.wgts);

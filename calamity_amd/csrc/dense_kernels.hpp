@@ -40,7 +40,7 @@ template <> struct DenseCfg<float> { static constexpr int max_nvec = 32 * kMaxNT
 struct PanelItem {
   int bl[kPanel];     // baseline ids (-1: padding slot)
   int nvec, nvp2, nvp32;
-  int pad;
+  int slice;          // the time slice all its baselines belong to (panels never mix slices): which DevState governs it
   int coff[kPanel];   // coefficient offset of each slot's group (0 for padding slots)
   int2 ant[kPanel];   // antenna pair of each slot (0, 0 for padding slots)
   // element offsets into MfmaArgs::ops (the whole buffer stays below 4 GB: the kernel adds 32-bit byte offsets to ONE base)
@@ -63,7 +63,8 @@ struct MfmaArgs {
   float* gc_r;                 // [ncoef] final coefficient gradient (every baseline owns its coefficients)
   float* gc_i;
   double* part;                // [npanels][4]
-  const DevState* state;
+  const DevState* state;       // [nslices]
+  int nslices;
   int fpad;
   int use_alpha;               // "sum" regulariser, second pass: e = -2 w r + alpha w with alpha = 2 (S - P) read from state
   int nbls;                    // row nbls of data_r / data_i / wgts / q0 is an all-zero spare row for padding slots
@@ -137,7 +138,9 @@ __device__ __forceinline__ void dense_panel(const MfmaArgs& A, unsigned char* sm
   const int nvec = P.nvec, NT = P.nvp32 / 32;
   const int ngk = (nvec + 7) / 8;  // forward k-groups of 8 vectors (4 k-steps)
   const int ncb = A.fpad / kCB;
-  const int stopped = A.state->done | A.state->done_after;
+  const DevState* sst = A.state;
+  if (A.nslices > 1) sst += P.slice;  // (several time slices: the panel's own, one dependent load beside the slot table's)
+  const int stopped = sst->done | sst->done_after;
 
   unsigned char* s_ring = smem_raw;                                                // [4 waves][kRing][1 KB] operand rings
   unsigned char* s_smp = smem_raw + 4 * kRing * 1024;                              // [4 waves][6 KB]: one channel block's samples
@@ -266,7 +269,7 @@ __device__ __forceinline__ void dense_panel(const MfmaArgs& A, unsigned char* sm
 #pragma unroll
     for (int j = 0; j < 16; ++j) dC[t][j] = 0.f;
   double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
-  const float al_r = A.use_alpha ? (float)A.state->alpha_r : 0.f, al_i = A.use_alpha ? (float)A.state->alpha_i : 0.f;
+  const float al_r = A.use_alpha ? (float)sst->alpha_r : 0.f, al_i = A.use_alpha ? (float)sst->alpha_i : 0.f;
   const char* p_g = reinterpret_cast<const char*>(A.gains);
   char* p_q = reinterpret_cast<char*>(A.q0);
   // this lane's two channels of every register group: + 0, 1 on the re lane, + 2, 3 on the im lane

@@ -68,6 +68,27 @@ struct DevState {
 };
 enum { OPT_ADAM = 0, OPT_ADAMAX = 1, OPT_SGD = 2, OPT_RMSPROP = 3, OPT_ADAGRAD = 4, OPT_NADAM = 5, OPT_ADADELTA = 6 };
 
+// Time slices (cal_problem_desc::nslices): one solver may hold several independent fits -- the (polarization, time) slices the
+// reference fits one after another (calibration.py:1160-1167) -- each with its own gains (antennas [t na_slice, (t + 1) na_slice)),
+// coefficients (a contiguous run of the flat planes), loss, regulariser sums and loop state.  DevState is an array with one entry
+// per slice; every kernel looks up the state of the slice its work belongs to, so a slice stops (tolerance, :712-717), keeps its
+// minimum (:702-710) and records its losses (:701) on its own.
+struct SliceMap {
+  const int* coff;      // [nslices + 1] first coefficient of every slice (offsets into one plane)
+  const int* part_ptr;  // [nslices + 1] the loss partials of slice t are entries part_ptr[t] .. part_ptr[t + 1] of part_idx
+  const int* part_idx;  // [nparts] indices into `part` grouped by slice; nullptr with one slice (identity)
+  int nslices;
+  int na_slice;         // antennas per slice
+};
+__device__ __forceinline__ int slice_of_coef(const SliceMap& M, int n) {  // largest t with coff[t] <= n
+  int lo = 0, hi = M.nslices - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (M.coff[mid] <= n) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 struct Item {        // one workgroup's share of a fitting group
   int bl0;           // first baseline of the GROUP
   int tile0, tile1;  // linear tile range inside the group: tile = (bl - bl0) * ntpb + channel_block
@@ -84,7 +105,7 @@ struct Item {        // one workgroup's share of a fitting group
   long long tile_first;
   int2 ant_first;
   int member0;       // head: its first entry in FusedArgs::members
-  int pad;
+  int slice;         // the time slice (cal_problem_desc::nslices) the item's group belongs to: which DevState governs it
 };
 
 struct Member {      // one baseline of a set that shares tiles
@@ -92,7 +113,9 @@ struct Member {      // one baseline of a set that shares tiles
   int coff;          // its group's coefficients
   int goff;          // where its coefficient gradient goes (its own item's slot)
   int ant0, ant1;
-  int pad[3];
+  int slice;         // its time slice
+  int item;          // its own item: where its loss partial goes (FusedArgs::part)
+  int pad;
 };
 template <typename T> struct MultiCfg { static constexpr int nb_max = sizeof(T) == 4 ? 8 : 4; };  // baselines per multi item (gradient accumulators live in registers)
 
@@ -114,7 +137,8 @@ struct FusedArgs {
   T* gcp1_r; T* gcp1_i;
   double* part;              // [nitems][4]: loss, s_r, s_i, unused
   T* model_r; T* model_i;    // MODE_MODEL output [nbls][fpad]
-  const DevState* state;
+  const DevState* state;     // [nslices] loop state of every time slice (the current half of the double buffer)
+  int nslices;
   int fpad;
   int nbls;                  // q0 / q1 have nbls + 1 rows; row nbls stays zero
   int stream_once;           // CAL_LAYOUT_STREAM: every tile is read once per pass
@@ -596,7 +620,9 @@ __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const 
   for (int m = 0; m < NBMAX; ++m)
 #pragma unroll
     for (int l = 0; l < L; ++l) acc[m][l].x = acc[m][l].y = 0;
-  double loss_acc = 0.0;
+  double loss_acc[R];  // per (member, channel) pair of this thread: each member's loss goes to its OWN slot (its time slice's sum)
+#pragma unroll
+  for (int r = 0; r < R; ++r) loss_acc[r] = 0.0;
   // this thread's (member, channel) pairs of the per-channel stage: pair p = r * 256 + tid -> member p / FB, channel p % FB
   int pm[R], pch[R];
   unsigned prow[R];    // sample row of the member: bl * fpad (32-bit element offsets: the host checks (nbls + 1) * fpad < 2^31)
@@ -672,7 +698,7 @@ __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const 
         const T m_i = G_i * vr + G_r * vi;
         const T r_r = d_r[r] - m_r;
         const T r_i = d_i[r] - m_i;
-        loss_acc += (double)(w[r] * (r_r * r_r + r_i * r_i));
+        loss_acc[r] += (double)(w[r] * (r_r * r_r + r_i * r_i));
         if (GRAD) {
           const T e_r = (T)-2 * w[r] * r_r;
           const T e_i = (T)-2 * w[r] * r_i;
@@ -707,18 +733,21 @@ __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const 
     // this tile's per-channel stage (it sits behind the second barrier); s_gv is rewritten behind the next first barrier
   }
 
-  // ---- epilogue: loss partial of the item (all members), coefficient gradients of every member
+  // ---- epilogue: loss partial of every member (into the member's own slot: members may belong to different time slices),
+  // coefficient gradients of every member.  Pair p = r * 256 + tid is (member p / FB, channel p % FB): the per-pair sums go to LDS
+  // (the coefficient area is free by now) and thread m adds the FB channels of member m in order.
   __syncthreads();
-  double* s_red = reinterpret_cast<double*>(s_pv);
-  const double ls = ldsum(loss_acc);
-  if (lane == 0) s_red[wave] = ls;
+  double* s_red = reinterpret_cast<double*>(smem);  // [R * kThreads] >= [NBMAX * FB]
+#pragma unroll
+  for (int r = 0; r < R; ++r) s_red[r * kThreads + tid] = loss_acc[r];
   __syncthreads();
-  if (tid == 0) {
+  if (tid < NB) {
     double a = 0;
-    for (int wv = 0; wv < kWaves; ++wv) a += s_red[wv];
-    A.part[(size_t)item_idx * 4 + 0] = a;
-    A.part[(size_t)item_idx * 4 + 1] = 0.0;
-    A.part[(size_t)item_idx * 4 + 2] = 0.0;
+    for (int ch = 0; ch < FB; ++ch) a += s_red[tid * FB + ch];
+    const size_t slot = (size_t)s_mem[tid].item * 4;
+    A.part[slot + 0] = a;
+    A.part[slot + 1] = 0.0;
+    A.part[slot + 2] = 0.0;
   }
   if (GRAD) {
 #pragma unroll
@@ -1066,7 +1095,9 @@ void fused_basis_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int idx = A.item_base + blockIdx.x;
   const Item it = A.items[idx];  // requested together with the stop flags: one round trip, not two
-  if (A.state->done | A.state->done_after) return;
+  const DevState* st = A.state;
+  if (A.nslices > 1) st += it.slice;  // (several time slices: the flags of the item's own slice, a dependent load)
+  if (st->done | st->done_after) return;
   // baselines that share tiles are processed together by fused_multi_kernel in the passes that have such a form
   if (!REG && (MODE == MODE_LOSS || MODE == MODE_GRAD) && (it.role_n & 3) != 0 && A.heads != nullptr) return;
   constexpr int FBM = FbSet<T>::fb_max;
@@ -1083,7 +1114,8 @@ __global__ __launch_bounds__(kThreads, 2) void fused_multi_kernel(const FusedArg
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int idx = A.heads[blockIdx.x];
   const Item it = A.items[idx];
-  if (A.state->done | A.state->done_after) return;
+  // (members of several time slices: the item runs while any of them does; a stopped member's outputs are not consumed)
+  if (A.nslices == 1 && (A.state->done | A.state->done_after)) return;
   constexpr int FBM = FbSet<T>::fb_max;
   const int fb = 1 << it.fb_log2;
   if (fb == FBM) process_multi_item<T, FBM, MODE>(A, it, smem, idx);
@@ -1096,9 +1128,11 @@ __global__ __launch_bounds__(kThreads, 2) void fused_multi_kernel(const FusedArg
 template <typename T, int MODE, bool REG>
 __global__ __launch_bounds__(kThreads) void fused_group_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (A.state->done | A.state->done_after) return;
   const int idx = A.item_base + blockIdx.x;
   const Item it = A.items[idx];
+  const DevState* st = A.state;
+  if (A.nslices > 1) st += it.slice;
+  if (st->done | st->done_after) return;
   constexpr int FBM = FbSet<T>::fb_max;
   const int fb = 1 << it.fb_log2;
   if (fb == FBM) process_group_item<T, FBM, MODE, REG>(A, it, smem, idx);
@@ -1113,10 +1147,11 @@ template <typename T>
 __global__ void coeff_partial_reduce_kernel(const T* __restrict__ gcp_r, const T* __restrict__ gcp_i, T* __restrict__ gc_r,
                                             T* __restrict__ gc_i, const int* __restrict__ coef_grp,
                                             const int* __restrict__ grp_coff, const int* __restrict__ grp_item_ptr,
-                                            const int* __restrict__ item_goff, int ncoef, const DevState* st) {
-  if (st->done | st->done_after) return;
+                                            const int* __restrict__ item_goff, int ncoef, const DevState* st, const SliceMap M) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= ncoef) return;
+  if (M.nslices > 1) st += slice_of_coef(M, n);
+  if (st->done | st->done_after) return;
   const int g = coef_grp[n];
   const int k = n - grp_coff[g];
   T a = 0, b = 0;
@@ -1128,12 +1163,14 @@ __global__ void coeff_partial_reduce_kernel(const T* __restrict__ gcp_r, const T
   gc_i[n] = b;
 }
 
-// Sum of the per-item loss partials (chi^2, S_r, S_i) by one 256-thread block, in a fixed order: thread t takes items
-// t, t + 256, ...; a butterfly over the 64 lanes of each wave; the four waves in order.  Shared by gain_grad_kernel's last
-// block and by every block of step_tail_kernel (the launch forms of a step must agree bit for bit).  x: the caller's loads of
-// item threadIdx.x (issued early so that they travel together with its other loads), valid when threadIdx.x < n.
-// Result in out[0..2] on every thread; sh: 12 doubles of LDS.
-__device__ __forceinline__ void sum_partials(const double* __restrict__ part, int n, const double x[3], double* sh, double out[3]) {
+// Sum of the loss partials (chi^2, S_r, S_i) of ONE time slice by one 256-thread block, in a fixed order: thread t takes entries
+// t, t + 256, ... of the slice's list; a butterfly over the 64 lanes of each wave; the four waves in order.  Shared by
+// gain_grad_kernel's last blocks and by every block of step_tail_kernel (the launch forms of a step must agree bit for bit).
+// Entry i of the list is part[idx ? idx[p0 + i] : p0 + i] (idx: SliceMap::part_idx, nullptr with one slice), n entries.
+// x: the caller's loads of entry threadIdx.x (issued early so that they travel together with its other loads), valid when
+// threadIdx.x < n.  Result in out[0..2] on every thread; sh: 12 doubles of LDS.
+__device__ __forceinline__ void sum_partials(const double* __restrict__ part, const int* __restrict__ idx, int p0, int n, const double x[3],
+                                             double* sh, double out[3]) {
   const int tid = threadIdx.x;
   double a = 0, b = 0, c = 0;
   if (tid < n) {
@@ -1142,9 +1179,10 @@ __device__ __forceinline__ void sum_partials(const double* __restrict__ part, in
     c = x[2];
   }
   for (int i = tid + 256; i < n; i += 256) {
-    a += part[(size_t)i * 4 + 0];
-    b += part[(size_t)i * 4 + 1];
-    c += part[(size_t)i * 4 + 2];
+    const size_t e = idx ? (size_t)idx[p0 + i] : (size_t)(p0 + i);
+    a += part[e * 4 + 0];
+    b += part[e * 4 + 1];
+    c += part[e * 4 + 2];
   }
   a = ldsum(a);
   b = ldsum(b);
@@ -1158,6 +1196,22 @@ __device__ __forceinline__ void sum_partials(const double* __restrict__ part, in
   out[0] = ((sh[0] + sh[3]) + sh[6]) + sh[9];
   out[1] = ((sh[1] + sh[4]) + sh[7]) + sh[10];
   out[2] = ((sh[2] + sh[5]) + sh[8]) + sh[11];
+}
+// the entries of slice t: first entry, count (one slice: all nparts), and this thread's early load of entry threadIdx.x
+__device__ __forceinline__ void slice_partials(const SliceMap& M, int t, int nparts, const double* __restrict__ part, int& p0, int& n, double x[3]) {
+  p0 = 0;
+  n = nparts;
+  if (M.nslices > 1) {
+    p0 = M.part_ptr[t];
+    n = M.part_ptr[t + 1] - p0;
+  }
+  x[0] = x[1] = x[2] = 0;
+  if ((int)threadIdx.x < n) {
+    const size_t e = M.part_idx ? (size_t)M.part_idx[p0 + threadIdx.x] : (size_t)(p0 + threadIdx.x);
+    x[0] = part[e * 4 + 0];
+    x[1] = part[e * 4 + 1];
+    x[2] = part[e * 4 + 2];
+  }
 }
 
 // The per-antenna reduction shared by gain_grad_kernel and step_tail_kernel (ONE body: the two launch forms of a step must
@@ -1248,27 +1302,25 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
                                                          const int2* __restrict__ ant_ent, vec2_t<T>* __restrict__ r0,
                                                          vec2_t<T>* __restrict__ r1, vec2_t<T>* __restrict__ r2, int nants,
                                                          int fpad, const double* __restrict__ part, int nitems,
-                                                         double* __restrict__ scal, const DevState* st) {
+                                                         double* __restrict__ scal, const DevState* st, const SliceMap M) {
   using T2 = vec2_t<T>;
   constexpr int CPL = 16 / (int)sizeof(T2) > 0 ? 16 / (int)sizeof(T2) : 1;  // channels per lane: 2 (fp32), 1 (fp64)
   typedef T vec_t __attribute__((ext_vector_type(2 * CPL)));
-  if (st->done | st->done_after) return;
   const int cblocks = (fpad + 64 * CPL - 1) / (64 * CPL);
   const int nb_main = nants * cblocks;
   if ((int)blockIdx.x >= nb_main) {
-    // last block: deterministic sum of the per-item loss partials -> scal[0..2]
+    // the last nslices blocks: deterministic sum of the loss partials of one time slice each -> scal[4 t + 0..2]
+    const int t = (int)blockIdx.x - nb_main;
+    if (st[t].done | st[t].done_after) return;
     __shared__ double sh[12];
-    double x[3] = {0, 0, 0}, tot[3];
-    if ((int)threadIdx.x < nitems) {
-      x[0] = part[(size_t)threadIdx.x * 4 + 0];
-      x[1] = part[(size_t)threadIdx.x * 4 + 1];
-      x[2] = part[(size_t)threadIdx.x * 4 + 2];
-    }
-    sum_partials(part, nitems, x, sh, tot);
+    double x[3], tot[3];
+    int p0, n;
+    slice_partials(M, t, nitems, part, p0, n, x);
+    sum_partials(part, M.part_idx, p0, n, x, sh, tot);
     if (threadIdx.x == 0) {
-      scal[0] = tot[0];
-      scal[1] = tot[1];
-      scal[2] = tot[2];
+      scal[4 * t + 0] = tot[0];
+      scal[4 * t + 1] = tot[1];
+      scal[4 * t + 2] = tot[2];
     }
     return;
   }
@@ -1281,6 +1333,23 @@ __global__ __launch_bounds__(256) void gain_grad_kernel(const vec2_t<T>* __restr
   const int a = blockIdx.x - cb * nants;
   const int lane = threadIdx.x & 63;
   const int f = (cb * 64 + lane) * CPL;
+  if (M.nslices > 1) st += a / M.na_slice;
+  if (st->done | st->done_after) {
+    // a stopped slice of several: its gradient rows are still part of the exchange payload -- keep them zero rather than stale
+    // (an all-reduce in place would multiply what is left there by the number of ranks, step after step)
+    if (M.nslices > 1 && threadIdx.x < 64 && f < fpad) {
+      vec_t z;
+#pragma unroll
+      for (int c = 0; c < 2 * CPL; ++c) z[c] = 0;
+      const long long idx = (long long)a * fpad + f;
+      *reinterpret_cast<vec_t*>(r0 + idx) = z;
+      if (REG) {
+        *reinterpret_cast<vec_t*>(r1 + idx) = z;
+        *reinterpret_cast<vec_t*>(r2 + idx) = z;
+      }
+    }
+    return;
+  }
   T s0[2 * CPL], s1[2 * CPL], s2[2 * CPL];
   const bool mine = antenna_sums<T, REG>(q0, q1, gains, ant_ptr, ant_ent, a, f, fpad, s_part, s0, s1, s2);
   if (mine) {
@@ -1452,19 +1521,21 @@ template <typename T> __device__ __forceinline__ T optimizer_step(T pi, T gi, T&
 }
 
 __global__ void finalize_kernel(DevState* st, const double* __restrict__ scal, double* __restrict__ losses, int losses_cap,
-                                int apply_update) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  DevState s = *st;
-  advance_state(s, scal[0], scal[1], scal[2], true, losses, losses_cap, apply_update != 0);
-  *st = s;
+                                int apply_update, int nslices) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per time slice
+  if (t >= nslices) return;
+  DevState s = st[t];
+  advance_state(s, scal[4 * t + 0], scal[4 * t + 1], scal[4 * t + 2], true, losses + (size_t)t * losses_cap, losses_cap, apply_update != 0);
+  st[t] = s;
 }
 
 // ---- "sum" regulariser, two-pass form (dense path): alpha = 2 (S - P) from the reduced sums of a loss-only pass
-__global__ void alpha_kernel(DevState* st, const double* __restrict__ scal) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (st->done | st->done_after) return;
-  st->alpha_r = 2.0 * (scal[1] - st->prior_r);
-  st->alpha_i = 2.0 * (scal[2] - st->prior_i);
+__global__ void alpha_kernel(DevState* st, const double* __restrict__ scal, int nslices) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nslices) return;
+  if (st[t].done | st[t].done_after) return;
+  st[t].alpha_r = 2.0 * (scal[4 * t + 1] - st[t].prior_r);
+  st[t].alpha_i = 2.0 * (scal[4 * t + 2] - st[t].prior_i);
 }
 
 // ---- "sum" regulariser: fold the alpha-weighted parts into the gradients once alpha is known.  The two folds are functions
@@ -1482,10 +1553,11 @@ template <typename T> __device__ __forceinline__ T fold_coeff(T g0, T same, T ot
 }
 template <typename T>
 __global__ void combine_gain_kernel(vec2_t<T>* __restrict__ r0, const vec2_t<T>* __restrict__ r1,
-                                    const vec2_t<T>* __restrict__ r2, int n, const DevState* st) {
-  if (st->done) return;
+                                    const vec2_t<T>* __restrict__ r2, int n, const DevState* st, const SliceMap M, int fpad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (M.nslices > 1) st += (i / fpad) / M.na_slice;
+  if (st->done) return;
   const T ar = (T)st->alpha_r, ai = (T)st->alpha_i;
   vec2_t<T> a = r0[i];
   const vec2_t<T> b = r1[i], c = r2[i];
@@ -1495,10 +1567,11 @@ __global__ void combine_gain_kernel(vec2_t<T>* __restrict__ r0, const vec2_t<T>*
 
 template <typename T>
 __global__ void combine_coeff_kernel(T* __restrict__ g0_r, T* __restrict__ g0_i, const T* __restrict__ g1_r,
-                                     const T* __restrict__ g1_i, int n, const DevState* st) {
-  if (st->done) return;
+                                     const T* __restrict__ g1_i, int n, const DevState* st, const SliceMap M) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (M.nslices > 1) st += slice_of_coef(M, i);
+  if (st->done) return;
   const T ar = (T)st->alpha_r, ai = (T)st->alpha_i;
   g0_r[i] = fold_coeff(g0_r[i], g1_r[i], g1_i[i], ar, ai, false);
   g0_i[i] = fold_coeff(g0_i[i], g1_i[i], g1_r[i], ar, ai, true);
@@ -1509,13 +1582,19 @@ __global__ void combine_coeff_kernel(T* __restrict__ g0_r, T* __restrict__ g0_i,
 // coefficients).
 template <typename T>
 struct AdamSet { T* p; const T* g; T* m; T* v; T* snap; long long n; };
+// slice of element i of the flat gain array [nants][fpad][2] / of the flat coefficient planes [2][ncoef]
+__device__ __forceinline__ int slice_of_gain_real(const SliceMap& M, long long i, int fpad) { return (int)(i / (2LL * fpad)) / M.na_slice; }
+__device__ __forceinline__ int slice_of_coef_real(const SliceMap& M, long long i, int ncoef) { return slice_of_coef(M, (int)(i >= ncoef ? i - ncoef : i)); }
+
 template <typename T>
-__global__ __launch_bounds__(256) void adam2_kernel(const AdamSet<T> a, const AdamSet<T> b, int nblk_a, const DevState* st) {
-  if (st->done) return;
+__global__ __launch_bounds__(256) void adam2_kernel(const AdamSet<T> a, const AdamSet<T> b, int nblk_a, const DevState* st, const SliceMap M,
+                                                    int fpad, int ncoef) {
   const bool first = (int)blockIdx.x < nblk_a;
   const AdamSet<T>& S = first ? a : b;
   const long long i = (long long)(first ? blockIdx.x : blockIdx.x - nblk_a) * blockDim.x + threadIdx.x;
   if (i >= S.n) return;
+  if (M.nslices > 1) st += first ? slice_of_gain_real(M, i, fpad) : slice_of_coef_real(M, i, ncoef);
+  if (st->done) return;
   const StepCoef<T> c = step_coef<T>(*st);
   T mi = S.m[i], vi = S.v[i];
   const T pi = optimizer_step<T>(S.p[i], S.g[i], mi, vi, c);
@@ -1538,33 +1617,41 @@ struct PartialSum {          // gradient of coefficient n = sum over the items q
   const int* coef_grp; const int* grp_coff; const int* grp_item_ptr; const int* item_goff;
   int ncoef;                 // 0: the gradient is read from AdamSet::g as it stands
 };
+template <typename T> struct SliceStep { StepCoef<T> c; int update, improved; };  // one slice's decisions of a step
 template <typename T>
 __global__ __launch_bounds__(256) void step_update_kernel(const AdamSet<T> a, const AdamSet<T> b, const PartialSum<T> ps,
                                                          const DevState* __restrict__ in, DevState* __restrict__ out,
-                                                         const double* __restrict__ scal, double* __restrict__ losses, int losses_cap) {
-  // ---- the step's decisions: thread 0 of every block derives them (identically), block 0 records them
-  __shared__ StepCoef<T> sh_c;
-  __shared__ int sh_update, sh_improved;
-  if (threadIdx.x == 0) {
-    DevState s = *in;
+                                                         const double* __restrict__ scal, double* __restrict__ losses, int losses_cap,
+                                                         const SliceMap M, int fpad, int ncoef) {
+  // ---- the step's decisions, slice by slice: threads 0 .. nslices - 1 of every block derive them (identically), block 0 records them
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  SliceStep<T>* sh = reinterpret_cast<SliceStep<T>*>(dyn_smem);  // [nslices]
+  __shared__ int sh_any;
+  if (threadIdx.x == 0) sh_any = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < M.nslices; t += blockDim.x) {
+    DevState s = in[t];
     const bool writer = blockIdx.x == 0;
-    const bool update = advance_state(s, scal[0], scal[1], scal[2], writer, losses, losses_cap, true);
-    if (writer) *out = s;
-    sh_update = update ? 1 : 0;
-    sh_improved = s.improved;
-    sh_c = step_coef<T>(s);
+    const bool update = advance_state(s, scal[4 * t + 0], scal[4 * t + 1], scal[4 * t + 2], writer, losses + (size_t)t * losses_cap, losses_cap, true);
+    if (writer) out[t] = s;
+    sh[t].update = update ? 1 : 0;
+    sh[t].improved = s.improved;
+    sh[t].c = step_coef<T>(s);
+    if (update) sh_any = 1;
   }
   __syncthreads();
-  if (!sh_update) return;
+  if (!sh_any) return;
   // ---- the update: sets a (gains) and b (coefficients) as one index space, grid-stride (the decisions above are taken
   // once per block, so a big problem runs a few thousand blocks, not one per 256 elements)
-  const StepCoef<T> c = sh_c;
-  const bool improved = sh_improved != 0;
   const long long total = a.n + b.n;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const bool first = e < a.n;
     const AdamSet<T>& S = first ? a : b;
     const long long i = first ? e : e - a.n;
+    const int sl = M.nslices > 1 ? (first ? slice_of_gain_real(M, i, fpad) : slice_of_coef_real(M, i, ncoef)) : 0;
+    if (!sh[sl].update) continue;
+    const StepCoef<T> c = sh[sl].c;
+    const bool improved = sh[sl].improved != 0;
     T gi;
     if (!first && ps.ncoef > 0) {
       const int plane = i >= ps.ncoef ? 1 : 0;
@@ -1608,8 +1695,11 @@ struct TailArgs {
   PartialSum<T> ps0, ps1;
   const double* part; int nparts;
   int nants, fpad, nblk_gain;
-  const DevState* in; DevState* out;
-  double* losses; int losses_cap;
+  const DevState* in; DevState* out;             // [nslices] each
+  double* losses; int losses_cap;                // [nslices][losses_cap]
+  SliceMap M;
+  const int* cblk_ptr;                           // several slices: [nslices + 1] the coefficient blocks of every slice (block index - nblk_gain)
+  int ncoef;
 };
 template <typename T, bool REG>
 __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
@@ -1622,22 +1712,39 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
   __shared__ int sh_update, sh_improved;
   __shared__ T s_part[3][3][64][2 * CPL];
   const int tid = threadIdx.x;
-  // A step of such a problem is a chain of dependent memory round trips, about a microsecond each, so everything that does
-  // not depend on the step's decisions is requested first and the chains run side by side: the loss partials and the loop
-  // state (-> decisions), and, in a gain block, antenna list -> gbar_G rows and gains (-> gradient) and the block's own gains
-  // and optimizer slots.  The decisions only gate the final writes.
-  double x[3] = {0, 0, 0};
-  if (tid < A.nparts) {
-    x[0] = A.part[(size_t)tid * 4 + 0];
-    x[1] = A.part[(size_t)tid * 4 + 1];
-    x[2] = A.part[(size_t)tid * 4 + 2];
-  }
-  DevState s;
-  if (tid == 0) s = *A.in;
   const bool gain_block = (int)blockIdx.x < A.nblk_gain;
   // ---- gain block: gain_grad_kernel's reduction (antenna_sums) for (antenna a, 64 CPL channels)
   const int cb = gain_block ? blockIdx.x / A.nants : 0;
   const int a = gain_block ? blockIdx.x - cb * A.nants : 0;
+  // the time slice this block works for (its loss, its loop state, its decisions), and -- coefficient blocks -- its share of it
+  int slice = 0;
+  long long cblk = (long long)blockIdx.x - A.nblk_gain, ncblk = (long long)gridDim.x - A.nblk_gain;  // this block among the slice's coefficient blocks
+  int c0 = 0, nc = A.ncoef;  // the slice's coefficients: [c0, c0 + nc) of each plane
+  if (A.M.nslices > 1) {
+    if (gain_block) {
+      slice = a / A.M.na_slice;
+    } else {
+      int lo = 0, hi = A.M.nslices - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (A.cblk_ptr[mid] <= (int)cblk) lo = mid; else hi = mid - 1;
+      }
+      slice = lo;
+      ncblk = A.cblk_ptr[slice + 1] - A.cblk_ptr[slice];
+      cblk -= A.cblk_ptr[slice];
+      c0 = A.M.coff[slice];
+      nc = A.M.coff[slice + 1] - c0;
+    }
+  }
+  // A step of such a problem is a chain of dependent memory round trips, about a microsecond each, so everything that does
+  // not depend on the step's decisions is requested first and the chains run side by side: the loss partials and the loop
+  // state (-> decisions), and, in a gain block, antenna list -> gbar_G rows and gains (-> gradient) and the block's own gains
+  // and optimizer slots.  The decisions only gate the final writes.
+  double x[3];
+  int p0, np;
+  slice_partials(A.M, slice, A.nparts, A.part, p0, np, x);
+  DevState s;
+  if (tid == 0) s = A.in[slice];
   const int lane = tid & 63, seg = tid >> 6;
   const int f = (cb * 64 + lane) * CPL;
   const long long idx = (long long)a * A.fpad + f;
@@ -1652,14 +1759,14 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
     }
     mine = antenna_sums<T, REG>(A.q0, A.q1, A.gains_in, A.ant_ptr, A.ant_ent, a, f, A.fpad, s_part, s0, s1, s2);
   }
-  // ---- loss partial sums (sum_partials: the order of gain_grad_kernel's last block), in every block
+  // ---- loss partial sums of the slice (sum_partials: the order of gain_grad_kernel's last blocks), in every block
   double tot[3];
-  sum_partials(A.part, A.nparts, x, sh, tot);
-  // ---- the step's decisions (advance_state): thread 0 of every block, block 0 records them
+  sum_partials(A.part, A.M.part_idx, p0, np, x, sh, tot);
+  // ---- the slice's decisions of this step (advance_state): thread 0 of every block; the slice's first gain block records them
   if (tid == 0) {
-    const bool writer = blockIdx.x == 0;
-    const bool upd = advance_state(s, tot[0], tot[1], tot[2], writer, A.losses, A.losses_cap, true);
-    if (writer) *A.out = s;
+    const bool writer = gain_block && cb == 0 && a == slice * A.M.na_slice;
+    const bool upd = advance_state(s, tot[0], tot[1], tot[2], writer, A.losses + (size_t)slice * A.losses_cap, A.losses_cap, true);
+    if (writer) A.out[slice] = s;
     sh_update = upd ? 1 : 0;
     sh_improved = s.improved;
     sh_c = step_coef<T>(s);
@@ -1696,14 +1803,16 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
     }
     return;
   }
-  // ---- coefficient blocks
+  // ---- coefficient blocks: element j of the slice's 2 nc reals (re plane, then im plane) = element i of the flat planes
   if (!update) return;
   const AdamSet<T>& S = A.coef;
-  const long long nb = (long long)gridDim.x - A.nblk_gain;
-  for (long long i = ((long long)blockIdx.x - A.nblk_gain) * blockDim.x + tid; i < S.n; i += nb * blockDim.x) {
+  const long long n2 = S.n / 2;  // = ncoef: the planes are [r | i], each n2 long
+  for (long long j = cblk * blockDim.x + tid; j < 2LL * nc; j += ncblk * blockDim.x) {
+    const bool imag = j >= nc;
+    const long long i = (imag ? n2 + (j - nc) : j) + c0;
     T gi, g1 = 0;
     if (A.ps0.ncoef > 0) {
-      const int plane = i >= A.ps0.ncoef ? 1 : 0;
+      const int plane = imag ? 1 : 0;
       const int n = (int)(i - (long long)plane * A.ps0.ncoef);
       const int g = A.ps0.coef_grp[n];
       const int k = n - A.ps0.grp_coff[g];
@@ -1719,21 +1828,19 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
       if (REG) g1 = A.coef_g1[i];
     }
     if (REG) {
-      // combine_coeff_kernel: g0_r += ar g1_r - ai g1_i ; g0_i += ar g1_i + ai g1_r  (planes: [r | i], each n2 long)
-      const long long n2 = S.n / 2;
-      const bool imag = i >= n2;
-      const long long j = imag ? i - n2 : i + n2;  // the same coefficient's other plane
+      // combine_coeff_kernel: g0_r += ar g1_r - ai g1_i ; g0_i += ar g1_i + ai g1_r
+      const long long jo = imag ? i - n2 : i + n2;  // the same coefficient's other plane
       T o1;
       if (A.ps0.ncoef > 0) {
         const int plane = imag ? 0 : 1;
-        const int n = (int)(j - (long long)plane * A.ps0.ncoef);
+        const int n = (int)(jo - (long long)plane * A.ps0.ncoef);
         const int g = A.ps0.coef_grp[n];
         const int k = n - A.ps0.grp_coff[g];
         const T* src1 = plane ? A.ps1.gcp_i : A.ps1.gcp_r;
         o1 = 0;
         for (int q = A.ps0.grp_item_ptr[g]; q < A.ps0.grp_item_ptr[g + 1]; ++q) o1 += src1[A.ps0.item_goff[q] + k];
       } else {
-        o1 = A.coef_g1[j];
+        o1 = A.coef_g1[jo];
       }
       gi = fold_coeff(gi, g1, o1, ar, ai, imag);
     }

@@ -47,7 +47,7 @@ constexpr int kMmTilePadElems = 2048;      // zeroed elements the tile buffers c
 
 inline size_t multi_mfma_lds_bytes(int nvec_max) {
   const size_t nt = (nvec_max + 15) / 16;
-  return 256 + 64 + nt * 4 * 64 * 4 + 4 * nt * 16 * 16 * 4 + 4 * 16 * kMmGvPitch * 4;  // members, loss partials, coefficient operand, four strips, four gbar_v buffers
+  return 256 + 256 + nt * 4 * 64 * 4 + 4 * nt * 16 * 16 * 4 + 4 * 16 * kMmGvPitch * 4;  // members, loss partials, coefficient operand, four strips, four gbar_v buffers
 }
 
 template <int MODE, int NT, int DEPTH>
@@ -65,8 +65,8 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   const unsigned FB = 1u << fb_log2;
 
   Member* s_mem = reinterpret_cast<Member*>(smem);
-  double* s_red = reinterpret_cast<double*>(smem + 256);
-  float* s_c = reinterpret_cast<float*>(smem + 320);                 // [NS steps][64 lanes]: C[4 s + (lane >> 4)][lane & 15]
+  double* s_red = reinterpret_cast<double*>(smem + 256);  // [4 waves][8 members]
+  float* s_c = reinterpret_cast<float*>(smem + 512);                 // [NS steps][64 lanes]: C[4 s + (lane >> 4)][lane & 15]
   float* s_strips = s_c + NS * 64;                                   // [4 waves][16 NT rows][16 channels], swizzled
   float* s_strip = s_strips + wave * NT * 256;
   float* s_gv = s_strips + 4 * NT * 256 + wave * (16 * kMmGvPitch);   // [16 columns][16 channels] gbar_v of the current job, pitch 20 words
@@ -151,7 +151,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   mm_f32x4 dC[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) dC[t] = mm_f32x4{0.f, 0.f, 0.f, 0.f};
-  double loss_acc = 0.0;
+  double loss_acc[2] = {0.0, 0.0};  // of this lane's two members: each member's loss goes to its OWN slot (its time slice's sum)
 
 #ifdef CAL_MM_STAMP
   long long t_bar = 0, t_f = 0, t_e = 0, t_b = 0, t_prev = 0;
@@ -219,7 +219,6 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
     // ---- E: v_permlane32_swap hands each lane the missing part of the two members it evaluates (the lower lane's acc[i] and
     // the upper lane's acc[i + 2] stay, the other two registers cross): (re, im) of member m_a + i on both lanes, no selects
     const unsigned ch0 = strip_of(n) * kMmStrip;
-    float lossj = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -235,7 +234,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
       const float m_r = G_r * vr - G_i * vi;
       const float m_i = G_i * vr + G_r * vi;
       const float r_r = d_r - m_r, r_i = d_i - m_i;
-      lossj += w * (r_r * r_r + r_i * r_i);
+      loss_acc[i] += (double)(w * (r_r * r_r + r_i * r_i));
       if (GRAD) {
         const float e_r = -2.f * w * r_r, e_i = -2.f * w * r_i;
         // gbar_v = conj(G) e -> the wave's [column][channel] buffer, from where B takes it as its operand
@@ -247,7 +246,6 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
         *reinterpret_cast<mm_f32x2*>(A.q0 + so[i] + ch0) = q;
       }
     }
-    loss_acc += (double)lossj;
     MM_STAMP(t_e)
 
     // ---- B: gradient tiles in pairs (independent accumulators back to back)
@@ -309,14 +307,22 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
       printf("stamp item %d NT %d wave %d jobs %d: barrier %lld F %lld E %lld B %lld (s_memtime ticks, 100 MHz)\n", item_idx, NT, wave, njobs, t_bar, t_f, t_e, t_b);
   }
 #endif
-  // ---- epilogue: loss partial of the item (all members), coefficient gradients of every member
-  const double ls = ldsum(loss_acc);
-  if (lane == 0) s_red[wave] = ls;
+  // ---- epilogue: loss partial of every member (into the member's own slot: members may belong to different time slices),
+  // coefficient gradients of every member.  Lane (col, kq) holds members m_a, m_a + 1 at its channels: sum over the 16 lanes of
+  // the row, then over the four waves in order.
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    double v = loss_acc[i];
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) v += __shfl_xor(v, sft, 64);
+    if (col == 0) s_red[wave * 8 + m_a + i] = v;
+  }
   __syncthreads();  // also: every wave has left its strip
-  if (tid == 0) {
-    A.part[(size_t)item_idx * 4 + 0] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
-    A.part[(size_t)item_idx * 4 + 1] = 0.0;
-    A.part[(size_t)item_idx * 4 + 2] = 0.0;
+  if (tid < NB) {
+    const size_t slot = (size_t)s_mem[tid].item * 4;
+    A.part[slot + 0] = ((s_red[tid] + s_red[8 + tid]) + s_red[16 + tid]) + s_red[24 + tid];
+    A.part[slot + 1] = 0.0;
+    A.part[slot + 2] = 0.0;
   }
   if (!GRAD) return;
   // dC[t][r] of lane (col, kq) of wave w = that wave's part of GC[16 t + 4 kq + r][col]; the four parts meet in the strip area:
@@ -349,7 +355,8 @@ __global__ __launch_bounds__(kThreads, 2) void fused_multi_mfma_kernel(const Fus
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int item_idx = A.heads[blockIdx.x];
   const Item it = A.items[item_idx];
-  if (A.state->done | A.state->done_after) return;
+  // (members of several time slices: the item runs while any of them does; a stopped member's outputs are not consumed)
+  if (A.nslices == 1 && (A.state->done | A.state->done_after)) return;
   // the ring of tile registers is 4 jobs deep up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads (7 to 14 KB) in flight per wave
   const bool quad = ((A.fpad >> 6) & 3) == 0;  // a wave's jobs come in fours
   switch ((it.nvec + 15) >> 4) {  // wave-uniform

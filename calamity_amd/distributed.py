@@ -71,10 +71,12 @@ def select_groups(prob, start, groups):
     return sub, sub_start
 
 
-def batch_time_slices(parts):
+def batch_time_slices(parts, per_slice=False):
     """Fit several independent time slices in ONE solver: slice ``t`` keeps its own gains by offsetting its antenna
     indices by ``t * nants`` (calibration.py:1167 loops over times; the fits are independent, Adam is element-wise, so
-    the joint update equals the separate updates; the recorded loss is the sum of the slices' losses).
+    the joint update equals the separate updates).  With ``per_slice`` the solver also keeps one loop state per slice
+    (``FitProblem.nslices``: every slice records its own losses and stops on its own, ``HipFitSolver.run_slices``);
+    without, the slices are one fit whose recorded loss is the sum of the slices' losses.
     ``parts``: list of (FitProblem, start) with identical nants / nfreqs.  Returns (FitProblem, start)."""
     nants, nfreqs = parts[0][0].nants, parts[0][0].nfreqs
     basis, key = [], {}
@@ -116,6 +118,7 @@ def batch_time_slices(parts):
         sky_r=cat("sky_r") if has_sky else None,
         sky_i=cat("sky_i") if has_sky else None,
         bl_alias=np.concatenate(alias) if same_bls and len(parts) > 1 else None,
+        nslices=len(parts) if per_slice else 1,
     )
     start = dict(
         g_r=np.concatenate([s["g_r"] for _, s in parts]),

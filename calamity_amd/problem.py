@@ -37,6 +37,9 @@ class FitProblem:
     # (nbls,) int32 or None: baseline b reads the basis tiles of baseline bl_alias[b] (-1: its own) -- the same physical
     # baseline in several time slices fitted by one solver (distributed.batch_time_slices); cal_problem_desc::bl_alias
     bl_alias: Optional[np.ndarray] = None
+    # number of independent time slices held together (cal_problem_desc::nslices): slice t owns antennas
+    # [t * nants / nslices, (t + 1) * nants / nslices), its groups are contiguous; each slice has its own loss and loop state
+    nslices: int = 1
 
     @property
     def ngrps(self):

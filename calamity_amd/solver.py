@@ -84,13 +84,14 @@ class HipFitSolver:
             nants=prob.nants, nfreqs=prob.nfreqs, ngrps=prob.ngrps, nbls=prob.nbls, nbasis=len(basis),
             basis_offset=_ptr(offs), basis_nvec=_ptr(nvec), basis_nrowblk=_ptr(nrb), basis_data=_ptr(flat),
             grp_basis=_ptr(keep[4]), grp_bl_start=_ptr(keep[5]), bl_ant0=_ptr(keep[6]), bl_ant1=_ptr(keep[7]),
-            bl_rowblk=_ptr(keep[8]), bl_alias=_ptr(keep[9]),
+            bl_rowblk=_ptr(keep[8]), bl_alias=_ptr(keep[9]), nslices=int(getattr(prob, "nslices", 1) or 1),
             layout={"stream": _lib.CAL_LAYOUT_STREAM, "shared": _lib.CAL_LAYOUT_SHARED}[layout],
             kernel_path={"auto": _lib.CAL_PATH_AUTO, "general": _lib.CAL_PATH_GENERAL, "dense": _lib.CAL_PATH_DENSE}[kernel_path],
         )
         _lib.check(self._lib.cal_solver_set_problem(self._h, C.byref(d)))
         self.problem = prob
         self.nants, self.nfreqs, self.nbls, self.ncoeffs = prob.nants, prob.nfreqs, prob.nbls, prob.ncoeffs
+        self.nslices = int(getattr(prob, "nslices", 1) or 1)
         if prob.data_r is not None:
             self.set_data(prob.data_r, prob.data_i, prob.wgts)
         return self
@@ -101,8 +102,16 @@ class HipFitSolver:
         _lib.check(self._lib.cal_solver_set_data(self._h, _ptr(a), _ptr(b), _ptr(c)))
 
     def set_regularization(self, mode=None, prior_r_sum=0.0, prior_i_sum=0.0):
+        """``prior_*_sum``: one number, or one per time slice of the solver (cal_solver_set_regularization_slices)."""
         code = _lib.CAL_REG_SUM if mode == "sum" else _lib.CAL_REG_NONE
-        _lib.check(self._lib.cal_solver_set_regularization(self._h, code, float(prior_r_sum), float(prior_i_sum)))
+        if np.ndim(prior_r_sum) == 0:
+            _lib.check(self._lib.cal_solver_set_regularization(self._h, code, float(prior_r_sum), float(prior_i_sum)))
+            return
+        pr = np.ascontiguousarray(prior_r_sum, dtype=np.float64)
+        pi = np.ascontiguousarray(prior_i_sum, dtype=np.float64)
+        if pr.shape != (self.nslices,) or pi.shape != (self.nslices,):
+            raise ValueError(f"expected {self.nslices} priors per component")
+        _lib.check(self._lib.cal_solver_set_regularization_slices(self._h, code, _ptr(pr), _ptr(pi)))
 
     def set_optimizer(self, optimizer="Adamax", **opt_kwargs):
         opt_id = OPTIMIZERS[optimizer]  # KeyError for anything else, like calibration.py:571
@@ -148,6 +157,12 @@ class HipFitSolver:
         _lib.check(self._lib.cal_solver_eval_loss(self._h, C.byref(loss)))
         return loss.value
 
+    def slice_losses(self):
+        """The loss of every time slice as of the last eval_loss / eval_grads."""
+        out = np.zeros(self.nslices, dtype=np.float64)
+        _lib.check(self._lib.cal_solver_get_slice_losses(self._h, _ptr(out)))
+        return out
+
     def eval_grads(self):
         gg_r = np.empty((self.nants, self.nfreqs), dtype=self.dtype)
         gg_i = np.empty_like(gg_r)
@@ -164,6 +179,17 @@ class HipFitSolver:
         res = _lib.RunResult()
         _lib.check(self._lib.cal_solver_run(self._h, C.byref(d), _ptr(losses), C.byref(res)))
         return losses[: res.nrecorded], bool(res.stopped), res.nupdates
+
+    def run_slices(self, nsteps, record=True, tol=1e-14, use_min=False, freeze_model=False):
+        """The same loop for every time slice of the solver at once (cal_solver_run_slices): each slice records its own
+        losses, applies the tolerance test and the use_min bookkeeping to its own loss and stops on its own.  Returns a
+        list with one (recorded losses, stopped, nupdates) per slice.  A non-finite loss in any slice raises (code
+        CAL_ERR_NONFINITE) after the others have finished."""
+        d = _lib.RunDesc(int(nsteps), int(bool(record)), int(bool(use_min)), int(bool(freeze_model)), float(tol))
+        losses = np.zeros((self.nslices, max(int(nsteps), 1)), dtype=np.float64)
+        res = (_lib.RunResult * self.nslices)()
+        _lib.check(self._lib.cal_solver_run_slices(self._h, C.byref(d), _ptr(losses), res))
+        return [(losses[t, : res[t].nrecorded].copy(), bool(res[t].stopped), res[t].nupdates) for t in range(self.nslices)]
 
     def model(self):
         m_r = np.empty((self.nbls, self.nfreqs), dtype=self.dtype)

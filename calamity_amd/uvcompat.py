@@ -106,7 +106,7 @@ class SimpleUVData:
         out = copy.copy(self)
         for k, v in self.__dict__.items():
             if isinstance(v, np.ndarray):
-                out.__dict__[k] = v.copy()
+                out.__dict__[k] = memo[id(v)] if id(v) in memo else v.copy()  # (memo: arrays the caller will replace anyway)
             elif isinstance(v, (list, tuple)):
                 out.__dict__[k] = copy.copy(v)
         out._ap_index = dict(self._ap_index)

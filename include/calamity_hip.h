@@ -98,7 +98,16 @@ typedef struct cal_problem_desc {
                                     baseline in the time slices one solver fits together (calibration.py:1160-1167 fits them one after
                                     another).  Both must be single-baseline groups on the same basis rows.  Such baselines are
                                     processed together: their tiles are read ONCE per pass for all of them. */
+  int32_t nslices;               /* 0 or 1: one fit.  T > 1: the solver holds T independent fits -- the (polarization, time) slices that
+                                    calibrate_and_model_tensor fits one after another (calibration.py:1160-1167) -- over the same kind of
+                                    array: nants = T * (antennas of one slice), slice t owns antennas [t nants / T, (t + 1) nants / T), a
+                                    baseline's two antennas and all baselines of a fitting group lie in ONE slice, groups are listed slice
+                                    by slice, every slice has at least one group; T <= CAL_MAX_SLICES.  Each slice keeps its own loss,
+                                    regulariser sums and priors, tolerance stop, use_min snapshot and optimizer iteration count
+                                    (cal_solver_run_slices); a stopped slice's parameters freeze while the others go on. */
+  int32_t reserved;
 } cal_problem_desc;
+#define CAL_MAX_SLICES 256
 
 typedef struct cal_optimizer_desc { /* **opt_kwargs -> tf.optimizers.X(...), calibration.py:571; semantics: Keras OptimizerV2
                                      * (TensorFlow 2.4 - 2.10), formulae in fit_kernels.hpp: optimizer_step */
@@ -127,7 +136,7 @@ typedef struct cal_run_result {
   int32_t nrecorded; /* losses written to losses_out by this call */
   int32_t stopped;   /* 1 if the tolerance test ended the loop */
   int32_t nupdates;  /* optimizer updates applied by this call */
-  int32_t reserved;
+  int32_t nonfinite; /* 1 if the loss became NaN/Inf (the call then returns CAL_ERR_NONFINITE) */
 } cal_run_result;
 
 typedef struct cal_kernel_timing { /* HIP-event timing of the dominant kernel of a pass: the fused basis-streaming kernel or the dense kernel (bench.py roofline) */
@@ -163,6 +172,8 @@ int cal_solver_set_problem(cal_solver* s, const cal_problem_desc* desc);
 int cal_solver_set_data(cal_solver* s, const void* data_r, const void* data_i, const void* wgts);
 /* model_regularization="sum": priors of calibration.py:619-625; mode = cal_regularization */
 int cal_solver_set_regularization(cal_solver* s, int mode, double prior_r_sum, double prior_i_sum);
+/* the same with one pair of priors per time slice (cal_problem_desc::nslices): prior_*_sum [nslices] */
+int cal_solver_set_regularization_slices(cal_solver* s, int mode, const double* prior_r_sum, const double* prior_i_sum);
 int cal_solver_set_optimizer(cal_solver* s, const cal_optimizer_desc* desc); /* also zeroes moments and t */
 
 /* tf.Variable(g_r), ... calibration.py:596-603.  gains [nants][nfreqs]; coefficients flat in group order,
@@ -180,11 +191,20 @@ int cal_solver_set_moments(cal_solver* s, const void* gm_r, const void* gm_i, co
                            const void* cm_r, const void* cm_i, const void* cv_r, const void* cv_i, int64_t t);
 
 /* loss_function() alone: mse_chunked / mse_chunked_sum_regularized, calibration.py:1612-1656 */
-int cal_solver_eval_loss(cal_solver* s, double* loss);
+int cal_solver_eval_loss(cal_solver* s, double* loss); /* several time slices: the sum of their losses */
+/* the loss of every time slice as of the last cal_solver_eval_loss / cal_solver_eval_grads: losses [nslices] */
+int cal_solver_get_slice_losses(cal_solver* s, double* losses);
 /* tape.gradient(loss, vars), calibration.py:664-666, without the update (parity tests) */
 int cal_solver_eval_grads(cal_solver* s, double* loss, void* gg_r, void* gg_i, void* gc_r, void* gc_i);
 /* train_step() x nsteps with the loop semantics of calibration.py:681-717; losses_out: [nsteps] doubles or NULL */
 int cal_solver_run(cal_solver* s, const cal_run_desc* run, double* losses_out, cal_run_result* result);
+/* The same loop for every time slice of the solver at once (cal_problem_desc::nslices; the time loop of calibration.py:1160-1167,
+ * :1244-1269 as ONE batch): each train step advances every slice that has not stopped; slice t records its own losses
+ * (losses_out [nslices][run->nsteps], row t holds results[t].nrecorded values), applies the tolerance test of :712-717 and the
+ * use_min bookkeeping of :702-710 to ITS loss, and stops on its own -- its gains and coefficients then stay as they are.
+ * cal_solver_get_params(which = 1) holds every slice's own minimum.  results: [nslices].  A non-finite loss stops that slice
+ * only; the call then returns CAL_ERR_NONFINITE after the other slices have finished (results[t].nonfinite tells which). */
+int cal_solver_run_slices(cal_solver* s, const cal_run_desc* run, double* losses_out, cal_run_result* results);
 /* yield_fg_model_array, calibration.py:402-444, per baseline instead of a nants x nants cube: [nbls][nfreqs] */
 int cal_solver_model(cal_solver* s, void* model_r, void* model_i);
 /* tensorize_fg_coeffs, calibration.py:828-913: per group least squares of src on the basis with samples of zero

@@ -1,0 +1,125 @@
+"""The kept entry point with its time loop as ONE batch (calibrate_and_model_tensor(batch_slices=...), devices=[...]).
+
+The reference fits the (polarization, time) slices one after another (calibration.py:1160-1167, :1244-1269).  The batched
+call must return what that loop returns: the same ``fit_history[pol][time]["loss"]`` (length included: every slice applies
+the tolerance test of :712-717 to its own loss), gains, model and residual -- with slices that stop at different steps, a
+skipped slice (:1173-1177, :1301-1309), use_min (:702-710), both regularisers -- to rounding (fp64: 1e-10), and a call that
+shares the fitting groups out over two workers (here: two workers on the one GPU, exchanging through host memory) must equal
+the one-worker call."""
+import time as _time
+
+import numpy as np
+import pytest
+
+from calamity_amd import calibration, synthetic, uvcompat
+
+pytestmark = pytest.mark.gpu
+
+
+def _five_times(seed=7, nants=7, nfreqs=64, ntimes=5, skip=3):
+    """Five times of one array: different noise levels (so the fits stop at different steps), one time flagged away."""
+    uvd, sky, vecs = synthetic.make_uvdata(nants=nants, nfreqs=nfreqs, ntimes=ntimes, seed=seed, redundant=True, flag_frac=0.02)
+    rng = np.random.default_rng(seed)
+    times = np.unique(uvd.time_array)
+    amp = np.sqrt(np.mean(np.abs(uvd.data_array) ** 2))
+    for k, t in enumerate(times):
+        sel = np.isclose(uvd.time_array, t, atol=1e-7, rtol=0.0)
+        noise = amp * 10.0 ** (-2.0 - 0.5 * k)
+        shape = uvd.data_array[sel].shape
+        uvd.data_array[sel] += noise * (rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
+    if skip is not None:
+        sel = np.isclose(uvd.time_array, times[skip], atol=1e-7, rtol=0.0)
+        uvd.flag_array[sel] = True
+    return uvd, sky
+
+
+def _same(a, b, rtol):
+    assert np.linalg.norm(np.asarray(a) - np.asarray(b)) <= rtol * max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def _equal_outputs(out1, out2, ntimes, rtol, skipped=()):
+    (m1, r1, g1, h1), (m2, r2, g2, h2) = out1, out2
+    assert sorted(h1) == sorted(h2)
+    for pol in h1:
+        assert sorted(h1[pol]) == sorted(h2[pol]) == [t for t in range(ntimes) if t not in skipped]
+        for ti in h1[pol]:
+            l1, l2 = np.asarray(h1[pol][ti]["loss"], dtype=np.float64), np.asarray(h2[pol][ti]["loss"], dtype=np.float64)
+            assert len(l1) == len(l2), (pol, ti, len(l1), len(l2))
+            np.testing.assert_allclose(l1, l2, rtol=rtol)
+    _same(m1.data_array, m2.data_array, rtol)
+    _same(r1.data_array, r2.data_array, rtol * 1e2)  # a difference of nearly equal numbers
+    _same(g1.gain_array, g2.gain_array, rtol)
+    assert np.array_equal(g1.flag_array, g2.flag_array) and np.array_equal(m1.flag_array, m2.flag_array) and np.array_equal(r1.flag_array, r2.flag_array)
+
+
+@pytest.mark.parametrize("reg, use_min", [("sum", True), ("post_hoc", False)])
+def test_batched_call_equals_the_loop(reg, use_min):
+    uvd, sky = _five_times()
+    kw = dict(min_dly=2.0 / 0.3, offset=2.0 / 0.3, uvdata=uvd, gains=None, sky_model=None, maxsteps=600, tol=3e-9, correct_resid=True,
+              correct_model=True, optimizer="Adam", learning_rate=1e-2, dtype=np.float64, model_regularization=reg, use_min=use_min)
+    loop = calibration.calibrate_and_model_dpss(batch_slices=False, **kw)
+    batched = calibration.calibrate_and_model_dpss(**kw)  # the default
+    _equal_outputs(loop, batched, 5, 1e-10, skipped=(3,))
+    n = [len(loop[3][0][t]["loss"]) for t in sorted(loop[3][0])]
+    assert len(set(n)) > 1 and min(n) < 600, n  # the slices did stop on their own, at different steps
+    # the skipped time: fully flagged, zero model, unity gains (test_calibration.py:633-640)
+    t3 = np.unique(uvd.time_array)[3]
+    sel = np.isclose(uvd.time_array, t3, atol=1e-7, rtol=0.0)
+    m, r, g, _ = batched
+    assert np.all(m.flag_array[sel]) and np.all(r.flag_array[sel]) and np.all(m.data_array[sel] == 0)
+    assert np.all(uvcompat.gain4(g.gain_array)[:, :, 3, 0] == 1.0) and np.all(uvcompat.gain4(g.flag_array)[:, :, 3, 0])
+    # two at a time: batches of 2, 2 (the skipped slice takes no place)
+    two = calibration.calibrate_and_model_dpss(batch_slices=2, **kw)
+    _equal_outputs(loop, two, 5, 1e-10, skipped=(3,))
+
+
+@pytest.mark.parametrize("layout", ["shared", "stream"])
+def test_batched_float32_and_layouts(layout):
+    uvd, sky = _five_times(seed=11, skip=None)
+    kw = dict(min_dly=2.0 / 0.3, offset=2.0 / 0.3, uvdata=uvd, gains=None, sky_model=None, maxsteps=60, tol=1e-30, optimizer="Adamax",
+              learning_rate=1e-2, dtype=np.float32, layout=layout, nsamples_in_weights=True, use_model_snr_weights=True)
+    loop = calibration.calibrate_and_model_dpss(batch_slices=False, **kw)
+    batched = calibration.calibrate_and_model_dpss(**kw)
+    _equal_outputs(loop, batched, 5, 2e-4)
+
+
+def test_two_workers_on_one_gpu_equal_one_worker():
+    """devices=[0, 0]: the fitting groups of every slice are shared out over two workers (threads of this process, each with
+    its own solver) that exchange gain gradients and per-slice loss sums every step -- against the one-worker call."""
+    uvd, sky = _five_times(seed=13, nants=8)
+    kw = dict(min_dly=2.0 / 0.3, offset=2.0 / 0.3, uvdata=uvd, gains=None, sky_model=None, maxsteps=300, tol=3e-9, correct_resid=True,
+              optimizer="Adam", learning_rate=1e-2, dtype=np.float64, use_min=True)
+    one = calibration.calibrate_and_model_dpss(devices=[0], **kw)
+    two = calibration.calibrate_and_model_dpss(devices=[0, 0], **kw)
+    _equal_outputs(one, two, 5, 1e-10, skipped=(3,))
+    three = calibration.calibrate_and_model_dpss(devices=[0, 0, 0], model_regularization=None, **dict(kw, sky_model=sky))
+    one_n = calibration.calibrate_and_model_dpss(devices=[0], model_regularization=None, **dict(kw, sky_model=sky))
+    _equal_outputs(one_n, three, 5, 1e-10, skipped=(3,))
+
+
+def test_batching_raises_the_step_rate_of_small_fits():
+    """Tutorial scale (20 antennas x 64 channels): a step of one slice is bound by launch latency, sixteen slices per launch
+    cost little more -- the per-slice step rate of a T = 16 call against a T = 1 call (>= 8x)."""
+    from calamity_amd.batched import SliceBatchFitter
+
+    p, _, start = synthetic.make_config("tutorial")
+    rates = {}
+    for nt in (1, 16):
+        f = SliceBatchFitter(p, nt, dtype=np.float32, layout="shared", devices=[0])
+        cat = lambda a: np.concatenate([a] * nt)  # noqa: E731
+        f.set_data(cat(p.data_r), cat(p.data_i), cat(p.wgts))
+        f.set_params(cat(start["g_r"]), cat(start["g_i"]), cat(start["c_r"]), cat(start["c_i"]))
+        f.set_regularization(None)
+        f.set_optimizer("Adam", learning_rate=1e-2)
+        f.run_slices(64, record=False)
+        best = 0.0
+        for _ in range(3):
+            t0 = _time.perf_counter()
+            res = f.run_slices(2048, record=True, tol=0.0)
+            dt = _time.perf_counter() - t0
+            best = max(best, 2048 * nt / dt)
+        assert all(len(r[0]) == 2048 for r in res)
+        rates[nt] = best
+        f.close()
+    print(f"slice-steps/s: T=1 {rates[1]:.0f}, T=16 {rates[16]:.0f} ({rates[16] / rates[1]:.1f}x)")
+    assert rates[16] >= 8.0 * rates[1], rates
