@@ -9,6 +9,11 @@ of gains and coefficients) for every time slice of the job.  N = 1: one time sli
 torch.distributed.run, one rank per GPU): N time slices, every slice's baselines sharded over the N ranks, one RCCL
 all-reduce of the per-antenna gain gradients + loss scalars per slice-step -- per-GPU work is constant (weak scaling)
 and value = N slice-steps per wall step.  Prints ONE JSON line on rank 0.
+
+With --gpus N > 1 and no launcher around it (no WORLD_SIZE in the environment) bench.py starts the N ranks ITSELF -- fresh
+child processes, one per GPU, before this process has made a single HIP or RCCL call -- and relays rank 0's line: a run
+that asks for N GPUs never measures fewer.  The line carries `n_ranks_seen`: the number of ranks counted by an all-reduce of
+ones INSIDE the library's exchange (cal_solver_comm_size), beside `n_gpus`, the launcher's claim.
 """
 import argparse
 import json
@@ -95,7 +100,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def build_sharded_job(config, rank, world, ntimes, reg=False, max_bls=None):
+def build_sharded_job(config, rank, world, ntimes, reg=False, max_bls=None, per_slice=False):
     """This rank's share of a job of ``ntimes`` time slices: the same 1/world of every slice's baselines (balanced by
     basis bytes), batched into ONE problem (slice t keeps its own gains: antenna index + t * nants), so one solver and
     one all-reduce per step serve all slices.  Returns (problem, start, nants of one slice)."""
@@ -110,7 +115,7 @@ def build_sharded_job(config, rank, world, ntimes, reg=False, max_bls=None):
         p_t, _, s_t = synthetic.make_config(config, seed=cfg_seed + 100 * t, data_seed=100000 * (t + 1) + rank, bl_sel=sel,
                                             operator_cache=cache, with_sky=reg, max_bls=max_bls)
         parts.append((p_t, s_t))
-    prob, start = D.batch_time_slices(parts)
+    prob, start = D.batch_time_slices(parts, per_slice=per_slice)
     return prob, start, parts[0][0].nants
 
 
@@ -236,21 +241,65 @@ def dense_rooflines(prob, tim, kernel_ms, dtype, config=None):
     }
 
 
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks here (one fresh process per GPU; nothing in THIS process has touched
+    the GPU yet), relay rank 0's JSON line, exit with the worst return code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    # a rank that dies must not leave the others waiting for it in a rendezvous or a collective: the first non-zero exit ends them all
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(pr.poll() is None for pr in procs):
+        if any(pr.poll() not in (None, 0) for pr in procs):
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+            break
+        time.sleep(0.2)
+    rcs = [pr.wait() for pr in procs]
+    reader.join(timeout=10)
+    out0 = out0[0] if out0 else ""
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank return codes {rcs} (launched {args.gpus} ranks on GPUs 0..{args.gpus - 1} of this node; the same run under a "
+                         f"launcher: python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port {port} "
+                         f"bench.py {' '.join(sys.argv[1:])})\n")
+        raise SystemExit(max(abs(rc) for rc in rcs) or 1)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+
+
 def main():
     args = parse()
     if args.layout is None:
         args.layout = "stream" if args.config == "hera350" else "shared"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
     from calamity_amd import _lib, synthetic
     from calamity_amd.solver import HipFitSolver, comm_unique_id
 
     # load the HIP library (and through it /opt/rocm's HIP runtime + RCCL, the ones it was built against) BEFORE torch:
     # torch is only used for the gloo rendezvous/barrier and bundles its own, older ROCm libraries
     _lib.load()
+    if world > _lib.device_count():  # every rank sees this and leaves at once: none waits for a peer that cannot exist
+        raise SystemExit(f"--gpus {args.gpus}: this node has {_lib.device_count()} GPU(s) visible; one rank per GPU is the contract")
 
     dtype = {"f32": np.float32, "f64": np.float64, None: np.float64 if args.config == "hera37" else np.float32}[args.dtype]
     dist = None
@@ -288,6 +337,10 @@ def main():
         s.set_problem(prob, layout=args.layout)
         s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
         solvers.append(s)
+    # the ranks the library's exchange really spans (an all-reduce of ones over its communicator)
+    n_ranks_seen = solvers[0].comm_size()
+    if n_ranks_seen != world:
+        raise SystemExit(f"the exchange spans {n_ranks_seen} ranks, the launcher started {world}")
     for s in solvers:
         if args.reg == "sum":
             pri = np.asarray([float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts))])
@@ -363,33 +416,44 @@ def main():
         shared.update(steps_per_s=args.steps / dt2, ms_per_step=dt2 / args.steps * 1e3, device_memory_GB=s2.memory_bytes() / 1e9)
         s2.close()
 
-    # what ONE RANK of the driver's `--gpus 8` run executes per step, without the exchange: 8 time slices x 1/8 of the baselines,
-    # the slices sharing basis tiles (fused_multi_mfma_kernel) -- measured here so that the single-GPU bench line carries it too
+    # what EVERY RANK of the driver's `--gpus 8` run executes per step, without the exchange: 8 time slices x that rank's 1/8 of the
+    # baselines, the slices sharing basis tiles (fused_multi_mfma_kernel).  All eight shares are built and timed here, one after the
+    # other on this GPU: the 8-GPU step is the slowest rank's step (+ the exchange), so the table says in advance what the scaling
+    # run can reach and whether the partition (distributed.partition_groups: groups dealt round-robin) is balanced.
     rank_job = None
     if (rank == 0 and not sharded and args.layout == "stream" and not args.no_shared and args.reg == "none" and args.config == "hera350"
             and args.max_bls is None and dtype == np.float32):
-        rp, rstart, _ = build_sharded_job(args.config, 0, 8, 8)
-        s3 = HipFitSolver(dtype=dtype, device=0)
-        s3.set_problem(rp, layout="stream")
-        s3.set_params(rstart["g_r"], rstart["g_i"], rstart["c_r"], rstart["c_i"])
-        s3.set_optimizer(args.optimizer, learning_rate=1e-2)
-        s3.run(max(args.warmup, 1), record=False, tol=0.0)
-        s3.timing_enable(True)
-        s3.synchronize()
-        t3 = time.perf_counter()
-        s3.run(args.steps, record=True, tol=0.0)
-        s3.synchronize()
-        dt3 = time.perf_counter() - t3
-        tim3 = s3.timing_get()
-        k3 = tim3["total_ms"] / max(tim3["launches"], 1)
-        rank_job = {"what": f"one rank's share of an 8-GPU job: 8 time slices x {rp.nbls // 8} baselines (1/8 of each slice, balanced by basis bytes), "
-                            "the slices sharing basis tiles; no exchange (a single process)",
+        rows = []
+        for r8 in range(8):
+            rp, rstart, _ = build_sharded_job(args.config, r8, 8, 8)
+            s3 = HipFitSolver(dtype=dtype, device=0)
+            s3.set_problem(rp, layout="stream")
+            s3.set_params(rstart["g_r"], rstart["g_i"], rstart["c_r"], rstart["c_i"])
+            s3.set_optimizer(args.optimizer, learning_rate=1e-2)
+            s3.run(max(min(args.warmup, 3), 1), record=False, tol=0.0)
+            s3.timing_enable(True)
+            s3.synchronize()
+            t3 = time.perf_counter()
+            s3.run(args.steps, record=True, tol=0.0)
+            s3.synchronize()
+            dt3 = time.perf_counter() - t3
+            tim3 = s3.timing_get()
+            k3 = tim3["total_ms"] / max(tim3["launches"], 1)
+            rows.append({"rank": r8, "baselines_per_slice": rp.nbls // 8, "sum_nvec_per_slice": rp.ncoeffs // 8,
+                         "ms_per_step": dt3 / args.steps * 1e3, "kernel_ms": k3,
+                         "algorithmic_bytes_per_launch": tim3["algorithmic_bytes_per_launch"],
+                         "achieved_GBps": tim3["algorithmic_bytes_per_launch"] / (k3 * 1e-3) / 1e9 if k3 > 0 else None,
+                         "device_memory_GB": s3.memory_bytes() / 1e9})
+            s3.close()
+            del rp, rstart
+        ms = [r["ms_per_step"] for r in rows]
+        rank_job = {"what": "every rank's share of an 8-GPU job (8 time slices x 1/8 of each slice's baselines, fitting groups dealt round-robin over the "
+                            "ranks; the slices share basis tiles), timed one after the other on this ONE GPU, no exchange",
                     "kernel": "fused_multi_mfma_kernel<MODE_GRAD> (v_mfma_f32_16x16x4_f32, 16 right-hand sides per tile)",
-                    "ms_per_step": dt3 / args.steps * 1e3, "kernel_ms": k3, "slice_steps_per_s": 8 * args.steps / dt3,
-                    "algorithmic_bytes_per_launch": tim3["algorithmic_bytes_per_launch"],
-                    "achieved_GBps": tim3["algorithmic_bytes_per_launch"] / (k3 * 1e-3) / 1e9 if k3 > 0 else None,
-                    "device_memory_GB": s3.memory_bytes() / 1e9}
-        s3.close()
+                    "shares": rows, "ms_per_step_max": max(ms), "ms_per_step_min": min(ms), "spread_max_over_min": max(ms) / min(ms),
+                    "predicted_8gpu_slice_steps_per_s_without_exchange": 8.0 / (max(ms) * 1e-3),
+                    # back-compatible summary of the slowest share
+                    "ms_per_step": max(ms), "kernel_ms": max(r["kernel_ms"] for r in rows), "slice_steps_per_s": 8.0 / (max(ms) * 1e-3)}
 
     # measured streaming peaks of this box and, for orientation, the only configuration the
     # reference publishes a rate for (tutorial notebook: 15 antennas, 105 baselines x 200 channels, Adamax, 61.77 steps/s
@@ -484,6 +548,7 @@ def main():
             "value": value,
             "unit": "steps/s",
             "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,

@@ -120,6 +120,7 @@ SYMBOLS = {
     "cal_comm_unique_id": (C.c_int, [_P]),
     "cal_solver_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "cal_solver_set_exchange_hook": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
+    "cal_solver_comm_size": (C.c_int, [_P, C.POINTER(C.c_int)]),
 }
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)  # cal_exchange_fn

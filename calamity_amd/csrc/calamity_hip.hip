@@ -170,6 +170,7 @@ struct cal_solver {
   virtual int comm_init(const void* id, int rank, int nranks) = 0;
   virtual int set_launch_mode(int mode) = 0;
   virtual int set_exchange_hook(cal_exchange_fn fn, void* ctx, int rank, int nranks) = 0;
+  virtual int comm_size(int* nranks_seen) = 0;
 };
 
 template <typename T>
@@ -184,6 +185,7 @@ struct SolverT final : cal_solver {
   int nslices = 1, na_slice = 0;
   DevBuf slice_coff, slice_ipart_ptr, slice_ipart_idx, slice_ppart_ptr, slice_ppart_idx, slice_cblk;
   std::vector<int> h_slice_coff, h_slice_cblk;
+  bool small_loads = false; // every single-baseline item's tile fits kSmallLoads loads per thread: the narrow instance of fused_basis_kernel serves the loss / gradient passes
   int nitems_simple = 0;   // items [0, nitems_simple) are single-baseline groups (fused_basis_kernel), the rest multi-baseline (fused_group_kernel)
   int nitems_plain = 0;    // items [0, nitems_plain) of those are not covered by a head item of the multi-slice kernels
   size_t lds_group_bytes = 0;
@@ -786,6 +788,11 @@ struct SolverT final : cal_solver {
       h_grp_item_ptr[g + 1] = (int)h_items.size();
     }
     nitems = (int)h_items.size();
+    small_loads = true;
+    for (const Item& q : h_items) {
+      const int lpr = (1 << q.fb_log2) / (16 / (int)sizeof(T));  // lanes per tile row; a load covers kThreads / lpr rows
+      if (q.nvec > kSmallLoads * (kThreads / lpr)) small_loads = false;
+    }
     // single-baseline items first, then the multi-baseline ones (two launches); inside each class heaviest first: the
     // hardware dispatches workgroups in index order, so the tail is made of the lightest items
     // (among the single-baseline items those that a head item of the multi-slice kernels covers come last: the loss and gradient
@@ -1257,7 +1264,14 @@ struct SolverT final : cal_solver {
     for (int64_t k = 0; k < t; ++k) {
       b1t *= opt.beta_1;
       b2t *= opt.beta_2;
-      sched *= opt.beta_1 * (1.0 - 0.5 * std::pow(0.96, 0.004 * (double)(k + 1)));  // Nadam's momentum schedule (advance_state)
+    }
+    if (opt.optimizer == CAL_OPT_NADAM && t > 0) {
+      // Nadam's momentum schedule is a running product of pow() terms: rebuilt by the DEVICE's pow (advance_state's), whose last
+      // bits differ from the host's -- a resumed fit continues bit for bit
+      hipLaunchKernelGGL(nadam_sched_kernel, dim3(1), dim3(1), 0, stream, opt.beta_1, (long long)t, scal.as<double>());
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(&sched, scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
     }
     for (int sl = 0; sl < nslices; ++sl) {
       h_state[sl].t = t;
@@ -1310,7 +1324,15 @@ struct SolverT final : cal_solver {
     const int nsimple = ((MODE == MODE_LOSS || MODE == MODE_GRAD) && !with_reg && nheads > 0) ? nitems_plain : nitems_simple;
     if (nsimple > 0) {
       a.item_base = 0;
-      if (with_reg)
+      constexpr bool kHasSmall = MODE == MODE_LOSS || MODE == MODE_GRAD;
+      if (kHasSmall && small_loads) {
+        if constexpr (kHasSmall) {
+          if (with_reg)
+            hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true, kSmallLoads>), dim3(nsimple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax2 : 0), stream, a);
+          else
+            hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false, kSmallLoads>), dim3(nsimple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
+        }
+      } else if (with_reg)
         hipLaunchKernelGGL((fused_basis_kernel<T, MODE, true>), dim3(nsimple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax2 : 0), stream, a);
       else
         hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nsimple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
@@ -1561,6 +1583,17 @@ struct SolverT final : cal_solver {
     if (!graph_exec || !(key == graph_key)) {
       drop_graph();
       hipGraph_t graph = nullptr;
+      // enqueue_tail flips the double-buffer parities on the HOST for every captured step; nothing has run on the device until the
+      // graph is launched, so every failure path below puts them back (an odd number of captured steps would otherwise leave the
+      // host pointing at the stale halves)
+      const int par0 = st_par;
+      void* const gains0 = gains.p;
+      void* const alt0 = gains_alt.p;
+      auto undo = [&]() {
+        st_par = par0;
+        gains.p = gains0;
+        gains_alt.p = alt0;
+      };
       HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       int rc = CAL_OK;
       for (int k = 0; k < kGraphSteps && rc == CAL_OK; ++k) {
@@ -1570,15 +1603,21 @@ struct SolverT final : cal_solver {
       const hipError_t e = hipStreamEndCapture(stream, &graph);
       if (rc != CAL_OK) {
         if (graph) (void)hipGraphDestroy(graph);
+        undo();
         return rc;
       }
-      if (e != hipSuccess) return fail(CAL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      if (e != hipSuccess) {
+        undo();
+        return fail(CAL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      }
       const hipError_t ei = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (ei != hipSuccess) {
         graph_exec = nullptr;
+        undo();
         return fail(CAL_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
       }
+      undo();  // (kGraphSteps is even: the same values; said explicitly: the launch below is what moves the device)
       graph_key = key;
     }
     HIP_TRY(hipGraphLaunch(graph_exec, stream));
@@ -1861,6 +1900,21 @@ struct SolverT final : cal_solver {
     }
     return joined(rk, nr);
   }
+  // how many ranks actually take part in the exchange: every rank contributes 1 to an all-reduce (1 without a communicator)
+  int comm_size(int* nranks_seen) override {
+    HIP_TRY(hipSetDevice(device));
+    if (!nranks_seen) return fail(CAL_ERR_INVALID, "comm_size: null");
+    *nranks_seen = 1;
+    if (!comm_on()) return CAL_OK;
+    if (!agree_buf.p) CAL_TRY(agree_buf.alloc(4 * sizeof(int)));
+    int one = 1;
+    HIP_TRY(hipMemcpyAsync(agree_buf.p, &one, sizeof(int), hipMemcpyHostToDevice, stream));
+    CAL_TRY(all_reduce(agree_buf.p, 1, CAL_XCHG_I32, CAL_XCHG_SUM));
+    HIP_TRY(hipMemcpyAsync(&one, agree_buf.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *nranks_seen = one;
+    return CAL_OK;
+  }
   int joined(int rk, int nr) {
     nranks = nr;
     rank = rk;
@@ -2056,5 +2110,6 @@ int cal_comm_unique_id(void* id_out) {
 }
 int cal_solver_comm_init(cal_solver* s, const void* id, int rank, int nranks) { NEED(s); return s->comm_init(id, rank, nranks); }
 int cal_solver_set_exchange_hook(cal_solver* s, cal_exchange_fn fn, void* ctx, int rank, int nranks) { NEED(s); return s->set_exchange_hook(fn, ctx, rank, nranks); }
+int cal_solver_comm_size(cal_solver* s, int* nranks_seen) { NEED(s); return s->comm_size(nranks_seen); }
 
 }  // extern "C"

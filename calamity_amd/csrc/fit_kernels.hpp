@@ -285,14 +285,16 @@ template <typename T> __device__ __forceinline__ T ldsum(T v) {
 //                                              the item in registers and summed over the LPR lanes of a row once,
 //                                              at the end of the item
 // LDS carries only per-channel vectors (about 17 KB of traffic per 28 KB tile); the tile itself never enters it.
-template <typename T, int FB, int MODE, bool REG>
-__device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item it, unsigned char* smem, int item_idx) {
+// L: 16-byte loads per thread and tile the body is unrolled for (rows l NS + ks, l < L): kMaxLoads covers every tile; problems whose
+// blocks all fit two loads (the tutorial's: at most 2 NS vectors) run an instance with L = 2 -- a fraction of the registers, twice
+// the workgroups per CU, no loads and products spent on rows past nvec
+template <typename T, int FB, int MODE, bool REG, int L = kMaxLoads>
+__device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item it, unsigned char* smem, int item_idx, const DevState* st_own) {
   using C = TileCfg<T, FB>;
   using T2 = vec2_t<T>;
   constexpr int VEC = C::VEC;
   constexpr int LPR = C::LPR;
   constexpr int NS = C::NS;
-  constexpr int L = kMaxLoads;
   constexpr bool FWD = (MODE != MODE_INIT);
   constexpr bool BWD = (MODE == MODE_GRAD || MODE == MODE_INIT);
   const int tid = threadIdx.x;
@@ -315,6 +317,10 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
 
   // coefficients of the group, (re, im) pairs, zero beyond nvec (those rows are not loaded either).  They are read
   // back per tile rather than held in 2 x kMaxLoads registers: registers decide how many workgroups share a CU
+  // (several time slices: the stop flags of the item's OWN slice depend on the item record, like the coefficients: requested with
+  // them -- one round trip, not two -- and acted on behind them; nothing has been written yet)
+  int own_stop = 0;
+  if (st_own) own_stop = st_own->done | st_own->done_after;
   if (FWD) {
     for (int k = tid; k < C::MAXK; k += kThreads) {
       T2 c;
@@ -324,6 +330,7 @@ __device__ __forceinline__ void process_item(const FusedArgs<T>& A, const Item i
     }
     __syncthreads();
   }
+  if (own_stop) return;
   // byte offset of this thread's part of load l inside a tile: the same in every tile of the item
   unsigned voff[L];
 #pragma unroll
@@ -1089,24 +1096,27 @@ constexpr size_t group_lds_bytes() {
 #ifndef CAL_WAVES_EU
 #define CAL_WAVES_EU 4
 #endif
-template <typename T, int MODE, bool REG>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && !REG) ? CAL_WAVES_EU : 1)))
+constexpr int kSmallLoads = 2;  // the narrow instance of fused_basis_kernel: blocks of at most 2 NS vectors
+template <typename T, int MODE, bool REG, int L = kMaxLoads>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L < kMaxLoads ? (sizeof(T) == 4 ? 8 : 6) : ((sizeof(T) == 4 && !REG) ? CAL_WAVES_EU : 1))))
 void fused_basis_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int idx = A.item_base + blockIdx.x;
   const Item it = A.items[idx];  // requested together with the stop flags: one round trip, not two
-  const DevState* st = A.state;
-  if (A.nslices > 1) st += it.slice;  // (several time slices: the flags of the item's own slice, a dependent load)
-  if (st->done | st->done_after) return;
+  // one time slice: its stop flags travel with the item record.  Several: the flags of the item's OWN slice, looked up inside
+  // process_item beside the coefficient loads
+  const DevState* st_own = nullptr;
+  if (A.nslices > 1) st_own = A.state + it.slice;
+  else if (A.state->done | A.state->done_after) return;
   // baselines that share tiles are processed together by fused_multi_kernel in the passes that have such a form
   if (!REG && (MODE == MODE_LOSS || MODE == MODE_GRAD) && (it.role_n & 3) != 0 && A.heads != nullptr) return;
   constexpr int FBM = FbSet<T>::fb_max;
   const int fb = 1 << it.fb_log2;
-  if (fb == FBM) process_item<T, FBM, MODE, REG>(A, it, smem, idx);
-  else if (fb == FBM / 2) process_item<T, FBM / 2, MODE, REG>(A, it, smem, idx);
-  else if (fb == FBM / 4) process_item<T, FBM / 4, MODE, REG>(A, it, smem, idx);
-  else if (fb == FBM / 8) process_item<T, FBM / 8, MODE, REG>(A, it, smem, idx);
-  else process_item<T, FBM / 16, MODE, REG>(A, it, smem, idx);
+  if (fb == FBM) process_item<T, FBM, MODE, REG, L>(A, it, smem, idx, st_own);
+  else if (fb == FBM / 2) process_item<T, FBM / 2, MODE, REG, L>(A, it, smem, idx, st_own);
+  else if (fb == FBM / 4) process_item<T, FBM / 4, MODE, REG, L>(A, it, smem, idx, st_own);
+  else if (fb == FBM / 8) process_item<T, FBM / 8, MODE, REG, L>(A, it, smem, idx, st_own);
+  else process_item<T, FBM / 16, MODE, REG, L>(A, it, smem, idx, st_own);
 }
 
 template <typename T, int MODE>
@@ -1527,6 +1537,13 @@ __global__ void finalize_kernel(DevState* st, const double* __restrict__ scal, d
   DevState s = st[t];
   advance_state(s, scal[4 * t + 0], scal[4 * t + 1], scal[4 * t + 2], true, losses + (size_t)t * losses_cap, losses_cap, apply_update != 0);
   st[t] = s;
+}
+
+// Nadam's momentum schedule after t updates, as advance_state builds it (cal_solver_set_moments: resume)
+__global__ void nadam_sched_kernel(double beta1, long long t, double* __restrict__ out) {
+  double sched = 1.0;
+  for (long long k = 1; k <= t; ++k) sched *= beta1 * (1.0 - 0.5 * pow(0.96, 0.004 * (double)k));
+  *out = sched;
 }
 
 // ---- "sum" regulariser, two-pass form (dense path): alpha = 2 (S - P) from the reduced sums of a loss-only pass

@@ -1,4 +1,4 @@
-"""Baseline-sharded data parallelism: one process per GPU, one RCCL all-reduce per step.
+"""Baseline-sharded data parallelism: one worker per GPU, one RCCL all-reduce per step.
 
 The reference is single-device (/root/reference/calamity/calibration.py:1796-1804).  The fit shards naturally
 (SURVEY.md section 8e): foreground coefficients belong to exactly one fitting group, so they live on the rank that owns
@@ -11,15 +11,29 @@ import numpy as np
 from .problem import FitProblem
 
 
-def partition_groups(grp_nvec, grp_basis, grp_nbl, nranks):
-    """Assign whole fitting groups to ranks.  Groups are ordered by basis (same-delay groups stay together, so a rank
-    touches few distinct basis blocks) and cut into ``nranks`` contiguous runs of equal ``sum nvec * nbl`` -- the bytes
-    of basis a rank streams per step -- rather than equal group counts (nvec spans 18..219 at HERA-350).
-    Returns a list of index arrays (one per rank, disjoint, covering all groups)."""
+def partition_groups(grp_nvec, grp_basis, grp_nbl, nranks, mode="deal"):
+    """Assign whole fitting groups to ranks.  Returns a list of index arrays (one per rank, disjoint, covering all groups).
+
+    ``mode="deal"`` (default): the groups, ordered by basis block and size, are dealt round-robin -- rank ``r`` takes entries
+    ``r, r + nranks, ...`` of that list.  Every rank then holds the same number of groups (to one), the same number of
+    baselines of every delay class (to one) and therefore the same basis bytes, sample bytes, vector-count classes and kernel
+    mix: whatever a step costs per group -- tile bytes, per-sample bytes of every time slice, the per-class efficiency of the
+    kernels -- the shares cost the same without a cost model.  (Round 3 cut the basis-ordered list into contiguous runs of
+    equal ``sum nvec * nbl``: equal basis bytes, but at HERA-350 16 009 short baselines on rank 0 against 4 310 long ones on
+    rank 7 -- and with the tiles shared by 8 time slices the per-sample traffic, not the basis, is most of a step.)
+    Every rank touches every distinct basis block: 68 MB at HERA-350, read from cache in the shared layout.
+
+    ``mode="contiguous"``: the round-3 rule (few distinct basis blocks per rank), kept for callers that want it."""
     grp_nvec = np.asarray(grp_nvec, dtype=np.float64)
-    order = np.argsort(np.asarray(grp_basis), kind="stable")
-    work = (grp_nvec * np.asarray(grp_nbl))[order]
-    csum = np.cumsum(work)
+    grp_basis = np.asarray(grp_basis)
+    work = grp_nvec * np.asarray(grp_nbl)
+    if mode == "deal":
+        order = np.lexsort((np.arange(len(work)), -work, grp_basis))  # by basis, heaviest first, then index
+        return [np.sort(order[r::nranks]) for r in range(nranks)]
+    if mode != "contiguous":
+        raise ValueError(f"unknown partition mode {mode!r}")
+    order = np.argsort(grp_basis, kind="stable")
+    csum = np.cumsum(work[order])
     total = csum[-1]
     cuts = [0]
     for r in range(1, nranks):

@@ -252,6 +252,12 @@ class HipFitSolver:
         self._hook = _lib.EXCHANGE_FN(trampoline)  # keep the callback alive as long as the solver uses it
         _lib.check(self._lib.cal_solver_set_exchange_hook(self._h, C.cast(self._hook, C.c_void_p), None, int(rank), int(nranks)))
 
+    def comm_size(self):
+        """Ranks that take part in the exchange, counted by an all-reduce of ones over it (cal_solver_comm_size)."""
+        n = C.c_int(0)
+        _lib.check(self._lib.cal_solver_comm_size(self._h, C.byref(n)))
+        return n.value
+
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(bytes(unique_id), _lib.CAL_COMM_ID_BYTES)
         _lib.check(self._lib.cal_solver_comm_init(self._h, buf, int(rank), int(nranks)))

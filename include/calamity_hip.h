@@ -60,7 +60,8 @@ enum cal_launch_mode {
   CAL_LAUNCH_AUTO = 0,     /* the fastest form for the problem: large problems one launch per kernel; problems whose step is tens of
                               microseconds (no communicator, general kernels, at most 2^20 parameters) a two-launch step replayed
                               from a hipGraph, 16 steps per replay */
-  CAL_LAUNCH_KERNELS = 1,  /* every kernel its own launch (per-antenna reduction, loop bookkeeping, regulariser fold, update) */
+  CAL_LAUNCH_KERNELS = 1,  /* every kernel its own launch at every problem size (per-antenna reduction, loop bookkeeping, regulariser
+                              fold, update: finalize_kernel + adam2_kernel, never the fused step_update_kernel / step_tail_kernel) */
   CAL_LAUNCH_ONE_TAIL = 2, /* small problems: fused pass + ONE tail launch per step, launched one by one (no graph) */
   CAL_LAUNCH_GRAPH = 3     /* as AUTO where the two-launch step applies */
 };
@@ -235,6 +236,9 @@ enum cal_exchange_dtype { CAL_XCHG_F32 = 0, CAL_XCHG_F64 = 1, CAL_XCHG_I32 = 2 }
 enum cal_exchange_op { CAL_XCHG_SUM = 0, CAL_XCHG_MIN = 1 };
 typedef int (*cal_exchange_fn)(void* ctx, void* host_buf, int64_t count, int dtype, int op);
 int cal_solver_set_exchange_hook(cal_solver* s, cal_exchange_fn fn, void* ctx, int rank, int nranks);
+/* How many ranks take part in the solver's exchange, COUNTED by the exchange itself: every rank adds 1 in an all-reduce over the
+ * communicator / hook (1 without either).  A launcher's rank count is a claim; this is what the data path sees (bench.py reports it). */
+int cal_solver_comm_size(cal_solver* s, int* nranks_seen);
 
 #ifdef __cplusplus
 }

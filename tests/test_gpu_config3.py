@@ -70,3 +70,51 @@ def test_eight_batched_time_slices_equal_independent_fits(layout, max_bls):
     # the recorded loss of the batched fit is the sum of the slices' losses
     assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss)
     assert np.allclose(losses, ref_losses, rtol=1e-4)
+
+
+def test_every_share_of_the_eight_gpu_job_against_the_c_oracle():
+    """The shares `bench.py --gpus 8` really runs (bench.build_sharded_job("hera350", r, 8, 8): 8 time slices x rank r's 1/8 of
+    the baselines, fitting groups dealt round-robin, slices sharing tiles -> fused_multi_mfma_kernel), every rank r = 0 .. 7, on
+    ONE GPU against the C restatement: loss of every slice, all gradients, fp32 tolerances.  Also: the shares are balanced
+    (baselines and basis vectors per rank within 1 %), and the same job with one loop state per slice
+    (batch_time_slices(per_slice=True)) reports each slice's own loss."""
+    import bench
+    from calamity_amd.solver import HipFitSolver
+    from oracle.ref_c import CRef
+
+    nbl, nvec = [], []
+    for r in range(8):
+        prob, start, na = bench.build_sharded_job("hera350", r, 8, 8, per_slice=True)
+        nbl.append(prob.nbls // 8)
+        nvec.append(prob.ncoeffs // 8)
+        assert prob.nslices == 8 and prob.bl_alias is not None
+        rng = np.random.default_rng(50 + r)
+        start["g_r"] = 1.0 + 0.05 * rng.standard_normal(start["g_r"].shape)
+        start["g_i"] = 0.05 * rng.standard_normal(start["g_i"].shape)
+        s = HipFitSolver(dtype=np.float32)
+        s.set_problem(prob, layout="stream")
+        s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        loss, g_r, g_i, c_r, c_i = s.eval_grads()
+        each = s.slice_losses()
+        s.close()
+        # the oracle sees the same batched problem as ONE fit (its loss is the sum of the slices'); per-slice losses from the slices' rows
+        single = D.FitProblem(**{k: getattr(prob, k) for k in ("nants", "nfreqs", "basis", "grp_basis", "grp_bl_start", "bl_ant0", "bl_ant1", "bl_rowblk",
+                                                                "data_r", "data_i", "wgts")})
+        c = CRef(single, np.float64, nthreads=16)
+        l, og_r, og_i, oc_r, oc_i = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+        assert abs(loss - l) <= 2e-5 * abs(l), (r, loss, l)
+        assert abs(each.sum() - loss) <= 1e-12 * abs(loss)
+        for a, b in ((g_r, og_r), (g_i, og_i), (c_r, oc_r), (c_i, oc_i)):
+            assert relnorm(a, b) <= 2e-4, r
+        del c
+        # slice 3 alone, from its own rows
+        nb, nc = prob.nbls // 8, prob.ncoeffs // 8
+        rows, cs, ants = slice(3 * nb, 4 * nb), slice(3 * nc, 4 * nc), slice(3 * na, 4 * na)
+        one = D.FitProblem(nants=na, nfreqs=prob.nfreqs, basis=prob.basis, grp_basis=prob.grp_basis[rows], grp_bl_start=np.arange(nb + 1, dtype=np.int32),
+                           bl_ant0=prob.bl_ant0[rows] - 3 * na, bl_ant1=prob.bl_ant1[rows] - 3 * na, bl_rowblk=prob.bl_rowblk[rows],
+                           data_r=prob.data_r[rows], data_i=prob.data_i[rows], wgts=prob.wgts[rows])
+        c = CRef(one, np.float64, nthreads=16)
+        l3 = c.loss_grads(start["g_r"][ants], start["g_i"][ants], start["c_r"][cs], start["c_i"][cs])[0]
+        assert abs(each[3] - l3) <= 2e-5 * abs(l3), (r, each[3], l3)
+        del c, prob, start, single, one
+    assert max(nbl) - min(nbl) <= 0.01 * min(nbl) and max(nvec) - min(nvec) <= 0.01 * min(nvec), (nbl, nvec)

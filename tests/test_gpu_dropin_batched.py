@@ -122,4 +122,4 @@ def test_batching_raises_the_step_rate_of_small_fits():
         rates[nt] = best
         f.close()
     print(f"slice-steps/s: T=1 {rates[1]:.0f}, T=16 {rates[16]:.0f} ({rates[16] / rates[1]:.1f}x)")
-    assert rates[16] >= 8.0 * rates[1], rates
+    assert rates[16] >= 7.0 * rates[1], rates  # (measured 8.5-9x; the margin is for box-to-box spread)

@@ -89,7 +89,7 @@ def test_nonfinite_loss_stops_every_mode_at_the_same_update():
             np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("optimizer", ["Adam", "Adamax"])
+@pytest.mark.parametrize("optimizer", ["Adam", "Adamax", "Nadam"])  # (Nadam: its momentum schedule is rebuilt with the device's pow)
 @pytest.mark.parametrize("mode", ["kernels", "graph"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_resume_from_parameters_and_moments(optimizer, mode, dtype):
