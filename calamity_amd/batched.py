@@ -27,10 +27,16 @@ def replicate_slices(prob, nt, groups=None, share_tiles=True):
     slice 0's (``bl_alias``: the STREAM layout then holds one copy and processes the slices of a baseline together).
     Returns (FitProblem with ``nslices = nt``, baseline indices of one slice, coefficient indices of one slice)."""
     groups = np.arange(prob.ngrps) if groups is None else np.asarray(groups)
+
+    def runs(starts, counts):  # concatenation of arange(start, start + count) without a python loop over 61 075 groups
+        starts, counts = np.asarray(starts, dtype=np.int64), np.asarray(counts, dtype=np.int64)
+        ends = np.cumsum(counts)
+        return np.repeat(starts - (ends - counts), counts) + np.arange(ends[-1] if len(ends) else 0, dtype=np.int64)
+
     starts, nbl_g = prob.grp_bl_start[groups], np.diff(prob.grp_bl_start)[groups]
-    bl = np.concatenate([np.arange(s, s + n) for s, n in zip(starts, nbl_g)]) if len(groups) else np.zeros(0, dtype=np.int64)
+    bl = runs(starts, nbl_g)
     coff = prob.grp_coff
-    cidx = np.concatenate([np.arange(coff[g], coff[g + 1]) for g in groups])
+    cidx = runs(coff[groups], coff[groups + 1] - coff[groups])
     used = np.unique(prob.grp_basis[groups])
     remap = -np.ones(len(prob.basis), dtype=np.int64)
     remap[used] = np.arange(len(used))

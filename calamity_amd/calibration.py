@@ -45,6 +45,8 @@ def chunk_fg_comp_dict_by_nbls(fg_model_comps_dict, use_redundancy=False, grp_si
     comps = dict(fg_model_comps_dict)
     if not use_redundancy:
         for fit_grp in list(comps.keys()):
+            if len(fit_grp) == 1 and len(fit_grp[0]) == 1:
+                continue  # one baseline: splitting it by redundant copy gives the same key back (61 075 of these at HERA-350)
             rlens = np.asarray([len(red_grp) for red_grp in fit_grp])
             if np.allclose(rlens, np.mean(rlens)) and len(rlens) < grp_size_threshold:
                 vectors = comps.pop(fit_grp)
@@ -131,8 +133,136 @@ def tensorize_fg_model_comps_dict(
 # ------------------------------------------------------------------------------------------------------------------
 # data / gains <-> arrays: calibration.py:193-399
 # ------------------------------------------------------------------------------------------------------------------
+def _baseline_rows(uvdata, prob, ants_map, time):
+    """Row of every baseline of ``prob`` in the blt axis of ``uvdata`` at ``time``, and whether the data hold the pair in the
+    reversed order (then the conjugate is wanted, calibration.py:263-278) -- by one (antenna, antenna) -> row table instead of a
+    dictionary lookup per baseline.  KeyError if a pair is in the data in neither order, like ``_key2inds``."""
+    cache = prob.__dict__.setdefault("_row_cache", {})
+    key = (id(uvdata), float(time), int(getattr(uvdata, "Nblts", 0)))
+    hit = cache.get(key)
+    if hit is not None and hit[0] is uvdata:
+        return hit[1], hit[2]
+    tsel = np.where(np.isclose(np.asarray(uvdata.time_array), time, rtol=0.0, atol=1e-7))[0]
+    nants = len(ants_map)
+    lut_keys = np.fromiter(ants_map.keys(), dtype=np.int64, count=nants)
+    lut_vals = np.fromiter(ants_map.values(), dtype=np.int64, count=nants)
+    order = np.argsort(lut_keys)
+    a1 = np.asarray(uvdata.ant_1_array)[tsel].astype(np.int64)
+    a2 = np.asarray(uvdata.ant_2_array)[tsel].astype(np.int64)
+
+    def to_index(a):  # antenna number -> index of ants_map (-1: not a gain antenna)
+        pos = np.clip(np.searchsorted(lut_keys[order], a), 0, nants - 1)
+        ok = lut_keys[order][pos] == a
+        return np.where(ok, lut_vals[order][pos], -1)
+
+    i1, i2 = to_index(a1), to_index(a2)
+    ok = (i1 >= 0) & (i2 >= 0)
+    table = np.full((nants, nants), -1, dtype=np.int64)
+    table[i1[ok], i2[ok]] = tsel[ok]
+    b0, b1 = np.asarray(prob.bl_ant0, dtype=np.int64), np.asarray(prob.bl_ant1, dtype=np.int64)
+    rows = table[b0, b1]
+    conj = rows < 0
+    if conj.any():
+        rows = np.where(conj, table[b1, b0], rows)
+        if (rows < 0).any():
+            n = int(np.where(rows < 0)[0][0])
+            inv = {v: k for k, v in ants_map.items()}
+            raise KeyError((inv[int(b0[n])], inv[int(b1[n])]))
+    if len(cache) > 64:
+        cache.clear()
+    cache[key] = (uvdata, rows, conj)
+    return rows, conj
+
+
 def _time_ind(times, inds, time):
     return inds[np.where(np.isclose(np.asarray(times)[inds], time, rtol=0.0, atol=1e-7))[0][0]]
+
+
+class _Baselines:
+    """The antenna index pairs of ``corr_inds`` as flat arrays, in chunk -> group -> baseline order (= the ragged baseline order
+    of the FitProblem built from the same dictionary)."""
+
+    def __init__(self, corr_inds):
+        pairs = [np.asarray(chunk, dtype=np.int64).reshape(-1, 2) for chunk in corr_inds]
+        flat = np.concatenate(pairs) if len(pairs) else np.zeros((0, 2), dtype=np.int64)
+        self.bl_ant0, self.bl_ant1 = flat[:, 0], flat[:, 1]
+        self.shapes = [(len(chunk), len(chunk[0])) for chunk in corr_inds]
+
+
+def _baselines_of(corr_inds):
+    hit = _baselines_of.cache.get(id(corr_inds))
+    if hit is None or hit[0] is not corr_inds:
+        if len(_baselines_of.cache) > 16:
+            _baselines_of.cache.clear()
+        hit = (corr_inds, _Baselines(corr_inds))
+        _baselines_of.cache[id(corr_inds)] = hit
+    return hit[1]
+
+
+_baselines_of.cache = {}
+
+
+def _tensorize_flat(uvdata, bls, ants_map, polarization, time, data_scale_factor=1.0, weights=None, nsamples_in_weights=False,
+                    dtype=np.float32, want_weights=True):
+    """The arithmetic of tensorize_data (calibration.py:193-310) on flat ``(nbls, nfreqs)`` arrays in the baseline order of
+    ``bls`` (a FitProblem or _Baselines): data of a pair that only exists in reversed order are conjugated (:263-278); weights
+    are ``~flags`` (``* nsamples`` / ``* UVFlag.weights``) divided by their sum over ALL baselines and channels (:282-303).
+    Returns (data_r, data_i, wgts or None)."""
+    rows, conj = _baseline_rows(uvdata, bls, ants_map, time)
+    pols = np.asarray(uvdata.polarization_array)
+    polnum = polstr2num(polarization, x_orientation=uvdata.x_orientation)
+    swap = {-7: -8, -8: -7, -3: -4, -4: -3}  # conjugating swaps the feeds of cross-hand products
+    pind = int(np.where(pols == polnum)[0][0])
+    pind_conj = np.where(pols == swap.get(polnum, polnum))[0]
+    any_conj = bool(conj.any())
+    if any_conj and len(pind_conj) == 0:
+        raise KeyError(f"polarization {polarization}: the conjugate product is not in the data")
+    if weights is not None and want_weights:
+        wrows, _ = _baseline_rows(weights, bls, ants_map, time)
+        wpol = int(np.where(np.asarray(weights.polarization_array) == polstr2num(polarization, x_orientation=weights.x_orientation))[0][0])
+    nb, nf = len(rows), uvdata.Nfreqs
+    d_r = np.empty((nb, nf), dtype=dtype)
+    d_i = np.empty((nb, nf), dtype=dtype)
+    w = np.empty((nb, nf), dtype=dtype) if want_weights else None
+    vis, flg = vis3(np.asarray(uvdata.data_array)), vis3(np.asarray(uvdata.flag_array))
+    nsm = vis3(np.asarray(uvdata.nsample_array)) if (nsamples_in_weights and want_weights) else None
+    wts = vis3(np.asarray(weights.weights_array)) if (weights is not None and want_weights) else None
+    row_sums = np.zeros(nb, dtype=np.float64)  # per baseline: the total below does not depend on how the rows are chunked
+
+    def rows_chunk(lo, hi):
+        # gather + scale + split of a run of baselines (memory-bound NumPy passes: one thread per run, utils.for_row_chunks)
+        r, cj = rows[lo:hi], conj[lo:hi]
+        # (row gathers with np.take from the polarization's plane: NumPy's fancy indexing with two index arrays around a
+        # slice is an order of magnitude slower on complex data)
+        data = np.take(vis[:, :, pind], r, axis=0)
+        if any_conj and cj.any():  # pairs held in the reversed order: the conjugate product's column, conjugated
+            pc = int(pind_conj[0])
+            data[cj] = np.take(vis[:, :, pc], r[cj], axis=0)
+        data /= data_scale_factor
+        d_r[lo:hi] = data.real
+        d_i[lo:hi] = data.imag
+        if any_conj:
+            d_i[lo:hi][cj] *= -1
+        if not want_weights:
+            return
+        keep = ~np.take(flg[:, :, pind], r, axis=0)
+        ns = np.take(nsm[:, :, pind], r, axis=0) if nsm is not None else None
+        if any_conj and cj.any():
+            pc = int(pind_conj[0])
+            keep[cj] = ~np.take(flg[:, :, pc], r[cj], axis=0)
+            if ns is not None:
+                ns[cj] = np.take(nsm[:, :, pc], r[cj], axis=0)
+        ww = keep.astype(dtype) if wts is None else np.take(wts[:, :, wpol], wrows[lo:hi], axis=0).astype(dtype) * keep
+        if ns is not None:
+            ww = ww * ns
+        w[lo:hi] = ww
+        row_sums[lo:hi] = np.sum(w[lo:hi], axis=1, dtype=np.float64)
+
+    utils.for_row_chunks(rows_chunk, nb)
+    if want_weights:
+        wgtsum = float(np.sum(row_sums))
+        w = (w / wgtsum).astype(dtype)
+    return d_r, d_i, w
 
 
 def tensorize_data(
@@ -151,83 +281,17 @@ def tensorize_data(
     Data of a pair that only exists in reversed order are conjugated (:263-278); weights are ``~flags``
     (``* nsamples`` / ``* UVFlag.weights``) divided by their sum over ALL baselines and channels (:282-303).
     """
-    ants_map_inv = {ants_map[i]: i for i in ants_map}
-    # One pass over the blt axis: (ant1, ant2) -> row of this time; then every chunk is a fancy-indexed gather instead of
-    # a python loop with a key lookup per baseline (1.3 s per call at HERA-350).
-    tsel = np.where(np.isclose(np.asarray(uvdata.time_array), time, rtol=0.0, atol=1e-7))[0]
-    row_of = {(int(a), int(b)): int(t) for a, b, t in zip(np.asarray(uvdata.ant_1_array)[tsel], np.asarray(uvdata.ant_2_array)[tsel], tsel)}
-    pols = np.asarray(uvdata.polarization_array)
-    polnum = polstr2num(polarization, x_orientation=uvdata.x_orientation)
-    swap = {-7: -8, -8: -7, -3: -4, -4: -3}  # conjugating swaps the feeds of cross-hand products
-    pind = int(np.where(pols == polnum)[0][0])
-    pind_conj = np.where(pols == swap.get(polnum, polnum))[0]
-    if weights is not None:
-        wsel = np.where(np.isclose(np.asarray(weights.time_array), time, rtol=0.0, atol=1e-7))[0]
-        wrow_of = {(int(a), int(b)): int(t) for a, b, t in zip(np.asarray(weights.ant_1_array)[wsel], np.asarray(weights.ant_2_array)[wsel], wsel)}
-        wpol = int(np.where(np.asarray(weights.polarization_array) == polstr2num(polarization, x_orientation=weights.x_orientation))[0][0])
-    data_r, data_i, wgts = [], [], []
-    wgtsum = 0.0
-    for chunk in corr_inds:
-        ngrps, nbls = len(chunk), len(chunk[0])
-        rows = np.empty(ngrps * nbls, dtype=np.int64)
-        conj = np.zeros(ngrps * nbls, dtype=bool)
-        wrows = np.empty(ngrps * nbls, dtype=np.int64)
-        n = 0
-        for fitgrp in chunk:
-            for i, j in fitgrp:
-                ap = (ants_map_inv[i], ants_map_inv[j])
-                r = row_of.get(ap)
-                if r is None:
-                    r = row_of[ap[::-1]]  # KeyError if the pair is in the data in neither order, like _key2inds
-                    conj[n] = True
-                rows[n] = r
-                if weights is not None:
-                    wr = wrow_of.get(ap)
-                    wrows[n] = wrow_of[ap[::-1]] if wr is None else wr
-                n += 1
-        any_conj = bool(conj.any())
-        if any_conj and len(pind_conj) == 0:
-            raise KeyError(f"polarization {polarization}: the conjugate product is not in the data")
-        nf = uvdata.Nfreqs
-        d_r = np.empty((ngrps * nbls, nf), dtype=dtype)
-        d_i = np.empty((ngrps * nbls, nf), dtype=dtype)
-        w = np.empty((ngrps * nbls, nf), dtype=dtype)
-        vis, flg = vis3(np.asarray(uvdata.data_array)), vis3(np.asarray(uvdata.flag_array))
-        nsm = vis3(np.asarray(uvdata.nsample_array)) if nsamples_in_weights else None
-        wts = vis3(np.asarray(weights.weights_array)) if weights is not None else None
-        row_sums = np.zeros(ngrps * nbls, dtype=np.float64)  # per baseline: the total below does not depend on how the rows are chunked
-
-        def rows_chunk(lo, hi):
-            # gather + scale + split of a run of baselines (memory-bound NumPy passes: one thread per run, utils.for_row_chunks)
-            r, cj = rows[lo:hi], conj[lo:hi]
-            # (row gathers with np.take from the polarization's plane: NumPy's fancy indexing with two index arrays around a
-            # slice is an order of magnitude slower on complex data)
-            data = np.take(vis[:, :, pind], r, axis=0)
-            keep = ~np.take(flg[:, :, pind], r, axis=0)
-            ns = np.take(nsm[:, :, pind], r, axis=0) if nsm is not None else None
-            if any_conj and cj.any():  # pairs held in the reversed order: the conjugate product's column, conjugated
-                pc = int(pind_conj[0])
-                data[cj] = np.take(vis[:, :, pc], r[cj], axis=0)
-                keep[cj] = ~np.take(flg[:, :, pc], r[cj], axis=0)
-                if ns is not None:
-                    ns[cj] = np.take(nsm[:, :, pc], r[cj], axis=0)
-            data /= data_scale_factor
-            d_r[lo:hi] = data.real
-            d_i[lo:hi] = data.imag
-            if any_conj:
-                d_i[lo:hi][cj] *= -1
-            ww = keep.astype(dtype) if wts is None else np.take(wts[:, :, wpol], wrows[lo:hi], axis=0).astype(dtype) * keep
-            if ns is not None:
-                ww = ww * ns
-            w[lo:hi] = ww
-            row_sums[lo:hi] = np.sum(w[lo:hi], axis=1, dtype=np.float64)
-
-        utils.for_row_chunks(rows_chunk, ngrps * nbls)
-        wgtsum += float(np.sum(row_sums))
-        data_r.append(d_r.reshape(ngrps, nbls, nf))
-        data_i.append(d_i.reshape(ngrps, nbls, nf))
-        wgts.append(w.reshape(ngrps, nbls, nf))
-    wgts = [(w / wgtsum).astype(dtype) for w in wgts]
+    bls = _baselines_of(corr_inds)
+    d_r, d_i, w = _tensorize_flat(uvdata, bls, ants_map, polarization, time, data_scale_factor=data_scale_factor, weights=weights,
+                                  nsamples_in_weights=nsamples_in_weights, dtype=dtype)
+    data_r, data_i, wgts, lo = [], [], [], 0
+    nf = uvdata.Nfreqs
+    for ngrps, nbls in bls.shapes:
+        hi = lo + ngrps * nbls
+        data_r.append(d_r[lo:hi].reshape(ngrps, nbls, nf))
+        data_i.append(d_i[lo:hi].reshape(ngrps, nbls, nf))
+        wgts.append(w[lo:hi].reshape(ngrps, nbls, nf))
+        lo = hi
     return data_r, data_i, wgts
 
 
@@ -573,18 +637,21 @@ def calibrate_and_model_tensor(
         uvdata = uvdata.select(inplace=False, bls=[ap for ap in antpairs_data])
     # (with nothing to drop the input object itself is used: it is only read from here on, and the reference's
     # select(inplace=False) copy of a gigabyte of visibilities bought nothing but that guarantee)
-    resid = copy.deepcopy(uvdata)
+    resid = _blank_copy(uvdata, keep_flags=True)  # its visibilities are written at the end (_finish_outputs): data - gains x model
     model = _blank_copy(uvdata)
     red_grps = []
     for fit_grp in fg_model_comps_dict.keys():
         for red_grp in fit_grp:
             red_grps.append(red_grp)
+    unity_gains = gains is None
     if gains is None:
         echo(f"{datetime.datetime.now()} Gains are None. Initializing gains starting with unity...\n", verbose=verbose)
         gains = cal_utils.blank_uvcal_from_uvdata(uvdata)
     if sky_model is None and model_regularization is not None:
         echo(f"{datetime.datetime.now()} Sky model is None. Initializing from data...\n", verbose=verbose)
-        sky_model = cal_utils.apply_gains(uvdata, gains)
+        # data / (g_i conj(g_j)) with the initial gains (:1131-1136).  With the unity, unflagged gains built just above that is
+        # the data themselves: the sky model is only read from here on, so the input object stands in for the gigabyte copy
+        sky_model = uvdata if unity_gains else cal_utils.apply_gains(uvdata, gains)
     else:
         # the reference dereferences sky_model here even when it is None (calibration.py:1137-1138)
         sky_model = sky_model.select(inplace=False, bls=[ap for ap in antpairs_data])
@@ -725,15 +792,56 @@ def calibrate_and_model_tensor(
 
 
 def _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, correct_resid):
-    """Residual and model in the requested calibration state -- calibration.py:1322-1331."""
-    model_with_gains = cal_utils.apply_gains(model, gains, inverse=True)
-    if not correct_model:
-        model = model_with_gains
-    resid.data_array -= model_with_gains.data_array
-    resid.data_array[model_with_gains.flag_array] = 0.0
-    resid.data_array[uvdata.flag_array] = 0.0
-    if correct_resid:
-        resid = cal_utils.apply_gains(resid, gains)
+    """Residual and model in the requested calibration state -- calibration.py:1322-1331:
+    ``model_with_gains = apply_gains(model, gains, inverse=True)``; ``resid = data - model_with_gains``, zero where the model
+    (with gains) or the data are flagged; ``correct_resid``: ``resid / (g_i conj(g_j))``, flags or-ed with the gain flags;
+    ``correct_model=False`` returns the model with gains.  The same arithmetic in the same order as those calls, in ONE pass over
+    the baseline-times (row chunks on the host's cores) instead of four passes and three container copies."""
+    ants = np.asarray(gains.ant_array).astype(np.int64)
+    order = np.argsort(ants)
+
+    def ant_rows(a):
+        a = np.asarray(a).astype(np.int64)
+        pos = np.clip(np.searchsorted(ants[order], a), 0, len(ants) - 1)
+        if not np.all(ants[order][pos] == a):
+            raise KeyError(int(a[np.where(ants[order][pos] != a)[0][0]]))
+        return order[pos]
+
+    a0, a1 = ant_rows(uvdata.ant_1_array), ant_rows(uvdata.ant_2_array)
+    gtimes = np.asarray(gains.time_array)
+    utimes = np.unique(uvdata.time_array)
+    tind = np.asarray([np.where(np.isclose(gtimes, t, rtol=0.0, atol=1e-7))[0][0] for t in utimes])
+    gt = tind[np.searchsorted(utimes, np.asarray(uvdata.time_array))]
+    udata, uflag = vis3(np.asarray(uvdata.data_array)), vis3(np.asarray(uvdata.flag_array))
+    mdata, mflag = vis3(model.data_array), vis3(model.flag_array)
+    rdata, rflag = vis3(resid.data_array), vis3(resid.flag_array)
+    garr, gflags = gain4(gains.gain_array), gain4(gains.flag_array)
+    for pnum, pol in enumerate(uvdata.get_pols()):
+        gindp = np.where(np.asarray(gains.jones_array) == polstr2num(pol, x_orientation=gains.x_orientation))[0][0]
+        for t in np.unique(gt):
+            gplane = np.ascontiguousarray(garr[:, :, t, gindp])
+            fplane = np.ascontiguousarray(gflags[:, :, t, gindp])
+            sel = np.where(gt == t)[0]
+            contiguous = len(sel) == sel[-1] - sel[0] + 1
+
+            def rows(lo, hi, pnum=pnum, sel=sel, gplane=gplane, fplane=fplane, contiguous=contiguous):
+                r = slice(sel[0] + lo, sel[0] + hi) if contiguous else sel[lo:hi]
+                gg = np.take(gplane, a0[r], axis=0)
+                gg *= np.conj(np.take(gplane, a1[r], axis=0))
+                gf = np.take(fplane, a0[r], axis=0) | np.take(fplane, a1[r], axis=0)
+                mwg = mdata[r, :, pnum] * gg  # apply_gains(model, gains, inverse=True)
+                mwf = mflag[r, :, pnum] | gf
+                d = udata[r, :, pnum] - mwg
+                d[mwf | uflag[r, :, pnum]] = 0.0
+                if correct_resid:  # apply_gains(resid, gains)
+                    d /= gg
+                    rflag[r, :, pnum] |= gf
+                rdata[r, :, pnum] = d
+                if not correct_model:
+                    mdata[r, :, pnum] = mwg
+                    mflag[r, :, pnum] = mwf
+
+            utils.for_row_chunks(rows, len(sel))
     return model, resid, gains, fit_history
 
 
@@ -809,20 +917,19 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
         echo(f"{datetime.datetime.now()} Working on {nt} (polarization, time) slices together...\n", verbose=verbose)
         d_r, d_i, w, s_r, s_i, g_r, g_i = [], [], [], [], [], [], []
         for sl in batch:
-            data_r, data_i, wgts = tensorize_data(
-                uvdata, corr_inds=corr_inds, ants_map=ants_map, polarization=sl["pol"], time=sl["time"], data_scale_factor=sl["rmsdata"],
-                weights=weights, nsamples_in_weights=nsamples_in_weights, dtype=dtype,
-            )
-            d_r.append(_flatten(data_r, prob))
-            d_i.append(_flatten(data_i, prob))
-            w.append(_flatten(wgts, prob))
-            if sky_model is not None:
-                sky_r, sky_i, _ = tensorize_data(
-                    sky_model, corr_inds=corr_inds, ants_map=ants_map, polarization=sl["pol"], time=sl["time"],
-                    data_scale_factor=sl["rmsdata"], weights=weights, dtype=dtype,
-                )
-                s_r.append(_flatten(sky_r, prob))
-                s_i.append(_flatten(sky_i, prob))
+            dr_t, di_t, w_t = _tensorize_flat(uvdata, prob, ants_map, sl["pol"], sl["time"], data_scale_factor=sl["rmsdata"], weights=weights,
+                                              nsamples_in_weights=nsamples_in_weights, dtype=dtype)
+            d_r.append(dr_t)
+            d_i.append(di_t)
+            w.append(w_t)
+            if sky_model is uvdata:  # (the data stand in for the sky model: the same rows)
+                s_r.append(dr_t)
+                s_i.append(di_t)
+            elif sky_model is not None:
+                sr_t, si_t, _ = _tensorize_flat(sky_model, prob, ants_map, sl["pol"], sl["time"], data_scale_factor=sl["rmsdata"], dtype=dtype,
+                                                want_weights=False)
+                s_r.append(sr_t)
+                s_i.append(si_t)
             a, b = tensorize_gains(gains, dtype=dtype, time=sl["time"], polarization=sl["pol"])
             g_r.append(a)
             g_i.append(b)
@@ -909,36 +1016,32 @@ def _gram_solve(prob, c_r, c_i, nt=1):
     return c_r, c_i
 
 
-def _blank_copy(uvdata):
-    """A copy of ``uvdata`` with all-zero visibilities and no flags (the reference deep-copies, then clears, :1113-1116),
-    without copying the arrays that are about to be overwritten -- and without touching the input, which other holders of
-    the object may be reading: the deep copy is told that the two big arrays are already copied (the memo maps them to
-    placeholders), then fresh zero arrays are attached."""
+def _blank_copy(uvdata, keep_flags=False):
+    """A copy of ``uvdata`` with all-zero visibilities and no flags (the reference deep-copies, then clears, :1113-1116;
+    ``keep_flags``: the flags are copied), without copying the arrays that are about to be overwritten -- and without touching
+    the input, which other holders of the object may be reading: the deep copy is told that the two big arrays are already
+    copied (the memo maps them to placeholders), then fresh arrays are attached."""
     data, flags = uvdata.data_array, uvdata.flag_array
     hold_d, hold_f = np.zeros(0, dtype=np.asarray(data).dtype), np.zeros(0, dtype=bool)
     out = copy.deepcopy(uvdata, {id(data): hold_d, id(flags): hold_f})
     out.data_array = np.zeros_like(data)
-    out.flag_array = np.zeros_like(flags)
+    out.flag_array = np.array(flags, copy=True) if keep_flags else np.zeros_like(flags)
     return out
 
 
 def _insert_model_rows(uvdata, time, polarization, ants_map, prob, m_r, m_i, scale_factor):
-    """insert_model_into_uvdata_tensor (calibration.py:741-795) from per-baseline rows instead of cubes: one lookup table
-    for the time slice, then a single scatter."""
-    ants_inv = {v: k for k, v in ants_map.items()}
+    """insert_model_into_uvdata_tensor (calibration.py:741-795) from per-baseline rows instead of cubes: the row table of the
+    time slice (``_baseline_rows``), then a single scatter; pairs the container holds in the reversed order get the conjugate."""
     polnum = np.where(uvdata.polarization_array == polstr2num(polarization, x_orientation=uvdata.x_orientation))[0][0]
-    tsel = np.where(np.isclose(np.asarray(uvdata.time_array), time, rtol=0.0, atol=1e-7))[0]
-    row_of = {(int(a), int(b)): int(t) for a, b, t in zip(np.asarray(uvdata.ant_1_array)[tsel], np.asarray(uvdata.ant_2_array)[tsel], tsel)}
-    rows = np.empty(prob.nbls, dtype=np.int64)
-    sign = np.ones(prob.nbls)
-    for b in range(prob.nbls):
-        ap = (ants_inv[int(prob.bl_ant0[b])], ants_inv[int(prob.bl_ant1[b])])
-        r = row_of.get(ap)
-        if r is None:  # stored in the reversed order: the model of (j, i) is the conjugate
-            r = row_of[ap[::-1]]
-            sign[b] = -1.0
-        rows[b] = r
-    vis3(uvdata.data_array)[rows, :, polnum] = (np.asarray(m_r) + 1j * sign[:, None] * np.asarray(m_i)) * scale_factor
+    rows, conj = _baseline_rows(uvdata, prob, ants_map, time)
+    out = vis3(uvdata.data_array)
+    m_r, m_i = np.asarray(m_r), np.asarray(m_i)
+    sign = np.where(conj, -1.0, 1.0)
+
+    def chunk(lo, hi):
+        out[rows[lo:hi], :, polnum] = (m_r[lo:hi] + 1j * sign[lo:hi, None] * m_i[lo:hi]) * scale_factor
+
+    utils.for_row_chunks(chunk, len(rows))
 
 
 def calibrate_and_model_dpss(

@@ -51,7 +51,8 @@ class FitProblem:
 
     @property
     def grp_nvec(self):
-        return np.asarray([self.basis[b].shape[1] for b in self.grp_basis], dtype=np.int32)
+        nvec_u = np.asarray([blk.shape[1] for blk in self.basis], dtype=np.int32)  # per distinct block, then one gather
+        return nvec_u[np.asarray(self.grp_basis)]
 
     @property
     def grp_coff(self):
@@ -69,12 +70,13 @@ class FitProblem:
             assert arr is None or arr.shape == (self.nbls, self.nfreqs)
         assert self.bl_ant0.min() >= 0 and self.bl_ant0.max() < self.nants
         assert self.bl_ant1.min() >= 0 and self.bl_ant1.max() < self.nants
-        for g in range(self.ngrps):
-            blk = self.basis[self.grp_basis[g]]
-            assert blk.shape[0] % self.nfreqs == 0
-            nrb = blk.shape[0] // self.nfreqs
-            rb = self.bl_rowblk[self.grp_bl_start[g] : self.grp_bl_start[g + 1]]
-            assert rb.min() >= 0 and rb.max() < nrb
+        # every baseline's row block exists in its group's basis (one vectorised check: 61 075 groups at HERA-350)
+        nrb_u = np.asarray([blk.shape[0] // self.nfreqs for blk in self.basis])
+        assert all(blk.shape[0] % self.nfreqs == 0 for blk in self.basis)
+        assert np.asarray(self.grp_basis).min() >= 0 and np.asarray(self.grp_basis).max() < len(self.basis)
+        grp_of_bl = np.repeat(np.arange(self.ngrps), np.diff(self.grp_bl_start))
+        rb = np.asarray(self.bl_rowblk)
+        assert rb.min() >= 0 and np.all(rb < nrb_u[np.asarray(self.grp_basis)][grp_of_bl])
 
 
 def problem_from_chunks(nants, fg_comps, corr_inds, data_r, data_i, wgts, sky_model_r=None, sky_model_i=None):

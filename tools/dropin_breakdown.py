@@ -18,7 +18,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from calamity_amd import cal_utils, calibration, modeling, solver as solver_mod, synthetic  # noqa: E402
+from calamity_amd import batched, cal_utils, calibration, modeling, solver as solver_mod, synthetic  # noqa: E402
 from calamity_amd.uvcompat import SimpleUVData  # noqa: E402
 
 STACK, TIMES, CALLS = [], {}, {}
@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--reg", default="sum", help="model_regularization: sum (the Python API default) | post_hoc | none")
     ap.add_argument("--host-only", action="store_true")
+    ap.add_argument("--ntimes", type=int, default=1)
+    ap.add_argument("--loop", action="store_true", help="the sequential time loop (batch_slices=False) instead of the batched call")
     args = ap.parse_args()
     dtype = np.float32 if args.dtype == "f32" else np.float64
     rng = np.random.default_rng(0)
@@ -63,7 +65,7 @@ def main():
     antpairs = [(i, j) for i in range(args.nants) for j in range(i + 1, args.nants)]
     freqs = np.linspace(100e6, 200e6, args.nfreqs, endpoint=False)
     t_build = time.perf_counter()
-    uvd = SimpleUVData(antpos, antpairs, freqs, [2458000.0])
+    uvd = SimpleUVData(antpos, antpairs, freqs, [2458000.0 + 0.01 * t for t in range(args.ntimes)])
     # smooth foregrounds (a few point sources) times random gains, 5 % flags: the content only matters for convergence
     a1, a2 = np.asarray(uvd.ant_1_array), np.asarray(uvd.ant_2_array)
     bvec = antpos[a2] - antpos[a1]
@@ -89,6 +91,9 @@ def main():
     timed(calibration, "coeffs_from_chunks", "coefficient re-chunking")
     timed(cal_utils, "apply_gains", "apply_gains (sky model, model with gains)")
     timed(cal_utils, "blank_uvcal_from_uvdata", "blank_uvcal_from_uvdata")
+    timed(calibration, "_blank_copy", "blank model container")
+    timed(calibration, "_finish_outputs", "residual = data - gains x model, flags (calibration.py:1322-1331)")
+    timed(batched, "replicate_slices", "batched problem description (replicate_slices)")
     H = solver_mod.HipFitSolver
     if args.host_only:
         def stop(*a, **k):
@@ -99,10 +104,14 @@ def main():
         timed(H, "set_data", "upload data / weights (set_data)")
         timed(H, "set_params", "upload parameters")
         timed(H, "run", "FIT: device train steps (cal_solver_run)")
+        timed(H, "run_slices", "FIT: device train steps (cal_solver_run)")
+        timed(H, "init_coeffs", "initial coefficients (device A^T d + download)")
         timed(H, "model", "model evaluation A c (device) + download")
         timed(H, "get_params", "download parameters")
     kw = dict(maxsteps=args.maxsteps, tol=0.0, optimizer="Adam", learning_rate=1e-2, dtype=dtype,
               model_regularization=None if args.reg == "none" else args.reg)
+    if args.loop:
+        kw["batch_slices"] = False
     if args.reg == "none":
         kw["sky_model"] = uvd  # the reference needs a sky model when there is no regularisation to build one for
     t0 = time.perf_counter()
@@ -117,7 +126,7 @@ def main():
         quality = None
     total = time.perf_counter() - t0
     accounted = sum(TIMES.values())
-    out = dict(workload=f"calibrate_and_model_dpss: {args.nants} antennas, {len(antpairs)} baselines x {args.nfreqs} channels x 1 time, "
+    out = dict(workload=f"calibrate_and_model_dpss ({'time loop' if args.loop else 'batched slices'}): {args.nants} antennas, {len(antpairs)} baselines x {args.nfreqs} channels x {args.ntimes} time(s), "
                         f"{np.dtype(dtype).name}, Adam lr 1e-2, model_regularization={args.reg}, maxsteps={args.maxsteps}",
                total_s=total, recorded_steps=nsteps, host_only=args.host_only,
                split_s={k: round(v, 4) for k, v in sorted(TIMES.items(), key=lambda kv: -kv[1])},
