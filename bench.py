@@ -325,7 +325,8 @@ def main():
         solvers.append(s)
     else:
         # N time slices; this rank owns the same 1/N of the baselines of every slice -> one all-reduce per step
-        prob, start, full_nants = build_sharded_job(args.config, rank, world, ntimes, reg=args.reg == "sum", max_bls=args.max_bls)
+        # (one loop state per time slice, as calibrate_and_model_tensor fits them: every slice records its own loss)
+        prob, start, full_nants = build_sharded_job(args.config, rank, world, ntimes, reg=args.reg == "sum", max_bls=args.max_bls, per_slice=True)
         truth = None
         tot = torch_sum_int(dist, [prob.nbls // ntimes, prob.ncoeffs // ntimes])
         full_nbls, full_ncoeffs = tot
@@ -343,10 +344,14 @@ def main():
         raise SystemExit(f"the exchange spans {n_ranks_seen} ranks, the launcher started {world}")
     for s in solvers:
         if args.reg == "sum":
-            pri = np.asarray([float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts))])
-            if dist is not None:
+            if sharded:  # one pair of priors per time slice, summed over the ranks' shares
+                nb = prob.nbls // ntimes
+                pri = np.concatenate([[float(np.sum((prob.sky_r * prob.wgts)[t * nb : (t + 1) * nb])) for t in range(ntimes)],
+                                      [float(np.sum((prob.sky_i * prob.wgts)[t * nb : (t + 1) * nb])) for t in range(ntimes)]])
                 pri = torch_sum_float(dist, pri)
-            s.set_regularization("sum", float(pri[0]), float(pri[1]))
+                s.set_regularization("sum", pri[:ntimes], pri[ntimes:])
+            else:
+                s.set_regularization("sum", float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts)))
         s.set_optimizer(args.optimizer, learning_rate=1e-2)
     t_setup = time.perf_counter() - t_setup
 
@@ -357,6 +362,9 @@ def main():
             dist.barrier()
 
     def run_steps(n, record):
+        if sharded:  # the recorded loss of the job: the sum of its slices' losses
+            res = [s.run_slices(n, record=record, tol=0.0) for s in solvers][0]
+            return np.sum([r[0] for r in res], axis=0) if record else []
         return [s.run(n, record=record, tol=0.0)[0] for s in solvers][0]
 
     run_steps(args.warmup, False) if args.warmup > 0 else None

@@ -305,20 +305,38 @@ def tensorize_gains(uvcal, polarization, time, dtype=np.float32):
 
 def renormalize(uvdata_reference_model, uvdata_deconv, gains, polarization, time, additional_flags=None):
     """Remove the arbitrary amplitude of the deconvolved model and gains -- calibration.py:313-366 (the phase factor is
-    computed by the reference but deliberately not applied, :359).  Modifies ``uvdata_deconv`` and ``gains``."""
+    computed by the reference but deliberately not applied, :359).  Modifies ``uvdata_deconv`` and ``gains``.
+    ``scale = sqrt(nanmean |reference / deconvolved|^2)`` over the samples no flag array marks, non-finite ratios left out
+    (:355-358) -- accumulated baseline by baseline on the host's cores instead of through three boolean-indexed copies of the slice."""
     polnum_data = np.where(uvdata_deconv.polarization_array == polstr2num(polarization, x_orientation=uvdata_deconv.x_orientation))[0][0]
-    bltsel = np.isclose(uvdata_deconv.time_array, time, atol=1e-7, rtol=0.0)
-    selection = ~uvdata_deconv.flag_array[bltsel, ..., polnum_data] & ~uvdata_reference_model.flag_array[bltsel, ..., polnum_data]
-    if additional_flags is not None:
-        selection = selection & ~additional_flags[bltsel, ..., polnum_data]
+    rows = np.where(np.isclose(uvdata_deconv.time_array, time, atol=1e-7, rtol=0.0))[0]
+    dec, dflag = vis3(uvdata_deconv.data_array), vis3(uvdata_deconv.flag_array)
+    ref, rflag = vis3(np.asarray(uvdata_reference_model.data_array)), vis3(np.asarray(uvdata_reference_model.flag_array))
+    aflag = vis3(np.asarray(additional_flags)) if additional_flags is not None else None
+    ssq = np.zeros(len(rows), dtype=np.float64)
+    cnt = np.zeros(len(rows), dtype=np.int64)
+
+    def chunk(lo, hi):
+        r = rows[lo:hi]
+        sel = ~(np.take(dflag[:, :, polnum_data], r, axis=0) | np.take(rflag[:, :, polnum_data], r, axis=0))
+        if aflag is not None:
+            sel &= ~np.take(aflag[:, :, polnum_data], r, axis=0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = np.take(ref[:, :, polnum_data], r, axis=0) / np.take(dec[:, :, polnum_data], r, axis=0)
+            p = ratio.real * ratio.real + ratio.imag * ratio.imag
+        sel &= np.isfinite(ratio.real) & np.isfinite(ratio.imag)  # data_ratio[~isfinite] = nan, then nanmean (:355-358)
+        ssq[lo:hi] = np.sum(np.where(sel, p, 0.0), axis=1)
+        cnt[lo:hi] = np.count_nonzero(sel, axis=1)
+
+    utils.for_row_chunks(chunk, len(rows))
+    n = int(cnt.sum())
     with np.errstate(divide="ignore", invalid="ignore"):
-        data_ratio = (
-            uvdata_reference_model.data_array[bltsel, ..., polnum_data][selection]
-            / uvdata_deconv.data_array[bltsel, ..., polnum_data][selection]
-        )
-    data_ratio[~np.isfinite(data_ratio)] = np.nan
-    scale_factor = np.sqrt(np.nanmean(np.abs(data_ratio) ** 2.0))
-    uvdata_deconv.data_array[bltsel, ..., polnum_data] *= scale_factor
+        scale_factor = np.sqrt(np.float64(ssq.sum()) / n) if n else np.float64("nan")
+
+    def scale(lo, hi):
+        dec[rows[lo:hi], :, polnum_data] *= scale_factor
+
+    utils.for_row_chunks(scale, len(rows))
     polnum_gains = np.where(np.asarray(gains.jones_array) == polstr2num(polarization, x_orientation=uvdata_deconv.x_orientation))[0][0]
     gindt = np.where(np.isclose(gains.time_array, time, atol=1e-7, rtol=0.0))[0][0]
     gains.gain_array[..., gindt, polnum_gains] *= (scale_factor) ** -0.5
@@ -501,8 +519,7 @@ def fit_gains_and_foregrounds(
         echo(f"Performing gradient descent on total of {prob.ncoeffs} complex foreground parameters", verbose=verbose)
     if model_regularization == "sum":
         # priors of calibration.py:619-625 (accumulated in float64 on the host)
-        w64 = w_flat.astype(np.float64)
-        solver.set_regularization("sum", float(np.sum(_flatten(sky_model_r, prob) * w64)), float(np.sum(_flatten(sky_model_i, prob) * w64)))
+        solver.set_regularization("sum", *_prior_sums(_flatten(sky_model_r, prob), _flatten(sky_model_i, prob), w_flat))
     else:
         solver.set_regularization(None)
     solver.set_optimizer(optimizer, **opt_kwargs)
@@ -702,9 +719,8 @@ def calibrate_and_model_tensor(
         g_r, g_i, fg_r, fg_i = carry.get("g_r"), carry.get("g_i"), carry.get("fg_r"), carry.get("fg_i")
         echo(f"{datetime.datetime.now()} Working on time {time_index + 1} of {uvdata.Ntimes}...\n", verbose=verbose)
         bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
-        frac_unflagged = np.count_nonzero(~vis3(uvdata.flag_array)[bltsel, :, polnum]) / (uvdata.Nbls * uvdata.Nfreqs)
+        frac_unflagged, rmsdata = _slice_stats(uvdata, bltsel, polnum)
         if frac_unflagged >= skip_threshold:
-            rmsdata = np.sqrt(np.mean(np.abs(vis3(uvdata.data_array)[bltsel, :, polnum][~vis3(uvdata.flag_array)[bltsel, :, polnum]]) ** 2.0))
             echo(f"{datetime.datetime.now()} Tensorizing data...\n", verbose=verbose)
             data_r, data_i, wgts = tensorize_data(
                 uvdata, corr_inds=corr_inds, ants_map=ants_map, polarization=pol, time=time, data_scale_factor=rmsdata,
@@ -845,6 +861,42 @@ def _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, cor
     return model, resid, gains, fit_history
 
 
+def _slice_stats(uvdata, bltsel, polnum):
+    """(fraction of unflagged samples, rms of the unflagged visibilities) of one (polarization, time) -- calibration.py:1168-1182
+    -- in one threaded pass over the slice's rows (the reference's boolean fancy indexing copies the slice twice)."""
+    rows = np.where(bltsel)[0]
+    vis, flg = vis3(np.asarray(uvdata.data_array)), vis3(np.asarray(uvdata.flag_array))
+    cnt = np.zeros(len(rows), dtype=np.int64)
+    ssq = np.zeros(len(rows), dtype=np.float64)
+
+    def chunk(lo, hi):
+        keep = ~np.take(flg[:, :, polnum], rows[lo:hi], axis=0)
+        d = np.take(vis[:, :, polnum], rows[lo:hi], axis=0)
+        p = d.real * d.real + d.imag * d.imag
+        cnt[lo:hi] = np.count_nonzero(keep, axis=1)
+        ssq[lo:hi] = np.sum(p * keep, axis=1)
+
+    utils.for_row_chunks(chunk, len(rows))
+    n = int(cnt.sum())
+    frac = n / (uvdata.Nbls * uvdata.Nfreqs)
+    return frac, (float(np.sqrt(ssq.sum() / n)) if n else float("nan"))
+
+
+def _prior_sums(sky_r, sky_i, wgts):
+    """``P_r, P_i = sum w * sky`` (calibration.py:619-625), accumulated in float64 baseline by baseline on the host's cores; the
+    total does not depend on how the rows are chunked."""
+    nb = len(wgts)
+    pr, pi = np.zeros(nb, dtype=np.float64), np.zeros(nb, dtype=np.float64)
+
+    def chunk(lo, hi):
+        w64 = wgts[lo:hi].astype(np.float64)
+        pr[lo:hi] = np.sum(sky_r[lo:hi] * w64, axis=1)
+        pi[lo:hi] = np.sum(sky_i[lo:hi] * w64, axis=1)
+
+    utils.for_row_chunks(chunk, nb)
+    return float(pr.sum()), float(pi.sum())
+
+
 def _lib_max_slices():
     from . import _lib
 
@@ -899,15 +951,13 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
     for polnum, pol in enumerate(pols):
         for time_index, time in enumerate(times):
             bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
-            unflagged = ~vis3(uvdata.flag_array)[bltsel, :, polnum]
-            frac_unflagged = np.count_nonzero(unflagged) / (uvdata.Nbls * uvdata.Nfreqs)
+            frac_unflagged, rmsdata = _slice_stats(uvdata, bltsel, polnum)
             if frac_unflagged < skip_threshold:
                 echo(f"{datetime.datetime.now()}: Only {frac_unflagged * 100}-percent of data unflagged. Skipping...\n", verbose=verbose)
                 flag_poltime(resid, time=time, polarization=pol)
                 flag_poltime(gains, time=time, polarization=pol)
                 flag_poltime(model, time=time, polarization=pol)
                 continue
-            rmsdata = np.sqrt(np.mean(np.abs(vis3(uvdata.data_array)[bltsel, :, polnum][unflagged]) ** 2.0))
             todo.append(dict(polnum=polnum, pol=pol, time_index=time_index, time=time, rmsdata=rmsdata, bltsel=bltsel))
     if devices is None:
         devices = _default_devices(float(min(len(todo), max_batch)) * prob.nbls * prob.nfreqs)
@@ -934,13 +984,12 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
             g_r.append(a)
             g_i.append(b)
         fitter = _batch_fitter(prob, nt, dtype, layout, devices)
-        cat = np.concatenate
-        w_all = cat(w)
-        zeros = np.zeros_like(w_all)
-        # tensorize_fg_coeffs x 2 (calibration.py:1219-1233) for every slice: one device pass gives both components
-        fitter.set_data(zeros, zeros, w_all)
-        del zeros
-        fitter.init_coeffs(cat(s_r), cat(s_i))
+        cat = lambda parts_: parts_[0] if len(parts_) == 1 else np.concatenate(parts_)  # noqa: E731
+        w_all, d_r, d_i, s_r, s_i = cat(w), cat(d_r), cat(d_i), cat(s_r), cat(s_i)
+        # tensorize_fg_coeffs x 2 (calibration.py:1219-1233) for every slice: one device pass gives both components (the weights
+        # it masks with are those of set_data; the sky model arrives as the pass's own source rows)
+        fitter.set_data(d_r, d_i, w_all)
+        fitter.init_coeffs(s_r, s_i)
         _, _, c_r, c_i = fitter.get_params()
         if _gram_factors(prob):
             c_r, c_i = _gram_solve(prob, c_r, c_i, nt)
@@ -952,12 +1001,13 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
                 rows = slice(t * prob.nbls, (t + 1) * prob.nbls)
                 w_new[rows] /= np.sum(w_new[rows])
             w_all = w_new.astype(dtype)
-        fitter.set_data(cat(d_r), cat(d_i), w_all)
+            fitter.set_data(d_r, d_i, w_all)
         fitter.set_params(cat(g_r), cat(g_i), c_r, c_i)
         if model_regularization == "sum":
             # priors of calibration.py:619-625, one pair per slice (accumulated in float64 on the host)
-            w64 = w_all.astype(np.float64).reshape(nt, -1)
-            fitter.set_regularization("sum", np.sum(cat(s_r).reshape(nt, -1) * w64, axis=1), np.sum(cat(s_i).reshape(nt, -1) * w64, axis=1))
+            nb = prob.nbls
+            pri = np.asarray([_prior_sums(s_r[t * nb : (t + 1) * nb], s_i[t * nb : (t + 1) * nb], w_all[t * nb : (t + 1) * nb]) for t in range(nt)])
+            fitter.set_regularization("sum", pri[:, 0], pri[:, 1])
         else:
             fitter.set_regularization(None)
         fitter.set_optimizer(optimizer, **opt_kwargs)

@@ -177,6 +177,14 @@ template <typename T>
 struct SolverT final : cal_solver {
   using T2 = vec2_t<T>;
   hipStream_t stream = nullptr;
+  // Synchronous copies go through the solver's OWN (non-blocking) stream, never the legacy stream: a copy there synchronises with
+  // every other stream, and HIP refuses it ("operation would make the legacy stream depend on a capturing ... stream") while ANOTHER
+  // thread's solver captures its step graph -- parallel_fits, the workers of a SliceBatchFitter.
+  hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(stream);
+  }
   bool has_problem = false, has_data = false, has_gains = false, has_coef = false, has_opt = false;
   // problem
   int nants = 0, nfreqs = 0, fpad = 0, ngrps = 0, nbls = 0, ncoef = 0, nitems = 0, layout = 0;
@@ -207,6 +215,7 @@ struct SolverT final : cal_solver {
   DevBuf members, heads;                       // baselines that share tiles (bl_alias): member lists of the head items, head item indices
   int nheads = 0;                              // heads[0 .. nheads_mfma): fused_multi_mfma_kernel (float32, at most kMmMaxVec vectors); the rest: fused_multi_kernel
   int nheads_mfma = 0;
+  int mm_grid = 0;                             // workgroups of the matrix-core multi-slice launch: its head list is dealt over the 8 XCDs (-1: empty slot)
   size_t lds_multi_bytes = 0, lds_multi_mfma_bytes = 0;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
@@ -487,7 +496,7 @@ struct SolverT final : cal_solver {
     for (int g = ngrps - 1; g >= 0; --g) h_slice_coff[grp_slice[g]] = h_grp_coff[g];  // first group of every slice
     h_slice_coff[0] = 0;
     CAL_TRY(slice_coff.alloc((nslices + 1) * sizeof(int), false));
-    HIP_TRY(hipMemcpy(slice_coff.p, h_slice_coff.data(), (nslices + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(slice_coff.p, h_slice_coff.data(), (nslices + 1) * sizeof(int), hipMemcpyHostToDevice));
     // ---- baselines that read another baseline's tiles (STREAM layout): the same physical baseline in several time slices
     std::vector<int> alias_root(nbls, -1);  // -1: owns its tiles
     if (d->bl_alias && layout == CAL_LAYOUT_STREAM) {
@@ -680,11 +689,11 @@ struct SolverT final : cal_solver {
     }
     raw.release();
     CAL_TRY(bl_tile.alloc(nbls * sizeof(long long), false));
-    HIP_TRY(hipMemcpy(bl_tile.p, h_bl_tile.data(), nbls * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(bl_tile.p, h_bl_tile.data(), nbls * sizeof(long long), hipMemcpyHostToDevice));
     std::vector<int2> h_ant(nbls);
     for (int b = 0; b < nbls; ++b) h_ant[b] = make_int2(d->bl_ant0[b], d->bl_ant1[b]);
     CAL_TRY(bl_ant.alloc(nbls * sizeof(int2), false));
-    HIP_TRY(hipMemcpy(bl_ant.p, h_ant.data(), nbls * sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(bl_ant.p, h_ant.data(), nbls * sizeof(int2), hipMemcpyHostToDevice));
 
     // ---- runs of the multi-baseline groups: consecutive baselines with the same row block, cut to kRunMax
     std::vector<int2> h_runs;
@@ -708,7 +717,7 @@ struct SolverT final : cal_solver {
     }
     h_grp_run0[ngrps] = (int)h_runs.size();
     CAL_TRY(runs.alloc(std::max<size_t>(1, h_runs.size()) * sizeof(int2), false));
-    if (!h_runs.empty()) HIP_TRY(hipMemcpy(runs.p, h_runs.data(), h_runs.size() * sizeof(int2), hipMemcpyHostToDevice));
+    if (!h_runs.empty()) HIP_TRY(copy_sync(runs.p, h_runs.data(), h_runs.size() * sizeof(int2), hipMemcpyHostToDevice));
 
     // ---- work items: whole groups when that already fills the chip, otherwise split along tiles
     long long total_tiles = 0;
@@ -846,9 +855,9 @@ struct SolverT final : cal_solver {
       std::vector<int> fill(ptr.begin(), ptr.end() - 1);
       for (int q = 0; q < nitems; ++q) idx[fill[sorted[q].slice]++] = q;
       CAL_TRY(slice_ipart_ptr.alloc(ptr.size() * sizeof(int), false));
-      HIP_TRY(hipMemcpy(slice_ipart_ptr.p, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(copy_sync(slice_ipart_ptr.p, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
       CAL_TRY(slice_ipart_idx.alloc(idx.size() * sizeof(int), false));
-      HIP_TRY(hipMemcpy(slice_ipart_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(copy_sync(slice_ipart_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     // coefficient blocks of step_tail_kernel: every slice gets its own (a block works for ONE slice's decisions)
     h_slice_cblk.assign(nslices + 1, 0);
@@ -858,7 +867,7 @@ struct SolverT final : cal_solver {
     }
     if (nslices > 1) {
       CAL_TRY(slice_cblk.alloc((nslices + 1) * sizeof(int), false));
-      HIP_TRY(hipMemcpy(slice_cblk.p, h_slice_cblk.data(), (nslices + 1) * sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(copy_sync(slice_cblk.p, h_slice_cblk.data(), (nslices + 1) * sizeof(int), hipMemcpyHostToDevice));
     }
     // ---- sets of baselines that share tiles -> head items with member lists (at most MultiCfg<T>::nb_max baselines each)
     nheads = 0;
@@ -915,37 +924,76 @@ struct SolverT final : cal_solver {
         }
       }
       nheads = (int)h_heads.size();
+      // XCD-affine, antenna-grouped dispatch of the matrix-core heads: a head reads 2 gain rows per member (8 slices x 2 x 8 KB of a
+      // 1024-channel band) -- a fifth of its bytes, 1.0 GB per pass of an 8-GPU rank's share against 23 MB of distinct gains, because
+      // with the heads in cost order nothing a workgroup brings into its XCD's L2 is wanted by its neighbours (hit rate 17 %).
+      // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one): every first antenna -- all heads whose baseline
+      // starts at it -- goes to ONE of 8 lists of equal cost (longest-processing-time-first), heaviest antenna groups first in a
+      // list, heaviest head first in a group, and workgroup b takes entry b / 8 of list b % 8.  The ant0 rows of a group then stay
+      // in that XCD's L2 for the whole group.  (-1 where a list is shorter.)
+      mm_grid = nheads_mfma;
+      if (nheads_mfma >= 64) {
+        auto cost = [&](int h) { return (double)sorted[h].nvec * (sorted[h].role_n >> 2) + 64.0; };
+        std::map<int, std::vector<int>> by_ant;
+        for (int i = 0; i < nheads_mfma; ++i) by_ant[sorted[h_heads[i]].ant_first.x].push_back(h_heads[i]);  // (already heaviest first)
+        std::vector<std::pair<double, int>> groups;
+        for (auto& kv : by_ant) {
+          double c = 0;
+          for (int h : kv.second) c += cost(h);
+          groups.push_back({c, kv.first});
+        }
+        std::stable_sort(groups.begin(), groups.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+        double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<std::vector<int>> lists(8);
+        for (auto& g : groups) {
+          const int x = (int)(std::min_element(load, load + 8) - load);
+          load[x] += g.first;
+          for (int h : by_ant[g.second]) lists[x].push_back(h);
+        }
+        size_t longest = 0;
+        for (auto& l : lists) longest = std::max(longest, l.size());
+        std::vector<int> dealt(8 * longest, -1);
+        for (int x = 0; x < 8; ++x)
+          for (size_t j = 0; j < lists[x].size(); ++j) dealt[j * 8 + x] = lists[x][j];
+        dealt.insert(dealt.end(), h_heads.begin() + nheads_mfma, h_heads.end());
+        mm_grid = (int)(8 * longest);
+        h_heads.swap(dealt);
+      }
       members.release();
       heads.release();
       if (nheads > 0) {
         CAL_TRY(members.alloc(h_members.size() * sizeof(Member), false));
-        HIP_TRY(hipMemcpy(members.p, h_members.data(), h_members.size() * sizeof(Member), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(members.p, h_members.data(), h_members.size() * sizeof(Member), hipMemcpyHostToDevice));
         CAL_TRY(heads.alloc(h_heads.size() * sizeof(int), false));
-        HIP_TRY(hipMemcpy(heads.p, h_heads.data(), h_heads.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(heads.p, h_heads.data(), h_heads.size() * sizeof(int), hipMemcpyHostToDevice));
         if (nheads > nheads_mfma) {
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_LOSS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_GRAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_LOSS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_GRAD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_LOSS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
         }
         if (nheads_mfma > 0) {
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_LOSS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_GRAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_LOSS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_GRAD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_LOSS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
         }
       }
     }
     CAL_TRY(items.alloc(nitems * sizeof(Item), false));
-    HIP_TRY(hipMemcpy(items.p, sorted.data(), nitems * sizeof(Item), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(items.p, sorted.data(), nitems * sizeof(Item), hipMemcpyHostToDevice));
     if (!gc_direct) {
       std::vector<int> h_coef_grp(ncoef);
       for (int g = 0; g < ngrps; ++g)
         for (int n = h_grp_coff[g]; n < h_grp_coff[g + 1]; ++n) h_coef_grp[n] = g;
       CAL_TRY(coef_grp.alloc(ncoef * sizeof(int), false));
-      HIP_TRY(hipMemcpy(coef_grp.p, h_coef_grp.data(), ncoef * sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(copy_sync(coef_grp.p, h_coef_grp.data(), ncoef * sizeof(int), hipMemcpyHostToDevice));
       CAL_TRY(grp_coff.alloc((ngrps + 1) * sizeof(int), false));
-      HIP_TRY(hipMemcpy(grp_coff.p, h_grp_coff.data(), (ngrps + 1) * sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(copy_sync(grp_coff.p, h_grp_coff.data(), (ngrps + 1) * sizeof(int), hipMemcpyHostToDevice));
       CAL_TRY(grp_item_ptr.alloc((ngrps + 1) * sizeof(int), false));
-      HIP_TRY(hipMemcpy(grp_item_ptr.p, h_grp_item_ptr.data(), (ngrps + 1) * sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(copy_sync(grp_item_ptr.p, h_grp_item_ptr.data(), (ngrps + 1) * sizeof(int), hipMemcpyHostToDevice));
       CAL_TRY(item_goff.alloc(nitems * sizeof(int), false));
-      HIP_TRY(hipMemcpy(item_goff.p, h_item_goff.data(), nitems * sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(copy_sync(item_goff.p, h_item_goff.data(), nitems * sizeof(int), hipMemcpyHostToDevice));
       CAL_TRY(gc0.alloc(2 * (size_t)ncoef * sizeof(T)));
     }
 
@@ -963,9 +1011,9 @@ struct SolverT final : cal_solver {
       h_ent[fill[d->bl_ant1[b]]++] = make_int2(b * 2 + 1, d->bl_ant0[b]);
     }
     CAL_TRY(ant_ptr.alloc((nants + 1) * sizeof(int), false));
-    HIP_TRY(hipMemcpy(ant_ptr.p, h_ant_ptr.data(), (nants + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(ant_ptr.p, h_ant_ptr.data(), (nants + 1) * sizeof(int), hipMemcpyHostToDevice));
     CAL_TRY(ant_ent.alloc(h_ent.size() * sizeof(int2), false));
-    HIP_TRY(hipMemcpy(ant_ent.p, h_ent.data(), h_ent.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(ant_ent.p, h_ent.data(), h_ent.size() * sizeof(int2), hipMemcpyHostToDevice));
 
     // ---- state arrays
     const size_t rowbytes = (size_t)(nbls + 1) * fpad * sizeof(T);  // + one all-zero spare row (padding slots of the dense path)
@@ -1199,8 +1247,8 @@ struct SolverT final : cal_solver {
     if (!has_problem) return fail(CAL_ERR_STATE, "set_params before set_problem");
     if (g_r) CAL_TRY(upload_rows(g_r, gains.as<T>(), nants, 2, 0));
     if (g_i) CAL_TRY(upload_rows(g_i, gains.as<T>(), nants, 2, 1));
-    if (c_r) HIP_TRY(hipMemcpy(coef.as<T>(), c_r, (size_t)ncoef * sizeof(T), hipMemcpyHostToDevice));
-    if (c_i) HIP_TRY(hipMemcpy(coef.as<T>() + ncoef, c_i, (size_t)ncoef * sizeof(T), hipMemcpyHostToDevice));
+    if (c_r) HIP_TRY(copy_sync(coef.as<T>(), c_r, (size_t)ncoef * sizeof(T), hipMemcpyHostToDevice));
+    if (c_i) HIP_TRY(copy_sync(coef.as<T>() + ncoef, c_i, (size_t)ncoef * sizeof(T), hipMemcpyHostToDevice));
     if (g_r && g_i) has_gains = true;
     if (c_r && c_i) has_coef = true;
     return CAL_OK;
@@ -1221,8 +1269,8 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipStreamSynchronize(stream));
     if (g_r) CAL_TRY(download_rows(g_r, g, nants, 2, 0));
     if (g_i) CAL_TRY(download_rows(g_i, g, nants, 2, 1));
-    if (c_r) HIP_TRY(hipMemcpy(c_r, c, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
-    if (c_i) HIP_TRY(hipMemcpy(c_i, c + ncoef, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
+    if (c_r) HIP_TRY(copy_sync(c_r, c, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
+    if (c_i) HIP_TRY(copy_sync(c_i, c + ncoef, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
     return CAL_OK;
   }
 
@@ -1236,10 +1284,10 @@ struct SolverT final : cal_solver {
     if (gv_r) CAL_TRY(download_rows(gv_r, gains_v.as<T>(), nants, 2, 0));
     if (gv_i) CAL_TRY(download_rows(gv_i, gains_v.as<T>(), nants, 2, 1));
     const size_t cb = (size_t)ncoef * sizeof(T);
-    if (cm_r) HIP_TRY(hipMemcpy(cm_r, coef_m.as<T>(), cb, hipMemcpyDeviceToHost));
-    if (cm_i) HIP_TRY(hipMemcpy(cm_i, coef_m.as<T>() + ncoef, cb, hipMemcpyDeviceToHost));
-    if (cv_r) HIP_TRY(hipMemcpy(cv_r, coef_v.as<T>(), cb, hipMemcpyDeviceToHost));
-    if (cv_i) HIP_TRY(hipMemcpy(cv_i, coef_v.as<T>() + ncoef, cb, hipMemcpyDeviceToHost));
+    if (cm_r) HIP_TRY(copy_sync(cm_r, coef_m.as<T>(), cb, hipMemcpyDeviceToHost));
+    if (cm_i) HIP_TRY(copy_sync(cm_i, coef_m.as<T>() + ncoef, cb, hipMemcpyDeviceToHost));
+    if (cv_r) HIP_TRY(copy_sync(cv_r, coef_v.as<T>(), cb, hipMemcpyDeviceToHost));
+    if (cv_i) HIP_TRY(copy_sync(cv_i, coef_v.as<T>() + ncoef, cb, hipMemcpyDeviceToHost));
     if (t) *t = h_state->t;
     return CAL_OK;
   }
@@ -1254,10 +1302,10 @@ struct SolverT final : cal_solver {
     if (gv_r) CAL_TRY(upload_rows(gv_r, gains_v.as<T>(), nants, 2, 0));
     if (gv_i) CAL_TRY(upload_rows(gv_i, gains_v.as<T>(), nants, 2, 1));
     const size_t cb = (size_t)ncoef * sizeof(T);
-    if (cm_r) HIP_TRY(hipMemcpy(coef_m.as<T>(), cm_r, cb, hipMemcpyHostToDevice));
-    if (cm_i) HIP_TRY(hipMemcpy(coef_m.as<T>() + ncoef, cm_i, cb, hipMemcpyHostToDevice));
-    if (cv_r) HIP_TRY(hipMemcpy(coef_v.as<T>(), cv_r, cb, hipMemcpyHostToDevice));
-    if (cv_i) HIP_TRY(hipMemcpy(coef_v.as<T>() + ncoef, cv_i, cb, hipMemcpyHostToDevice));
+    if (cm_r) HIP_TRY(copy_sync(coef_m.as<T>(), cm_r, cb, hipMemcpyHostToDevice));
+    if (cm_i) HIP_TRY(copy_sync(coef_m.as<T>() + ncoef, cm_i, cb, hipMemcpyHostToDevice));
+    if (cv_r) HIP_TRY(copy_sync(coef_v.as<T>(), cv_r, cb, hipMemcpyHostToDevice));
+    if (cv_i) HIP_TRY(copy_sync(coef_v.as<T>() + ncoef, cv_i, cb, hipMemcpyHostToDevice));
     // beta^t as the device keeps it: a running product, one factor per update (pow() differs from it in the last bits, and a
     // resumed fit must continue bit for bit).  Uses the betas of the optimizer set so far: set_optimizer comes first.
     double b1t = 1.0, b2t = 1.0, sched = 1.0;
@@ -1321,7 +1369,7 @@ struct SolverT final : cal_solver {
   template <int MODE> void launch_fused(const FusedArgs<T>& a0, bool with_reg) {
     FusedArgs<T> a = a0;
     // the passes with a multi-slice form leave the covered items to it (fused_basis_kernel would return at once for each of them)
-    const int nsimple = ((MODE == MODE_LOSS || MODE == MODE_GRAD) && !with_reg && nheads > 0) ? nitems_plain : nitems_simple;
+    const int nsimple = ((MODE == MODE_LOSS || MODE == MODE_GRAD) && nheads > 0) ? nitems_plain : nitems_simple;
     if (nsimple > 0) {
       a.item_base = 0;
       constexpr bool kHasSmall = MODE == MODE_LOSS || MODE == MODE_GRAD;
@@ -1338,15 +1386,20 @@ struct SolverT final : cal_solver {
         hipLaunchKernelGGL((fused_basis_kernel<T, MODE, false>), dim3(nsimple), dim3(kThreads), lds_bytes + (MODE == MODE_GRAD ? kQLdsMax1 : 0), stream, a);
     }
     if constexpr (MODE == MODE_LOSS || MODE == MODE_GRAD) {
-      // baselines that share tiles (skipped by the launch above): one workgroup per set
-      if (nheads > 0 && !with_reg) {
+      // baselines that share tiles (skipped by the launch above): one workgroup per set.  With the regulariser these kernels take
+      // the two-pass form (loss pass: S; gradient pass: alpha of each member's slice from the state) -- enqueue_pass orders the passes
+      if (nheads > 0) {
         if constexpr (std::is_same<T, float>::value) {
-          if (nheads_mfma > 0) hipLaunchKernelGGL((fused_multi_mfma_kernel<MODE>), dim3(nheads_mfma), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
+          if (nheads_mfma > 0) {
+            if (with_reg) hipLaunchKernelGGL((fused_multi_mfma_kernel<MODE, true>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
+            else hipLaunchKernelGGL((fused_multi_mfma_kernel<MODE, false>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
+          }
         }
         if (nheads > nheads_mfma) {
           FusedArgs<T> b = a;
-          b.heads = a.heads + nheads_mfma;
-          hipLaunchKernelGGL((fused_multi_kernel<T, MODE>), dim3(nheads - nheads_mfma), dim3(kThreads), lds_multi_bytes, stream, b);
+          b.heads = a.heads + mm_grid;
+          if (with_reg) hipLaunchKernelGGL((fused_multi_kernel<T, MODE, true>), dim3(nheads - nheads_mfma), dim3(kThreads), lds_multi_bytes, stream, b);
+          else hipLaunchKernelGGL((fused_multi_kernel<T, MODE, false>), dim3(nheads - nheads_mfma), dim3(kThreads), lds_multi_bytes, stream, b);
         }
       }
     }
@@ -1426,6 +1479,16 @@ struct SolverT final : cal_solver {
         if (grads) launch_dense<true>(m); else launch_dense<false>(m);
       }
     } else {
+      if (grads && R && nheads > 0) {
+        // baselines that share tiles + the "sum" regulariser: their multi-slice kernels need alpha = 2 (S - P) of every slice BEFORE
+        // the gradient pass (no second adjoint set there): a loss pass over everything, the slices' sums, alpha -- then the gradients
+        launch_fused<MODE_LOSS>(a, true);
+        hipLaunchKernelGGL((gain_grad_kernel<T, false>), dim3(nslices), dim3(256), 0, stream, q0.as<T2>(), q1.as<T2>(), gains.as<T2>(),
+                           ant_ptr.as<int>(), ant_ent.as<int2>(), comm.as<T2>(), comm.as<T2>(), comm.as<T2>(), 0, fpad, part.as<double>(),
+                           nitems, scal.as<double>(), st, smap(false));
+        if (comm_on()) CAL_TRY(all_reduce(scal.p, 4 * (size_t)nslices, CAL_XCHG_F64, CAL_XCHG_SUM));
+        hipLaunchKernelGGL(alpha_kernel, dim3((nslices + 63) / 64), dim3(64), 0, stream, st, scal.as<double>(), nslices);
+      }
       if (grads) launch_fused<MODE_GRAD>(a, R); else launch_fused<MODE_LOSS>(a, R);
     }
     const int n_parts = use_mfma ? mf_npanels : nitems;
@@ -1495,7 +1558,10 @@ struct SolverT final : cal_solver {
   bool tail_fits_one_launch() const { return 2LL * nants * fpad + 2LL * ncoef <= (1LL << 20) && launch_mode != CAL_LAUNCH_KERNELS; }
   // Problems whose step is tens of microseconds: the whole tail as ONE launch (step_tail_kernel) -- no communicator (the
   // exchange sits between the reduction and the update), general kernels, and not when every kernel is asked to be its own launch
-  bool one_launch_tail() const { return !comm_on() && !mf_ok && tail_fits_one_launch() && launch_mode != CAL_LAUNCH_KERNELS; }
+  // (... nor with the regulariser over baselines that share tiles: alpha is needed between that path's two passes)
+  bool one_launch_tail() const {
+    return !comm_on() && !mf_ok && tail_fits_one_launch() && launch_mode != CAL_LAUNCH_KERNELS && !(reg == CAL_REG_SUM && nheads > 0);
+  }
   void launch_tail(const TailArgs<T>& a, unsigned grid, bool R) {
     if (R)
       hipLaunchKernelGGL((step_tail_kernel<T, true>), dim3(grid), dim3(256), 0, stream, a);
@@ -1690,8 +1756,8 @@ struct SolverT final : cal_solver {
     if (grads) {
       if (gg_r) CAL_TRY(download_rows(gg_r, comm.as<T>(), nants, 2, 0));
       if (gg_i) CAL_TRY(download_rows(gg_i, comm.as<T>(), nants, 2, 1));
-      if (gc_r) HIP_TRY(hipMemcpy(gc_r, grad_c0(), (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
-      if (gc_i) HIP_TRY(hipMemcpy(gc_i, grad_c0() + ncoef, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
+      if (gc_r) HIP_TRY(copy_sync(gc_r, grad_c0(), (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
+      if (gc_i) HIP_TRY(copy_sync(gc_i, grad_c0() + ncoef, (size_t)ncoef * sizeof(T), hipMemcpyDeviceToHost));
     }
     return CAL_OK;
   }
@@ -1770,7 +1836,7 @@ struct SolverT final : cal_solver {
         res[t].nonfinite = h.nonfinite ? 1 : 0;
       }
       if (r->record && losses_out && h.n_recorded > 0)
-        HIP_TRY(hipMemcpy(losses_out + (size_t)t * r->nsteps, losses.as<double>() + (size_t)t * cap,
+        HIP_TRY(copy_sync(losses_out + (size_t)t * r->nsteps, losses.as<double>() + (size_t)t * cap,
                           (size_t)std::min(h.n_recorded, r->nsteps) * sizeof(double), hipMemcpyDeviceToHost));
       if (h.nonfinite && bad < 0) bad = t;
     }

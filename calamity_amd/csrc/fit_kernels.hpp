@@ -582,7 +582,9 @@ constexpr size_t multi_lds_bytes() {
   constexpr int NB = MultiCfg<T>::nb_max;
   return ((size_t)NB * TileCfg<T, FB>::MAXK + (size_t)NB * kWaves * FB + (size_t)NB * FB) * 2 * sizeof(T) + NB * sizeof(Member) + 64;
 }
-template <typename T, int FB, int MODE>
+// REG: the "sum" regulariser in two passes (see multi_mfma_item): the loss pass also sums S = sum w m per member, the gradient
+// pass applies e = -2 w r + alpha w with the alpha of the member's slice and leaves the loss partials of the loss pass in place
+template <typename T, int FB, int MODE, bool REG>
 __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const Item it, unsigned char* smem, int item_idx) {
   using C = TileCfg<T, FB>;
   using T2 = vec2_t<T>;
@@ -628,8 +630,12 @@ __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const 
 #pragma unroll
     for (int l = 0; l < L; ++l) acc[m][l].x = acc[m][l].y = 0;
   double loss_acc[R];  // per (member, channel) pair of this thread: each member's loss goes to its OWN slot (its time slice's sum)
+  double sr_acc[REG && !GRAD ? R : 1], si_acc[REG && !GRAD ? R : 1];
+  T al_r[REG && GRAD ? R : 1], al_i[REG && GRAD ? R : 1];
 #pragma unroll
   for (int r = 0; r < R; ++r) loss_acc[r] = 0.0;
+#pragma unroll
+  for (int r = 0; r < (REG && !GRAD ? R : 1); ++r) sr_acc[r] = si_acc[r] = 0.0;
   // this thread's (member, channel) pairs of the per-channel stage: pair p = r * 256 + tid -> member p / FB, channel p % FB
   int pm[R], pch[R];
   unsigned prow[R];    // sample row of the member: bl * fpad (32-bit element offsets: the host checks (nbls + 1) * fpad < 2^31)
@@ -643,6 +649,10 @@ __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const 
     prow[r] = (unsigned)s_mem[mm].bl * (unsigned)A.fpad + (unsigned)pch[r];
     pg0[r] = (unsigned)s_mem[mm].ant0 * (unsigned)A.fpad + (unsigned)pch[r];
     pg1[r] = (unsigned)s_mem[mm].ant1 * (unsigned)A.fpad + (unsigned)pch[r];
+    if (REG && GRAD) {
+      al_r[r] = (T)A.state[s_mem[mm].slice].alpha_r;
+      al_i[r] = (T)A.state[s_mem[mm].slice].alpha_i;
+    }
   }
   __syncthreads();  // s_c complete
 
@@ -705,10 +715,18 @@ __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const 
         const T m_i = G_i * vr + G_r * vi;
         const T r_r = d_r[r] - m_r;
         const T r_i = d_i[r] - m_i;
-        loss_acc[r] += (double)(w[r] * (r_r * r_r + r_i * r_i));
+        if (!(REG && GRAD)) loss_acc[r] += (double)(w[r] * (r_r * r_r + r_i * r_i));
+        if (REG && !GRAD) {
+          sr_acc[r] += (double)(w[r] * m_r);
+          si_acc[r] += (double)(w[r] * m_i);
+        }
         if (GRAD) {
-          const T e_r = (T)-2 * w[r] * r_r;
-          const T e_i = (T)-2 * w[r] * r_i;
+          T e_r = (T)-2 * w[r] * r_r;
+          T e_i = (T)-2 * w[r] * r_i;
+          if (REG) {
+            e_r += al_r[r] * w[r];
+            e_i += al_i[r] * w[r];
+          }
           T2 gv;  // gbar_v = conj(G) e
           gv.x = G_r * e_r + G_i * e_i;
           gv.y = G_r * e_i - G_i * e_r;
@@ -744,17 +762,28 @@ __device__ __forceinline__ void process_multi_item(const FusedArgs<T>& A, const 
   // coefficient gradients of every member.  Pair p = r * 256 + tid is (member p / FB, channel p % FB): the per-pair sums go to LDS
   // (the coefficient area is free by now) and thread m adds the FB channels of member m in order.
   __syncthreads();
-  double* s_red = reinterpret_cast<double*>(smem);  // [R * kThreads] >= [NBMAX * FB]
+  if (!(REG && GRAD)) {
+    double* s_red = reinterpret_cast<double*>(smem);  // [R * kThreads] >= [NBMAX * FB]
+    constexpr int NQ = REG ? 3 : 1;  // loss (, S_r, S_i), one after the other through the same area
+    double tot[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-  for (int r = 0; r < R; ++r) s_red[r * kThreads + tid] = loss_acc[r];
-  __syncthreads();
-  if (tid < NB) {
-    double a = 0;
-    for (int ch = 0; ch < FB; ++ch) a += s_red[tid * FB + ch];
-    const size_t slot = (size_t)s_mem[tid].item * 4;
-    A.part[slot + 0] = a;
-    A.part[slot + 1] = 0.0;
-    A.part[slot + 2] = 0.0;
+    for (int qn = 0; qn < NQ; ++qn) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) s_red[r * kThreads + tid] = qn == 0 ? loss_acc[r] : (qn == 1 ? sr_acc[REG && !GRAD ? r : 0] : si_acc[REG && !GRAD ? r : 0]);
+      __syncthreads();
+      if (tid < NB) {
+        double a = 0;
+        for (int ch = 0; ch < FB; ++ch) a += s_red[tid * FB + ch];
+        tot[qn] = a;
+      }
+      __syncthreads();
+    }
+    if (tid < NB) {
+      const size_t slot = (size_t)s_mem[tid].item * 4;
+      A.part[slot + 0] = tot[0];
+      A.part[slot + 1] = tot[1];
+      A.part[slot + 2] = tot[2];
+    }
   }
   if (GRAD) {
 #pragma unroll
@@ -1109,7 +1138,7 @@ void fused_basis_kernel(const FusedArgs<T> A) {
   if (A.nslices > 1) st_own = A.state + it.slice;
   else if (A.state->done | A.state->done_after) return;
   // baselines that share tiles are processed together by fused_multi_kernel in the passes that have such a form
-  if (!REG && (MODE == MODE_LOSS || MODE == MODE_GRAD) && (it.role_n & 3) != 0 && A.heads != nullptr) return;
+  if ((MODE == MODE_LOSS || MODE == MODE_GRAD) && (it.role_n & 3) != 0 && A.heads != nullptr) return;
   constexpr int FBM = FbSet<T>::fb_max;
   const int fb = 1 << it.fb_log2;
   if (fb == FBM) process_item<T, FBM, MODE, REG, L>(A, it, smem, idx, st_own);
@@ -1119,7 +1148,7 @@ void fused_basis_kernel(const FusedArgs<T> A) {
   else process_item<T, FBM / 16, MODE, REG, L>(A, it, smem, idx, st_own);
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool REG>
 __global__ __launch_bounds__(kThreads, 2) void fused_multi_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int idx = A.heads[blockIdx.x];
@@ -1128,11 +1157,11 @@ __global__ __launch_bounds__(kThreads, 2) void fused_multi_kernel(const FusedArg
   if (A.nslices == 1 && (A.state->done | A.state->done_after)) return;
   constexpr int FBM = FbSet<T>::fb_max;
   const int fb = 1 << it.fb_log2;
-  if (fb == FBM) process_multi_item<T, FBM, MODE>(A, it, smem, idx);
-  else if (fb == FBM / 2) process_multi_item<T, FBM / 2, MODE>(A, it, smem, idx);
-  else if (fb == FBM / 4) process_multi_item<T, FBM / 4, MODE>(A, it, smem, idx);
-  else if (fb == FBM / 8) process_multi_item<T, FBM / 8, MODE>(A, it, smem, idx);
-  else process_multi_item<T, FBM / 16, MODE>(A, it, smem, idx);
+  if (fb == FBM) process_multi_item<T, FBM, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 2) process_multi_item<T, FBM / 2, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 4) process_multi_item<T, FBM / 4, MODE, REG>(A, it, smem, idx);
+  else if (fb == FBM / 8) process_multi_item<T, FBM / 8, MODE, REG>(A, it, smem, idx);
+  else process_multi_item<T, FBM / 16, MODE, REG>(A, it, smem, idx);
 }
 
 template <typename T, int MODE, bool REG>

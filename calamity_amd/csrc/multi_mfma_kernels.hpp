@@ -47,10 +47,14 @@ constexpr int kMmTilePadElems = 2048;      // zeroed elements the tile buffers c
 
 inline size_t multi_mfma_lds_bytes(int nvec_max) {
   const size_t nt = (nvec_max + 15) / 16;
-  return 256 + 256 + nt * 4 * 64 * 4 + 4 * nt * 16 * 16 * 4 + 4 * 16 * kMmGvPitch * 4;  // members, loss partials, coefficient operand, four strips, four gbar_v buffers
+  return 256 + 768 + 64 + nt * 4 * 64 * 4 + 4 * nt * 16 * 16 * 4 + 4 * 16 * kMmGvPitch * 4;  // members, loss partials, coefficient operand, four strips, four gbar_v buffers
 }
 
-template <int MODE, int NT, int DEPTH>
+// REG: the "sum" regulariser (calibration.py:1623-1656) in two passes, like the dense kernels: the loss pass also sums S = sum w m of
+// every member; once the slices' alpha = 2 (S - P) are known (alpha_kernel) the gradient pass applies e = -2 w r + alpha w with the
+// alpha of each member's own slice -- no second adjoint set, the tiles stream once per pass for all members.  The gradient pass
+// then leaves the loss partials of the loss pass in place.
+template <int MODE, int NT, int DEPTH, bool REG>
 __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const Item& it, int item_idx, unsigned char* smem) {
   constexpr bool GRAD = MODE == MODE_GRAD;
   constexpr int NS = 4 * NT;   // forward k-steps (four vectors each), run as two interleaved accumulator chains
@@ -65,14 +69,20 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   const unsigned FB = 1u << fb_log2;
 
   Member* s_mem = reinterpret_cast<Member*>(smem);
-  double* s_red = reinterpret_cast<double*>(smem + 256);  // [4 waves][8 members]
-  float* s_c = reinterpret_cast<float*>(smem + 512);                 // [NS steps][64 lanes]: C[4 s + (lane >> 4)][lane & 15]
+  double* s_red = reinterpret_cast<double*>(smem + 256);  // [loss, S_r, S_i][4 waves][8 members]
+  float* s_al = reinterpret_cast<float*>(smem + 1024);               // REG, gradient pass: [8 members](alpha_r, alpha_i) of the member's slice
+  float* s_c = reinterpret_cast<float*>(smem + 1088);                 // [NS steps][64 lanes]: C[4 s + (lane >> 4)][lane & 15]
   float* s_strips = s_c + NS * 64;                                   // [4 waves][16 NT rows][16 channels], swizzled
   float* s_strip = s_strips + wave * NT * 256;
   float* s_gv = s_strips + 4 * NT * 256 + wave * (16 * kMmGvPitch);   // [16 columns][16 channels] gbar_v of the current job, pitch 20 words
 
   if (tid < NB * (int)(sizeof(Member) / 4)) reinterpret_cast<int*>(s_mem)[tid] = reinterpret_cast<const int*>(A.members + it.member0)[tid];
   __syncthreads();
+  if (REG && GRAD && tid < 8) {
+    const DevState* sst = A.state + (tid < NB ? s_mem[tid].slice : 0);
+    s_al[2 * tid] = tid < NB ? (float)sst->alpha_r : 0.f;
+    s_al[2 * tid + 1] = tid < NB ? (float)sst->alpha_i : 0.f;
+  }
   for (int n = tid; n < NS * 64; n += kThreads) {
     const int k = n >> 4, j = n & 15, m = j & 7;
     float v = 0.f;
@@ -152,6 +162,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
 #pragma unroll
   for (int t = 0; t < NT; ++t) dC[t] = mm_f32x4{0.f, 0.f, 0.f, 0.f};
   double loss_acc[2] = {0.0, 0.0};  // of this lane's two members: each member's loss goes to its OWN slot (its time slice's sum)
+  double sr_acc[2] = {0.0, 0.0}, si_acc[2] = {0.0, 0.0};  // REG, loss pass: S = sum w m of the two members
 
 #ifdef CAL_MM_STAMP
   long long t_bar = 0, t_f = 0, t_e = 0, t_b = 0, t_prev = 0;
@@ -234,9 +245,17 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
       const float m_r = G_r * vr - G_i * vi;
       const float m_i = G_i * vr + G_r * vi;
       const float r_r = d_r - m_r, r_i = d_i - m_i;
-      loss_acc[i] += (double)(w * (r_r * r_r + r_i * r_i));
+      if (!(REG && GRAD)) loss_acc[i] += (double)(w * (r_r * r_r + r_i * r_i));
+      if (REG && !GRAD) {
+        sr_acc[i] += (double)(w * m_r);
+        si_acc[i] += (double)(w * m_i);
+      }
       if (GRAD) {
-        const float e_r = -2.f * w * r_r, e_i = -2.f * w * r_i;
+        float e_r = -2.f * w * r_r, e_i = -2.f * w * r_i;
+        if (REG) {
+          e_r += s_al[2 * (m_a + i)] * w;
+          e_i += s_al[2 * (m_a + i) + 1] * w;
+        }
         // gbar_v = conj(G) e -> the wave's [column][channel] buffer, from where B takes it as its operand
         s_gw[i * kMmGvPitch] = G_r * e_r + G_i * e_i;
         s_gw[(8 + i) * kMmGvPitch] = G_r * e_i - G_i * e_r;
@@ -310,19 +329,25 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   // ---- epilogue: loss partial of every member (into the member's own slot: members may belong to different time slices),
   // coefficient gradients of every member.  Lane (col, kq) holds members m_a, m_a + 1 at its channels: sum over the 16 lanes of
   // the row, then over the four waves in order.
+  if (!(REG && GRAD)) {
+    constexpr int NQ = REG ? 3 : 1;  // loss (, S_r, S_i): s_red [quantity][4 waves][8 members]
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    double v = loss_acc[i];
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int sft = 1; sft < 16; sft <<= 1) v += __shfl_xor(v, sft, 64);
-    if (col == 0) s_red[wave * 8 + m_a + i] = v;
+      for (int qn = 0; qn < NQ; ++qn) {
+        double v = qn == 0 ? loss_acc[i] : (qn == 1 ? sr_acc[i] : si_acc[i]);
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) v += __shfl_xor(v, sft, 64);
+        if (col == 0) s_red[qn * 32 + wave * 8 + m_a + i] = v;
+      }
+    }
   }
   __syncthreads();  // also: every wave has left its strip
-  if (tid < NB) {
+  if (!(REG && GRAD) && tid < NB) {
     const size_t slot = (size_t)s_mem[tid].item * 4;
     A.part[slot + 0] = ((s_red[tid] + s_red[8 + tid]) + s_red[16 + tid]) + s_red[24 + tid];
-    A.part[slot + 1] = 0.0;
-    A.part[slot + 2] = 0.0;
+    A.part[slot + 1] = REG ? ((s_red[32 + tid] + s_red[40 + tid]) + s_red[48 + tid]) + s_red[56 + tid] : 0.0;
+    A.part[slot + 2] = REG ? ((s_red[64 + tid] + s_red[72 + tid]) + s_red[80 + tid]) + s_red[88 + tid] : 0.0;
   }
   if (!GRAD) return;
   // dC[t][r] of lane (col, kq) of wave w = that wave's part of GC[16 t + 4 kq + r][col]; the four parts meet in the strip area:
@@ -350,30 +375,31 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   }
 }
 
-template <int MODE>
+template <int MODE, bool REG>
 __global__ __launch_bounds__(kThreads, 2) void fused_multi_mfma_kernel(const FusedArgs<float> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int item_idx = A.heads[blockIdx.x];
+  if (item_idx < 0) return;  // an empty slot of the XCD-affine head list
   const Item it = A.items[item_idx];
   // (members of several time slices: the item runs while any of them does; a stopped member's outputs are not consumed)
   if (A.nslices == 1 && (A.state->done | A.state->done_after)) return;
   // the ring of tile registers is 4 jobs deep up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads (7 to 14 KB) in flight per wave
   const bool quad = ((A.fpad >> 6) & 3) == 0;  // a wave's jobs come in fours
   switch ((it.nvec + 15) >> 4) {  // wave-uniform
-    case 1: if (quad) multi_mfma_item<MODE, 1, 4>(A, it, item_idx, smem); else multi_mfma_item<MODE, 1, 2>(A, it, item_idx, smem); break;
-    case 2: if (quad) multi_mfma_item<MODE, 2, 4>(A, it, item_idx, smem); else multi_mfma_item<MODE, 2, 2>(A, it, item_idx, smem); break;
-    case 3: if (quad) multi_mfma_item<MODE, 3, 4>(A, it, item_idx, smem); else multi_mfma_item<MODE, 3, 2>(A, it, item_idx, smem); break;
-    case 4: multi_mfma_item<MODE, 4, 2>(A, it, item_idx, smem); break;
-    case 5: multi_mfma_item<MODE, 5, 2>(A, it, item_idx, smem); break;
-    case 6: multi_mfma_item<MODE, 6, 2>(A, it, item_idx, smem); break;
-    case 7: multi_mfma_item<MODE, 7, 2>(A, it, item_idx, smem); break;
-    case 8: multi_mfma_item<MODE, 8, 1>(A, it, item_idx, smem); break;
-    case 9: multi_mfma_item<MODE, 9, 1>(A, it, item_idx, smem); break;
-    case 10: multi_mfma_item<MODE, 10, 1>(A, it, item_idx, smem); break;
-    case 11: multi_mfma_item<MODE, 11, 1>(A, it, item_idx, smem); break;
-    case 12: multi_mfma_item<MODE, 12, 1>(A, it, item_idx, smem); break;
-    case 13: multi_mfma_item<MODE, 13, 1>(A, it, item_idx, smem); break;
-    case 14: multi_mfma_item<MODE, 14, 1>(A, it, item_idx, smem); break;
+    case 1: if (quad) multi_mfma_item<MODE, 1, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<MODE, 1, 2, REG>(A, it, item_idx, smem); break;
+    case 2: if (quad) multi_mfma_item<MODE, 2, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<MODE, 2, 2, REG>(A, it, item_idx, smem); break;
+    case 3: if (quad) multi_mfma_item<MODE, 3, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<MODE, 3, 2, REG>(A, it, item_idx, smem); break;
+    case 4: multi_mfma_item<MODE, 4, 2, REG>(A, it, item_idx, smem); break;
+    case 5: multi_mfma_item<MODE, 5, 2, REG>(A, it, item_idx, smem); break;
+    case 6: multi_mfma_item<MODE, 6, 2, REG>(A, it, item_idx, smem); break;
+    case 7: multi_mfma_item<MODE, 7, 2, REG>(A, it, item_idx, smem); break;
+    case 8: multi_mfma_item<MODE, 8, 1, REG>(A, it, item_idx, smem); break;
+    case 9: multi_mfma_item<MODE, 9, 1, REG>(A, it, item_idx, smem); break;
+    case 10: multi_mfma_item<MODE, 10, 1, REG>(A, it, item_idx, smem); break;
+    case 11: multi_mfma_item<MODE, 11, 1, REG>(A, it, item_idx, smem); break;
+    case 12: multi_mfma_item<MODE, 12, 1, REG>(A, it, item_idx, smem); break;
+    case 13: multi_mfma_item<MODE, 13, 1, REG>(A, it, item_idx, smem); break;
+    case 14: multi_mfma_item<MODE, 14, 1, REG>(A, it, item_idx, smem); break;
     default: break;  // the host gives this kernel no wider block
   }
 }

@@ -59,6 +59,21 @@ def baseline_to_antnums(bl):
     return (bl // 2048 - 1, bl % 2048 - 1)
 
 
+def _copy_array(a):
+    """``a.copy()``; arrays of hundreds of megabytes (visibilities, nsamples at HERA-350) row chunk by row chunk on the host's cores."""
+    if a.nbytes < (64 << 20) or a.ndim < 2 or not a.flags.c_contiguous:
+        return a.copy()
+    from .utils import for_row_chunks
+
+    out = np.empty_like(a)
+
+    def chunk(lo, hi):
+        out[lo:hi] = a[lo:hi]
+
+    for_row_chunks(chunk, a.shape[0])
+    return out
+
+
 class SimpleUVData:
     """Container with the UVData attributes and methods the calamity path uses."""
 
@@ -106,7 +121,7 @@ class SimpleUVData:
         out = copy.copy(self)
         for k, v in self.__dict__.items():
             if isinstance(v, np.ndarray):
-                out.__dict__[k] = memo[id(v)] if id(v) in memo else v.copy()  # (memo: arrays the caller will replace anyway)
+                out.__dict__[k] = memo[id(v)] if id(v) in memo else _copy_array(v)  # (memo: arrays the caller will replace anyway)
             elif isinstance(v, (list, tuple)):
                 out.__dict__[k] = copy.copy(v)
         out._ap_index = dict(self._ap_index)

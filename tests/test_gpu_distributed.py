@@ -51,14 +51,18 @@ def test_one_rank_rehearsal_under_torchrun_matches_plain_solver(layout, reg):
     import bench
     from calamity_amd.solver import HipFitSolver
 
-    prob, start, _ = bench.build_sharded_job("hera350", 0, 1, SLICES, reg=reg == "sum", max_bls=MAX_BLS)
+    # the same job in a plain solver: one loop state per time slice (each slice its own priors and loss), the job's loss their sum
+    prob, start, _ = bench.build_sharded_job("hera350", 0, 1, SLICES, reg=reg == "sum", max_bls=MAX_BLS, per_slice=True)
     s = HipFitSolver(dtype=np.float32)
     s.set_problem(prob, layout=layout)
     s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
     if reg == "sum":
-        s.set_regularization("sum", float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts)))
+        nb = prob.nbls // SLICES
+        s.set_regularization("sum", np.asarray([float(np.sum((prob.sky_r * prob.wgts)[t * nb : (t + 1) * nb])) for t in range(SLICES)]),
+                             np.asarray([float(np.sum((prob.sky_i * prob.wgts)[t * nb : (t + 1) * nb])) for t in range(SLICES)]))
     s.set_optimizer("Adam", learning_rate=1e-2)
-    s.run(WARMUP, record=False)
-    ref, _, _ = s.run(STEPS, record=True, tol=0.0)
+    s.run_slices(WARMUP, record=False)
+    ref = np.sum([r[0] for r in s.run_slices(STEPS, record=True, tol=0.0)], axis=0)
     s.close()
     assert np.array_equal(losses, ref), (losses, ref)
+    assert out["n_ranks_seen"] == 1

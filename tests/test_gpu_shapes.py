@@ -142,7 +142,7 @@ def test_time_slices_that_share_tiles(nslices):
     (SURVEY.md section 8e "Multiple times"; calibration.py:1160-1167 loops over times).  Every tile width, sets larger than a multi
     item holds (10 slices: 8 + 2 in float32, 4 + 4 + 2 in float64; 9 slices: the last baseline of a set is left over and runs as an
     ordinary item), loss / gradients against the C restatement of the batched problem, the regularised form
-    (which runs the baselines one by one), model evaluation and initial coefficients, and a short trajectory against the one
+    (two passes of the same kernels: S first, then the gradients with every slice's alpha), model evaluation and initial coefficients, and a short trajectory against the one
     of the same problem WITHOUT the alias table (every baseline streaming its own copy; the loss partials are summed in another
     order, so equal to rounding, not to the bit)."""
     from calamity_amd import distributed as D
@@ -163,13 +163,18 @@ def test_time_slices_that_share_tiles(nslices):
     check(prob, start, layouts=("stream",))
     plain = D.batch_time_slices(parts)[0]
     plain.bl_alias = None
-    for dtype in (np.float64, np.float32):
+    pri = float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts))
+    for dtype, reg in ((np.float64, False), (np.float32, False), (np.float64, True), (np.float32, True)):
+        # (with the regulariser: the two-pass form of the multi-slice kernels against the one-pass, two-adjoint-set form of the
+        # same problem without the alias table)
         outs = []
         for pr in (prob, plain):
             s = HipFitSolver(dtype=dtype)
             s.set_problem(pr, layout="stream")
             mem = s.memory_bytes()
             s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+            if reg:
+                s.set_regularization("sum", *pri)
             s.set_optimizer("Adam", learning_rate=1e-2)
             losses, _, _ = s.run(7, record=True, tol=0.0)
             model = s.model()
