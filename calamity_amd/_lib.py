@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcalamity_hip.so")  # the one shipped build; experiment harnesses (tools/) assign this attribute before load()
 
 CAL_F32, CAL_F64 = 0, 1
-CAL_OPT_ADAM, CAL_OPT_ADAMAX, CAL_OPT_SGD, CAL_OPT_RMSPROP, CAL_OPT_ADAGRAD, CAL_OPT_NADAM, CAL_OPT_ADADELTA = range(7)
+CAL_OPT_ADAM, CAL_OPT_ADAMAX, CAL_OPT_SGD, CAL_OPT_RMSPROP, CAL_OPT_ADAGRAD, CAL_OPT_NADAM, CAL_OPT_ADADELTA, CAL_OPT_FTRL = range(8)
 CAL_REG_NONE, CAL_REG_SUM = 0, 1
 CAL_LAYOUT_STREAM, CAL_LAYOUT_SHARED = 0, 1
 CAL_PATH_AUTO, CAL_PATH_GENERAL, CAL_PATH_DENSE = 0, 1, 2
@@ -56,6 +56,11 @@ class OptimizerDesc(C.Structure):
         ("initial_accumulator_value", C.c_double),
         ("nesterov", C.c_int32),
         ("reserved", C.c_int32),
+        ("learning_rate_power", C.c_double),
+        ("l1_regularization_strength", C.c_double),
+        ("l2_regularization_strength", C.c_double),
+        ("l2_shrinkage_regularization_strength", C.c_double),
+        ("beta", C.c_double),
     ]
 
 

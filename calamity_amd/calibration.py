@@ -10,8 +10,8 @@ gradient-descent fitter: ``calibrate_and_model_dpss`` (:1503-1584) -> ``calibrat
   (:140-146, :167); ``fg_comps`` arguments accept either form;
 * ``graph_mode`` / ``graph_args_dict`` are accepted and ignored (there is no tracing compiler on this path);
 * ``n_profile_steps`` writes HIP-event kernel timings as JSON into ``profile_log_dir`` instead of a TF profile;
-* optimizers: "Adamax", "Adam", "SGD", "RMSprop", "Adagrad", "Adadelta", "Nadam" with the Keras (OptimizerV2) semantics, defaults
-  and constructor arguments; "Ftrl", "LAMB" and every other name raise ``KeyError`` like ``OPTIMIZERS[...]`` (:571).
+* optimizers: "Adamax", "Adam", "SGD", "RMSprop", "Adagrad", "Adadelta", "Nadam", "Ftrl" with the Keras (OptimizerV2) semantics,
+  defaults and constructor arguments; the tensorflow-addons "LAMB" and every other name raise ``KeyError`` like ``OPTIMIZERS[...]`` (:571).
 
 There is no CPU fallback: without the HIP library / a GPU these functions raise.
 """
@@ -373,11 +373,11 @@ def get_solver(fg_model_comps, dtype=np.float32, layout=None, device=None):
     dtype = np.dtype(dtype)
     cache = fg_model_comps.__dict__.setdefault("_solvers", {})
     # (a caller's explicit choice -- calibrate_and_model_tensor(layout=..., devices=[...]) -- travels with the components)
-    layout = layout or fg_model_comps.__dict__.get("_layout") or os.environ.get("CALAMITY_AMD_LAYOUT", "shared")
+    layout = layout or fg_model_comps.__dict__.get("_layout") or "shared"
     if device is None:
         device = fg_model_comps.__dict__.get("_device")
     if device is None:
-        device = _DEVICE["index"] if _DEVICE["index"] is not None else int(os.environ.get("CALAMITY_AMD_DEVICE", "0"))
+        device = _DEVICE["index"] if _DEVICE["index"] is not None else 0
     # one solver per calling thread: a handle is not re-entrant, and concurrent fits of different (pol, time) slices
     # (calibrate_and_model_tensor, parallel_fits > 1) each need their own device buffers and stream
     key = (dtype.str, layout, device, threading.get_ident())
@@ -646,7 +646,8 @@ def calibrate_and_model_tensor(
       share of the fitting groups of every slice; the caller's process drives them all.
     * ``layout``: "shared" (default; baselines alias the distinct basis blocks) or "stream" (every baseline owns its tiles).
     * ``parallel_fits`` (default 1): with ``batch_slices=False``, fits that many slices concurrently, each on its own
-      solver and HIP stream."""
+      solver and HIP stream.
+    (Nothing here is steered by environment variables: layout, devices and concurrency are arguments.)"""
     antpairs_data = uvdata.get_antpairs()
     if not include_autos:
         antpairs_data = set([ap for ap in antpairs_data if ap[0] != ap[1]])
@@ -688,7 +689,7 @@ def calibrate_and_model_tensor(
     del fg_model_comps_dict
     prob = fg_model_comps
     if parallel_fits is None:
-        parallel_fits = int(os.environ.get("CALAMITY_AMD_PARALLEL_FITS", "1"))
+        parallel_fits = 1
     if init_guesses_from_previous_time_step:
         parallel_fits = 1
     times = np.unique(uvdata.time_array)
@@ -909,7 +910,7 @@ def _default_devices(nsamples_per_step):
     one device selected for the process (read_calibrate_and_model_dpss: calibration.py:1741-1753)."""
     from . import _lib
 
-    first = _DEVICE["index"] if _DEVICE["index"] is not None else int(os.environ.get("CALAMITY_AMD_DEVICE", "0"))
+    first = _DEVICE["index"] if _DEVICE["index"] is not None else 0
     n = _lib.device_count()
     if n > 1 and _DEVICE["index"] is None and nsamples_per_step >= 2.0e7:
         return list(range(n))
@@ -944,7 +945,7 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
     with per-slice loop control.  Returns ``fit_history``."""
     OPTIMIZERS[optimizer]  # unknown optimizer -> KeyError, like calibration.py:571
     dtype = np.dtype(dtype)
-    layout = layout or os.environ.get("CALAMITY_AMD_LAYOUT", "shared")
+    layout = layout or "shared"
     pols = list(uvdata.get_pols())
     fit_history = {polnum: {} for polnum in range(len(pols))}
     todo = []

@@ -258,7 +258,7 @@ struct SolverT final : cal_solver {
     return m;
   }
   // settings
-  cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7, 0.9, 0.0, 0.1, 0, 0};
+  cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7, 0.9, 0.0, 0.1, 0, 0, -0.5, 0.0, 0.0, 0.0, 0.0};
   int reg = CAL_REG_NONE;
   // timing
   bool timing = false;
@@ -1219,13 +1219,13 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipSetDevice(device));
     if (!has_problem) return fail(CAL_ERR_STATE, "set_optimizer before set_problem");
     if (!d) return fail(CAL_ERR_INVALID, "set_optimizer: null");
-    if (d->optimizer < CAL_OPT_ADAM || d->optimizer > CAL_OPT_ADADELTA)
+    if (d->optimizer < CAL_OPT_ADAM || d->optimizer > CAL_OPT_FTRL)
       return fail(CAL_ERR_INVALID, "set_optimizer: unknown optimizer id %d", d->optimizer);
     opt = *d;
     HIP_TRY(hipMemsetAsync(gains_m.p, 0, gains_m.bytes, stream));
     HIP_TRY(hipMemsetAsync(coef_m.p, 0, coef_m.bytes, stream));
-    if (d->optimizer == CAL_OPT_ADAGRAD && d->initial_accumulator_value != 0.0) {
-      // Adagrad's accumulator starts at initial_accumulator_value (Keras default 0.1)
+    if ((d->optimizer == CAL_OPT_ADAGRAD || d->optimizer == CAL_OPT_FTRL) && d->initial_accumulator_value != 0.0) {
+      // Adagrad's / Ftrl's accumulator starts at initial_accumulator_value (Keras default 0.1)
       hipLaunchKernelGGL(fill_kernel<T>, dim3(grid_for((long long)(gains_v.bytes / sizeof(T)))), dim3(256), 0, stream, gains_v.as<T>(),
                          (long long)(gains_v.bytes / sizeof(T)), (T)d->initial_accumulator_value);
       hipLaunchKernelGGL(fill_kernel<T>, dim3(grid_for((long long)(coef_v.bytes / sizeof(T)))), dim3(256), 0, stream, coef_v.as<T>(),
@@ -1707,6 +1707,10 @@ struct SolverT final : cal_solver {
       h.nesterov = opt.nesterov;
       h.momentum = opt.momentum;
       h.rho = opt.rho;
+      h.ftrl[0] = opt.learning_rate_power;
+      h.ftrl[1] = opt.l1_regularization_strength;
+      h.ftrl[2] = opt.l2_regularization_strength + opt.beta / (2.0 * opt.learning_rate);
+      h.ftrl[3] = opt.l2_shrinkage_regularization_strength;
       h.reg = reg == CAL_REG_SUM;
       h.f32 = std::is_same<T, float>::value ? 1 : 0;
       h.prior_r = prior_r_t[t];

@@ -64,9 +64,10 @@ struct DevState {
   int nesterov;       // SGD
   double momentum, rho;      // SGD / RMSprop momentum; RMSprop / Adadelta decay
   double nadam_sched;        // Nadam: running product of its momentum schedule (Keras' _m_cache), 1 before the first update
+  double ftrl[4];            // Ftrl: learning_rate_power, l1, l2 + beta / (2 lr), l2_shrinkage
   double k[6];               // the current step's update coefficients, per optimizer: see optimizer_step
 };
-enum { OPT_ADAM = 0, OPT_ADAMAX = 1, OPT_SGD = 2, OPT_RMSPROP = 3, OPT_ADAGRAD = 4, OPT_NADAM = 5, OPT_ADADELTA = 6 };
+enum { OPT_ADAM = 0, OPT_ADAMAX = 1, OPT_SGD = 2, OPT_RMSPROP = 3, OPT_ADAGRAD = 4, OPT_NADAM = 5, OPT_ADADELTA = 6, OPT_FTRL = 7 };
 
 // Time slices (cal_problem_desc::nslices): one solver may hold several independent fits -- the (polarization, time) slices the
 // reference fits one after another (calibration.py:1160-1167) -- each with its own gains (antennas [t na_slice, (t + 1) na_slice)),
@@ -1452,6 +1453,7 @@ __device__ inline bool advance_state(DevState& s, double l0, double l1, double l
     case OPT_SGD: s.k[1] = s.momentum; s.k[2] = s.nesterov ? 1.0 : 0.0; break;
     case OPT_RMSPROP: s.k[1] = s.rho; s.k[2] = s.momentum; break;
     case OPT_ADADELTA: s.k[1] = s.rho; break;
+    case OPT_FTRL: s.k[1] = s.ftrl[0]; s.k[2] = s.ftrl[1]; s.k[3] = s.ftrl[2]; s.k[4] = s.ftrl[3]; break;
     case OPT_NADAM: {
       const double mu_t = s.beta1 * (1.0 - 0.5 * pow(0.96, 0.004 * (double)s.t));
       const double mu_t1 = s.beta1 * (1.0 - 0.5 * pow(0.96, 0.004 * (double)(s.t + 1)));
@@ -1493,6 +1495,8 @@ __device__ inline bool advance_state(DevState& s, double l0, double l1, double l
 //   RMSprop  v <- rho v + (1 - rho) g^2; momentum 0 -> p -= lr g / (sqrt(v) + eps); else m <- mom m + lr g / sqrt(v + eps), p -= m
 //   Adagrad  v <- v + g^2 (v starts at initial_accumulator_value); p -= lr g / (sqrt(v) + eps)
 //   Adadelta v <- rho v + (1 - rho) g^2; u = sqrt(m + eps) / sqrt(v + eps) g; p -= lr u; m <- rho m + (1 - rho) u^2
+//   Ftrl     (ResourceApplyFtrl[V2]; m = linear, v = accumulator from initial_accumulator_value; k1 = lr_power, k2 = l1, k3 = l2 + beta / (2 lr),
+//            k4 = l2_shrinkage)  v' = v + g^2; sigma = (v'^-k1 - v^-k1) / lr; m += g + 2 k4 p - sigma p; p = |m| > k2 ? (sign(m) k2 - m) / (v'^-k1 / lr + 2 k3) : 0
 //   Nadam    g' = g / k1; m <- b1 m + (1 - b1) g; m' = m / k2; v <- b2 v + (1 - b2) g^2; v' = v / k3; p -= lr (k4 g' + k5 m') / (sqrt(v') + eps)
 template <typename T>
 struct StepCoef { T b1, b2, eps, k[6]; int opt; };
@@ -1545,6 +1549,19 @@ template <typename T> __device__ __forceinline__ T optimizer_step(T pi, T gi, T&
       const T upd = sqrt(mi_io + c.eps) / sqrt(acc + c.eps) * gi;
       mi_io = c.k[1] * mi_io + ((T)1 - c.k[1]) * upd * upd;
       return pi - c.k[0] * upd;
+    }
+    case OPT_FTRL: {
+      const T acc = vi_io, acc_new = acc + gi * gi;
+      const bool half = c.k[1] == (T)-0.5;  // the special case of the TensorFlow kernel: square roots instead of pow
+      const T pn = half ? sqrt(acc_new) : pow(acc_new, -c.k[1]);
+      const T po = half ? sqrt(acc) : pow(acc, -c.k[1]);
+      const T g_shr = gi + (T)2 * c.k[4] * pi;  // l2 shrinkage enters the linear term only
+      const T lin = mi_io + g_shr - (pn - po) / c.k[0] * pi;
+      mi_io = lin;
+      vi_io = acc_new;
+      const T quad = pn / c.k[0] + (T)2 * c.k[3];
+      const T sgn = lin > (T)0 ? (T)1 : (lin < (T)0 ? (T)-1 : (T)0);
+      return fabs(lin) > c.k[2] ? (sgn * c.k[2] - lin) / quad : (T)0;
     }
     default: {  // OPT_NADAM
       const T g_prime = gi / c.k[1];

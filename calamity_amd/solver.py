@@ -6,12 +6,12 @@ import numpy as np
 from . import _lib
 from .problem import FitProblem
 
-# OPTIMIZERS of /root/reference/calamity/calibration.py:17-27 that the HIP fitter implements ("Ftrl" and the
-# tensorflow-addons "LAMB" are not provided); any other name raises KeyError exactly like ``OPTIMIZERS[optimizer]`` at
+# OPTIMIZERS of /root/reference/calamity/calibration.py:17-27 that the HIP fitter implements (the tensorflow-addons "LAMB"
+# is not provided); any other name raises KeyError exactly like ``OPTIMIZERS[optimizer]`` at
 # calibration.py:571.  Constructor arguments and defaults are those of tf.keras.optimizers.* (OptimizerV2, TF 2.4 - 2.10);
 # an argument the optimizer does not take raises TypeError, as the Keras constructor would.
 OPTIMIZERS = {"Adam": _lib.CAL_OPT_ADAM, "Adamax": _lib.CAL_OPT_ADAMAX, "SGD": _lib.CAL_OPT_SGD, "RMSprop": _lib.CAL_OPT_RMSPROP,
-              "Adagrad": _lib.CAL_OPT_ADAGRAD, "Nadam": _lib.CAL_OPT_NADAM, "Adadelta": _lib.CAL_OPT_ADADELTA}
+              "Adagrad": _lib.CAL_OPT_ADAGRAD, "Nadam": _lib.CAL_OPT_NADAM, "Adadelta": _lib.CAL_OPT_ADADELTA, "Ftrl": _lib.CAL_OPT_FTRL}
 _MOMENTS = dict(learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
 _OPT_DEFAULTS = {
     "Adam": _MOMENTS,
@@ -21,6 +21,8 @@ _OPT_DEFAULTS = {
     "RMSprop": dict(learning_rate=1e-3, rho=0.9, momentum=0.0, epsilon=1e-7),
     "Adagrad": dict(learning_rate=1e-3, initial_accumulator_value=0.1, epsilon=1e-7),
     "Adadelta": dict(learning_rate=1e-3, rho=0.95, epsilon=1e-7),
+    "Ftrl": dict(learning_rate=1e-3, learning_rate_power=-0.5, initial_accumulator_value=0.1, l1_regularization_strength=0.0,
+                 l2_regularization_strength=0.0, l2_shrinkage_regularization_strength=0.0, beta=0.0),
 }
 
 
@@ -122,7 +124,11 @@ class HipFitSolver:
         kw = dict(defaults, **opt_kwargs)
         d = _lib.OptimizerDesc(opt_id, kw["learning_rate"], kw.get("beta_1", 0.9), kw.get("beta_2", 0.999), kw.get("epsilon", 1e-7),
                                kw.get("rho", 0.9), kw.get("momentum", 0.0), kw.get("initial_accumulator_value", 0.1),
-                               int(bool(kw.get("nesterov", False))), 0)
+                               int(bool(kw.get("nesterov", False))), 0, kw.get("learning_rate_power", -0.5),
+                               kw.get("l1_regularization_strength", 0.0), kw.get("l2_regularization_strength", 0.0),
+                               kw.get("l2_shrinkage_regularization_strength", 0.0), kw.get("beta", 0.0))
+        if optimizer == "Ftrl" and (kw["learning_rate_power"] > 0.0 or kw["initial_accumulator_value"] < 0.0):
+            raise ValueError("Ftrl: learning_rate_power must be <= 0 and initial_accumulator_value >= 0 (as the Keras constructor checks)")
         _lib.check(self._lib.cal_solver_set_optimizer(self._h, C.byref(d)))
 
     # ---- parameters ----------------------------------------------------------------------------------------

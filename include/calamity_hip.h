@@ -39,8 +39,9 @@ enum cal_status {
 };
 
 enum cal_dtype { CAL_F32 = 0, CAL_F64 = 1 };                 /* dtype kwarg, calibration.py:464, :974 */
-enum cal_optimizer { /* OPTIMIZERS, calibration.py:17-27 (Ftrl and the tensorflow-addons LAMB are not provided) */
-  CAL_OPT_ADAM = 0, CAL_OPT_ADAMAX = 1, CAL_OPT_SGD = 2, CAL_OPT_RMSPROP = 3, CAL_OPT_ADAGRAD = 4, CAL_OPT_NADAM = 5, CAL_OPT_ADADELTA = 6
+enum cal_optimizer { /* OPTIMIZERS, calibration.py:17-27 (the tensorflow-addons LAMB is not provided) */
+  CAL_OPT_ADAM = 0, CAL_OPT_ADAMAX = 1, CAL_OPT_SGD = 2, CAL_OPT_RMSPROP = 3, CAL_OPT_ADAGRAD = 4, CAL_OPT_NADAM = 5, CAL_OPT_ADADELTA = 6,
+  CAL_OPT_FTRL = 7
 };
 enum cal_regularization { CAL_REG_NONE = 0, CAL_REG_SUM = 1 }; /* model_regularization, calibration.py:619-661 */
 enum cal_layout {
@@ -122,6 +123,12 @@ typedef struct cal_optimizer_desc { /* **opt_kwargs -> tf.optimizers.X(...), cal
   double initial_accumulator_value; /* Adagrad: 0.1 */
   int32_t nesterov;               /* SGD */
   int32_t reserved;
+  /* Ftrl (initial_accumulator_value above: 0.1) */
+  double learning_rate_power;                  /* -0.5 */
+  double l1_regularization_strength;           /* 0 */
+  double l2_regularization_strength;           /* 0 */
+  double l2_shrinkage_regularization_strength; /* 0 */
+  double beta;                                 /* 0 */
 } cal_optimizer_desc;
 
 typedef struct cal_run_desc { /* loop controls of fit_gains_and_foregrounds, calibration.py:457-461 */
@@ -185,7 +192,8 @@ int cal_solver_get_params(cal_solver* s, int which, void* g_r, void* g_i, void* 
 /* optimizer slots (checkpoint / resume; no counterpart in the reference): m and v (Adam) / u (Adamax).  A fit resumed with
  * set_params + set_moments (after set_optimizer, whose betas the bias corrections are rebuilt from) continues bit for bit.
  * The two slots per parameter, (m, v): Adam / Nadam first and second moment; Adamax (m, u); SGD (momentum accumulator, unused);
- * RMSprop (momentum accumulator, mean square); Adagrad (unused, accumulator); Adadelta (accumulated updates, accumulated gradients). */
+ * RMSprop (momentum accumulator, mean square); Adagrad (unused, accumulator); Adadelta (accumulated updates, accumulated gradients);
+ * Ftrl (linear, accumulator). */
 int cal_solver_get_moments(cal_solver* s, void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i,
                            void* cv_r, void* cv_i, int64_t* t);
 int cal_solver_set_moments(cal_solver* s, const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i,

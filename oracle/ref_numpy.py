@@ -337,7 +337,34 @@ class Nadam(_SlotOptimizer):
 
 
 # calibration.py:17-27 without Ftrl and the tensorflow-addons LAMB (KeyError, like any unknown name at :571)
-OPTIMIZERS = {"Adam": Adam, "Adamax": Adamax, "SGD": SGD, "RMSprop": RMSprop, "Adagrad": Adagrad, "Adadelta": Adadelta, "Nadam": Nadam}
+class Ftrl(_SlotOptimizer):
+    """tf.keras.optimizers.Ftrl (OptimizerV2, ResourceApplyFtrl / ResourceApplyFtrlV2 with l2 shrinkage): slots linear (0) and
+    accumulator (initial_accumulator_value);  accum' = accum + g^2;  sigma = (accum'^-p - accum^-p) / lr  (p = learning_rate_power,
+    -0.5: square roots);  linear += g + 2 l2_shrinkage var - sigma var;
+    var = |linear| > l1 ? (sign(linear) l1 - linear) / (accum'^-p / lr + 2 (l2 + beta / (2 lr))) : 0."""
+
+    def __init__(self, learning_rate=0.001, learning_rate_power=-0.5, initial_accumulator_value=0.1, l1_regularization_strength=0.0,
+                 l2_regularization_strength=0.0, l2_shrinkage_regularization_strength=0.0, beta=0.0):
+        super().__init__()
+        self.lr, self.p = learning_rate, learning_rate_power
+        self.l1, self.l2 = l1_regularization_strength, l2_regularization_strength + beta / (2.0 * learning_rate)
+        self.l2s = l2_shrinkage_regularization_strength
+        self.slot_init = (0.0, initial_accumulator_value)
+
+    def apply_gradients(self, grads_and_vars):
+        self.t += 1
+        for n, (g, var) in enumerate(grads_and_vars):
+            linear, accum = self.slots(n, var)
+            new_accum = accum + g * g
+            pn, po = new_accum ** (-self.p), accum ** (-self.p)
+            linear += g + 2.0 * self.l2s * var - (pn - po) / self.lr * var
+            quad = pn / self.lr + 2.0 * self.l2
+            var[...] = np.where(np.abs(linear) > self.l1, (np.sign(linear) * self.l1 - linear) / quad, 0.0).astype(var.dtype)
+            accum[...] = new_accum
+
+
+OPTIMIZERS = {"Adam": Adam, "Adamax": Adamax, "SGD": SGD, "RMSprop": RMSprop, "Adagrad": Adagrad, "Adadelta": Adadelta, "Nadam": Nadam,
+              "Ftrl": Ftrl}
 
 
 # --------------------------------------------------------------------------------------------------

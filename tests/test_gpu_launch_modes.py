@@ -135,6 +135,9 @@ OPT_CASES = [
     ("Adagrad", dict(learning_rate=5e-2, initial_accumulator_value=0.0)),
     ("Adadelta", dict(learning_rate=1.0, rho=0.9)),
     ("Nadam", dict(learning_rate=1e-2)),
+    ("Ftrl", dict(learning_rate=5e-2)),
+    ("Ftrl", dict(learning_rate=5e-2, learning_rate_power=-0.3, l1_regularization_strength=1e-4, l2_regularization_strength=1e-3,
+                  l2_shrinkage_regularization_strength=1e-3, beta=0.05, initial_accumulator_value=0.2)),
 ]
 
 
@@ -176,7 +179,9 @@ def test_optimizer_arguments_are_checked_like_keras():
     p, start = make_case(seed=1)
     s = make_solver(p, start, np.float32)
     with pytest.raises(KeyError):
-        s.set_optimizer("Ftrl")
+        s.set_optimizer("LAMB")
+    with pytest.raises(ValueError):
+        s.set_optimizer("Ftrl", learning_rate_power=0.5)  # Keras: learning_rate_power must be <= 0
     with pytest.raises(TypeError):
         s.set_optimizer("SGD", beta_1=0.9)  # not an argument of tf.keras.optimizers.SGD
     with pytest.raises(TypeError):

@@ -195,6 +195,24 @@ def test_other_keras_optimizers_known_answers():
     s2 = s1 * mu[1]
     step2 = ((1 - mu[1]) * g2 / (1 - s2) + mu[2] * m2 / (1 - s2 * mu[2])) / (np.sqrt(v2 / (1 - 0.999**2)) + 1e-7)
     np.testing.assert_allclose(b, a - lr * step2, rtol=1e-14)
+    # Ftrl (defaults: learning_rate_power -0.5, accumulator from 0.1, no l1 / l2): with x = 0 the sigma x term vanishes in step 1
+    a, b = two_steps("Ftrl", learning_rate=lr)
+    n1 = 0.1 + g1**2
+    z1 = g1
+    x1 = -z1 / (np.sqrt(n1) / lr)
+    np.testing.assert_allclose(a, x1, rtol=1e-15)
+    n2 = n1 + g2**2
+    z2 = z1 + g2 - (np.sqrt(n2) - np.sqrt(n1)) / lr * x1
+    np.testing.assert_allclose(b, -z2 / (np.sqrt(n2) / lr), rtol=1e-14)
+    # ... with l1 (soft threshold), l2, beta and l2 shrinkage, a general power
+    kw = dict(learning_rate=lr, learning_rate_power=-0.4, l1_regularization_strength=0.3, l2_regularization_strength=0.2,
+              l2_shrinkage_regularization_strength=0.05, beta=0.1)
+    a, b = two_steps("Ftrl", **kw)
+    l2 = 0.2 + 0.1 / (2 * lr)
+    x1 = np.where(np.abs(z1) > 0.3, (np.sign(z1) * 0.3 - z1) / (n1**0.4 / lr + 2 * l2), 0.0)
+    np.testing.assert_allclose(a, x1, rtol=1e-14)
+    z2 = z1 + g2 + 2 * 0.05 * x1 - (n2**0.4 - n1**0.4) / lr * x1
+    np.testing.assert_allclose(b, np.where(np.abs(z2) > 0.3, (np.sign(z2) * 0.3 - z2) / (n2**0.4 / lr + 2 * l2), 0.0), rtol=1e-14)
 
 
 def test_loop_semantics():
