@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--extras", action="store_true", help="also time the tutorial-notebook and the redundant-groups configurations (they launch "
                     "the same kernels at other sizes, so a rocprofv3 --stats summary of such a run no longer averages the headline launches alone)")
     ap.add_argument("--cpu-sample-bls", type=int, default=192)
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
+                    help="the exchange between the ranks: RCCL over xGMI (one rank per GPU: the measurement), or the library's exchange hook over "
+                         "gloo (ranks may then SHARE a GPU: a functional rehearsal of the N-rank path on a one-GPU box, not a measurement)")
     ap.add_argument("--dist-rehearsal", type=int, default=0, metavar="T",
                     help="with ONE rank (plain or under torch.distributed.run --nproc-per-node 1): take the multi-rank code path anyway -- "
                          "T batched time slices, group partition, gloo rendezvous, unique id broadcast, RCCL communicator of one rank, "
@@ -298,8 +301,10 @@ def main():
     # load the HIP library (and through it /opt/rocm's HIP runtime + RCCL, the ones it was built against) BEFORE torch:
     # torch is only used for the gloo rendezvous/barrier and bundles its own, older ROCm libraries
     _lib.load()
-    if world > _lib.device_count():  # every rank sees this and leaves at once: none waits for a peer that cannot exist
-        raise SystemExit(f"--gpus {args.gpus}: this node has {_lib.device_count()} GPU(s) visible; one rank per GPU is the contract")
+    ndev = _lib.device_count()
+    if world > ndev and args.transport == "rccl":  # every rank sees this and leaves at once: none waits for a peer that cannot exist
+        raise SystemExit(f"--gpus {args.gpus}: this node has {ndev} GPU(s) visible; one rank per GPU is the contract "
+                         "(--transport gloo lets ranks share a GPU for a functional rehearsal)")
 
     dtype = {"f32": np.float32, "f64": np.float64, None: np.float64 if args.config == "hera37" else np.float32}[args.dtype]
     dist = None
@@ -330,11 +335,20 @@ def main():
         truth = None
         tot = torch_sum_int(dist, [prob.nbls // ntimes, prob.ncoeffs // ntimes])
         full_nbls, full_ncoeffs = tot
-        uid = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        s = HipFitSolver(dtype=dtype, device=local_rank)
+        s = HipFitSolver(dtype=dtype, device=local_rank % ndev)
         # communicator first: set_problem then agrees the kernel path and the steps per host synchronisation over the ranks
-        s.comm_init(uid[0], rank, world)
+        if args.transport == "rccl":
+            uid = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            s.comm_init(uid[0], rank, world)
+        else:
+            import torch
+
+            def gloo_all_reduce(arr, op):
+                t = torch.from_numpy(arr)  # the library's staging buffer: reduced in place
+                dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.SUM)
+
+            s.set_exchange_hook(gloo_all_reduce, rank, world)
         s.set_problem(prob, layout=args.layout)
         s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
         solvers.append(s)
@@ -570,7 +584,8 @@ def main():
                             f"(sum nvec = {full_ncoeffs}) per time slice, {ntimes} time slice(s), optimizer {args.optimizer} lr 1e-2, "
                             f"model_regularization {args.reg}",
                 "layout": args.layout,
-                "parallelism": (f"every slice's baselines sharded over {world} GPUs (one process each), one RCCL all-reduce of the gain gradients + loss scalars per step"
+                "transport": args.transport if sharded else None,
+                "parallelism": (f"every slice's baselines sharded over {world} ranks (one process each), one {'RCCL' if args.transport == 'rccl' else 'gloo (exchange hook)'} all-reduce of the gain gradients + loss scalars per step"
                                 + (" [one-rank rehearsal of the multi-rank path]" if world == 1 else "")) if sharded else "single GPU",
             },
             "roofline": roofline,

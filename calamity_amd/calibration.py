@@ -698,7 +698,7 @@ def calibrate_and_model_tensor(
     if init_guesses_from_previous_time_step:
         batch_slices = False  # every time starts from the previous one's result: a chain, not a batch
     if batch_slices:
-        max_batch = _lib_max_slices() if batch_slices is True else max(1, min(int(batch_slices), _lib_max_slices()))
+        max_batch = _auto_batch(prob, dtype) if batch_slices is True else max(1, min(int(batch_slices), _lib_max_slices()))
         fit_history = _fit_slices_batched(
             uvdata=uvdata, sky_model=sky_model, gains=gains, resid=resid, model=model, prob=prob, corr_inds=corr_inds, ants_map=ants_map,
             times=times, weights=weights, nsamples_in_weights=nsamples_in_weights, dtype=dtype, skip_threshold=skip_threshold,
@@ -902,6 +902,30 @@ def _lib_max_slices():
     from . import _lib
 
     return _lib.CAL_MAX_SLICES
+
+
+def _auto_batch(prob, dtype):
+    """How many slices one batch may hold when the caller does not say: what fits a quarter of the host memory now available (five
+    per-sample arrays per slice and their concatenation) and half a device's memory (about eight per-sample arrays per slice), at
+    most the library's CAL_MAX_SLICES.  Tutorial-scale arrays batch hundreds of slices; at HERA-350 (0.25 GB per array and slice)
+    the batches are a few slices -- where a step is bound by arithmetic, not by launches, and batching buys nothing anyway."""
+    from . import _lib
+
+    per_array = float(prob.nbls) * prob.nfreqs * np.dtype(dtype).itemsize
+    host_avail = 8.0e9
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                host_avail = float(line.split()[1]) * 1024.0
+                break
+    except OSError:
+        pass
+    try:
+        dev_total = float(_lib.device_info(_DEVICE["index"] or 0)["total_mem_bytes"])
+    except Exception:  # noqa: BLE001 -- sizing only
+        dev_total = 64.0e9
+    n = min(0.25 * host_avail / (10.0 * per_array), 0.5 * dev_total / (8.0 * per_array))
+    return int(max(1, min(n, _lib_max_slices())))
 
 
 def _default_devices(nsamples_per_step):

@@ -66,3 +66,68 @@ def test_one_rank_rehearsal_under_torchrun_matches_plain_solver(layout, reg):
     s.close()
     assert np.array_equal(losses, ref), (losses, ref)
     assert out["n_ranks_seen"] == 1
+
+
+def test_two_self_launched_ranks_share_the_gpu_over_gloo():
+    """`bench.py --gpus 2` WITHOUT a launcher: it starts its two ranks itself (fresh processes); with `--transport gloo` they share
+    the one GPU of this box and exchange through the library's hook, so the whole N-rank path of the bench runs here: the dealt
+    partition, the per-slice priors summed over ranks, one loop state per slice, the per-step exchange, the max-over-ranks timing,
+    rank 0's line -- `n_ranks_seen` counted by the exchange itself.  The job (2 time slices, each slice's baselines over 2 ranks)
+    is the job of the one-rank rehearsal with 2 slices: same losses to fp32 summation order."""
+    common = ["--max-bls", str(MAX_BLS), "--steps", str(STEPS), "--warmup", str(WARMUP), "--layout", "stream", "--reg", "sum", "--no-cpu-baseline", "--no-shared"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "gloo"] + common, cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + "\n" + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["n_ranks_seen"] == 2 and two["config"]["transport"] == "gloo"
+    # the same job in ONE plain solver: both ranks' shares of every slice put together (slice-major), per-slice priors summed
+    import bench
+    from calamity_amd.problem import FitProblem
+    from calamity_amd.solver import HipFitSolver
+
+    shares = [bench.build_sharded_job("hera350", r, 2, 2, reg=True, max_bls=MAX_BLS, per_slice=True) for r in range(2)]
+    na = shares[0][2]
+    rows, coefs, gb, nb_r, nc_r = [], [], [], [], []
+    for r, (p_r, st_r, _) in enumerate(shares):
+        nb_r.append(p_r.nbls // 2)
+        nc_r.append(p_r.ncoeffs // 2)
+    off = [0, len(shares[0][0].basis)]
+    cat = {k: [] for k in ("grp_basis", "bl_ant0", "bl_ant1", "bl_rowblk", "data_r", "data_i", "wgts", "sky_r", "sky_i")}
+    c_r, c_i = [], []
+    for t in range(2):
+        for r, (p_r, st_r, _) in enumerate(shares):
+            rs, cs = slice(t * nb_r[r], (t + 1) * nb_r[r]), slice(t * nc_r[r], (t + 1) * nc_r[r])
+            cat["grp_basis"].append(p_r.grp_basis[rs] + off[r])
+            for k in ("bl_ant0", "bl_ant1", "bl_rowblk", "data_r", "data_i", "wgts", "sky_r", "sky_i"):
+                cat[k].append(getattr(p_r, k)[rs])
+            c_r.append(st_r["c_r"][cs])
+            c_i.append(st_r["c_i"][cs])
+    cc = {k: np.concatenate(v) for k, v in cat.items()}
+    nbl = len(cc["bl_ant0"])
+    whole = FitProblem(nants=2 * na, nfreqs=shares[0][0].nfreqs, basis=list(shares[0][0].basis) + list(shares[1][0].basis),
+                       grp_basis=cc["grp_basis"].astype(np.int32), grp_bl_start=np.arange(nbl + 1, dtype=np.int32), bl_ant0=cc["bl_ant0"],
+                       bl_ant1=cc["bl_ant1"], bl_rowblk=cc["bl_rowblk"], data_r=cc["data_r"], data_i=cc["data_i"], wgts=cc["wgts"], nslices=2)
+    s = HipFitSolver(dtype=np.float32)
+    s.set_problem(whole, layout="stream")
+    s.set_params(shares[0][1]["g_r"], shares[0][1]["g_i"], np.concatenate(c_r), np.concatenate(c_i))  # (the gains are the same on every rank)
+    half = nbl // 2
+    s.set_regularization("sum", np.asarray([float(np.sum((cc["sky_r"] * cc["wgts"])[t * half : (t + 1) * half])) for t in range(2)]),
+                         np.asarray([float(np.sum((cc["sky_i"] * cc["wgts"])[t * half : (t + 1) * half])) for t in range(2)]))
+    s.set_optimizer("Adam", learning_rate=1e-2)
+    s.run_slices(WARMUP, record=False)
+    b = np.sum([r_[0] for r_ in s.run_slices(STEPS, record=True, tol=0.0)], axis=0)
+    s.close()
+    a = np.asarray(two["extra"]["losses"])
+    assert a.shape == b.shape == (STEPS,) and a[-1] < a[0]
+    np.testing.assert_allclose(a, b, rtol=2e-5)
+    # a node with fewer GPUs than ranks is an error on every rank under the default transport -- never a one-GPU measurement
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    from calamity_amd import _lib
+
+    if _lib.device_count() < 2:
+        assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

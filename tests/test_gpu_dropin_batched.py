@@ -123,3 +123,31 @@ def test_batching_raises_the_step_rate_of_small_fits():
         f.close()
     print(f"slice-steps/s: T=1 {rates[1]:.0f}, T=16 {rates[16]:.0f} ({rates[16] / rates[1]:.1f}x)")
     assert rates[16] >= 7.0 * rates[1], rates  # (measured 8.5-9x; the margin is for box-to-box spread)
+
+
+def test_two_polarizations_batched():
+    """Two polarizations x three times = six slices in one batch (fit_history keyed by polarization, then time), one of them
+    skipped, against the loop."""
+    uvd1, sky1, _ = synthetic.make_uvdata(nants=6, nfreqs=64, ntimes=3, seed=17, redundant=True, flag_frac=0.02)
+    rng = np.random.default_rng(17)
+    d1, f1 = uvcompat.vis3(uvd1.data_array), uvcompat.vis3(uvd1.flag_array)
+    d2 = 0.6 * d1 * np.exp(0.3j) + 1e-3 * np.abs(d1).mean() * (rng.standard_normal(d1.shape) + 1j * rng.standard_normal(d1.shape))
+    data = np.concatenate([d1, d2], axis=2)
+    flags = np.concatenate([f1, rng.random(f1.shape) < 0.03], axis=2)
+    t1 = np.unique(uvd1.time_array)[1]
+    flags[np.isclose(uvd1.time_array, t1, atol=1e-7, rtol=0.0), :, 1] = True  # (yy, time 1): skipped
+    uvd = uvcompat.SimpleUVData(uvd1.antenna_positions, uvd1.get_antpairs(), uvcompat.freqs_1d(uvd1), np.unique(uvd1.time_array),
+                                pols=(-5, -6), data=data[:, None], flags=flags[:, None])
+    kw = dict(min_dly=2.0 / 0.3, offset=2.0 / 0.3, uvdata=uvd, gains=None, sky_model=None, maxsteps=150, tol=1e-9, correct_resid=True,
+              optimizer="Adam", learning_rate=1e-2, dtype=np.float64)
+    loop = calibration.calibrate_and_model_dpss(batch_slices=False, **kw)
+    batched = calibration.calibrate_and_model_dpss(**kw)
+    (m1, r1, g1, h1), (m2, r2, g2, h2) = loop, batched
+    assert sorted(h1) == sorted(h2) == [0, 1] and sorted(h2[0]) == [0, 1, 2] and sorted(h2[1]) == [0, 2]
+    for pol in h1:
+        for ti in h1[pol]:
+            np.testing.assert_allclose(np.asarray(h2[pol][ti]["loss"], dtype=np.float64), np.asarray(h1[pol][ti]["loss"], dtype=np.float64), rtol=1e-10)
+    _same(m2.data_array, m1.data_array, 1e-10)
+    _same(g2.gain_array, g1.gain_array, 1e-10)
+    _same(r2.data_array, r1.data_array, 1e-8)
+    assert np.array_equal(g1.flag_array, g2.flag_array) and np.array_equal(m1.flag_array, m2.flag_array)

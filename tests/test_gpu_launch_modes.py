@@ -135,7 +135,7 @@ OPT_CASES = [
     ("Adagrad", dict(learning_rate=5e-2, initial_accumulator_value=0.0)),
     ("Adadelta", dict(learning_rate=1.0, rho=0.9)),
     ("Nadam", dict(learning_rate=1e-2)),
-    ("Ftrl", dict(learning_rate=5e-2)),
+    ("Ftrl", dict(learning_rate=0.5)),  # (Ftrl sets the parameter from its accumulators: a small rate leaves coefficients of 1e-5, all cancellation in float32)
     ("Ftrl", dict(learning_rate=5e-2, learning_rate_power=-0.3, l1_regularization_strength=1e-4, l2_regularization_strength=1e-3,
                   l2_shrinkage_regularization_strength=1e-3, beta=0.05, initial_accumulator_value=0.2)),
 ]
