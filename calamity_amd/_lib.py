@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcalamity_hip.so")  # the one shipped build; experiment harnesses (tools/) assign this attribute before load()
 
 CAL_F32, CAL_F64 = 0, 1
-CAL_OPT_ADAM, CAL_OPT_ADAMAX, CAL_OPT_SGD, CAL_OPT_RMSPROP, CAL_OPT_ADAGRAD, CAL_OPT_NADAM, CAL_OPT_ADADELTA, CAL_OPT_FTRL = range(8)
+CAL_OPT_ADAM, CAL_OPT_ADAMAX, CAL_OPT_SGD, CAL_OPT_RMSPROP, CAL_OPT_ADAGRAD, CAL_OPT_NADAM, CAL_OPT_ADADELTA, CAL_OPT_FTRL, CAL_OPT_LAMB = range(9)
 CAL_REG_NONE, CAL_REG_SUM = 0, 1
 CAL_LAYOUT_STREAM, CAL_LAYOUT_SHARED = 0, 1
 CAL_PATH_AUTO, CAL_PATH_GENERAL, CAL_PATH_DENSE = 0, 1, 2
@@ -41,6 +41,7 @@ class ProblemDesc(C.Structure):
         ("bl_alias", C.c_void_p),
         ("nslices", C.c_int32),
         ("reserved", C.c_int32),
+        ("grp_var", C.c_void_p),
     ]
 
 
@@ -61,6 +62,7 @@ class OptimizerDesc(C.Structure):
         ("l2_regularization_strength", C.c_double),
         ("l2_shrinkage_regularization_strength", C.c_double),
         ("beta", C.c_double),
+        ("weight_decay_rate", C.c_double),
     ]
 
 

@@ -57,6 +57,7 @@ def replicate_slices(prob, nt, groups=None, share_tiles=True):
         bl_alias=(np.concatenate([np.full(nb, -1, dtype=np.int32)] + [np.arange(nb, dtype=np.int32)] * (nt - 1))
                   if share_tiles and single and nt > 1 else None),
         nslices=nt,
+        chunk_of_grp=None if prob.chunk_of_grp is None else np.tile(np.asarray(prob.chunk_of_grp)[groups], nt).astype(np.int32),
     )
     return sub, bl, cidx
 

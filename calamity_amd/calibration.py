@@ -10,8 +10,9 @@ gradient-descent fitter: ``calibrate_and_model_dpss`` (:1503-1584) -> ``calibrat
   (:140-146, :167); ``fg_comps`` arguments accept either form;
 * ``graph_mode`` / ``graph_args_dict`` are accepted and ignored (there is no tracing compiler on this path);
 * ``n_profile_steps`` writes HIP-event kernel timings as JSON into ``profile_log_dir`` instead of a TF profile;
-* optimizers: "Adamax", "Adam", "SGD", "RMSprop", "Adagrad", "Adadelta", "Nadam", "Ftrl" with the Keras (OptimizerV2) semantics,
-  defaults and constructor arguments; the tensorflow-addons "LAMB" and every other name raise ``KeyError`` like ``OPTIMIZERS[...]`` (:571).
+* optimizers: the whole ``OPTIMIZERS`` table (:17-27) -- "Adamax", "Adam", "SGD", "RMSprop", "Adagrad", "Adadelta", "Nadam", "Ftrl" with
+  the Keras (OptimizerV2) semantics, defaults and constructor arguments, "LAMB" with those of tensorflow-addons; every other name
+  raises ``KeyError`` like ``OPTIMIZERS[...]`` (:571).
 
 There is no CPU fallback: without the HIP library / a GPU these functions raise.
 """

@@ -258,7 +258,11 @@ struct SolverT final : cal_solver {
     return m;
   }
   // settings
-  cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7, 0.9, 0.0, 0.1, 0, 0, -0.5, 0.0, 0.0, 0.0, 0.0};
+  cal_optimizer_desc opt{CAL_OPT_ADAMAX, 1e-3, 0.9, 0.999, 1e-7, 0.9, 0.0, 0.1, 0, 0, -0.5, 0.0, 0.0, 0.0, 0.0, 0.0};
+  // LAMB: the optimizer's variables (g_r, g_i of every slice; the coefficient runs of every (slice, cal_problem_desc::grp_var) per plane)
+  DevBuf lamb_vars, lamb_cvar_ptr, lamb_partial, lamb_ratio;
+  int lamb_nvar = 0, lamb_ncvar = 0;
+  bool lamb_ok = true;
   int reg = CAL_REG_NONE;
   // timing
   bool timing = false;
@@ -497,6 +501,31 @@ struct SolverT final : cal_solver {
     h_slice_coff[0] = 0;
     CAL_TRY(slice_coff.alloc((nslices + 1) * sizeof(int), false));
     HIP_TRY(copy_sync(slice_coff.p, h_slice_coff.data(), (nslices + 1) * sizeof(int), hipMemcpyHostToDevice));
+    {
+      // the optimizer's variables (LAMB): a new coefficient variable wherever the (slice, grp_var) of the groups changes
+      lamb_ok = true;
+      std::vector<int> cptr;
+      for (int g = 0; g < ngrps; ++g) {
+        const int var = d->grp_var ? d->grp_var[g] : 0;
+        // (groups of one variable scattered over a slice: fine for every element-wise optimizer; LAMB is refused in set_optimizer)
+        if (g > 0 && grp_slice[g] == grp_slice[g - 1] && d->grp_var && var < d->grp_var[g - 1]) lamb_ok = false;
+        if (g == 0 || grp_slice[g] != grp_slice[g - 1] || (d->grp_var && var != d->grp_var[g - 1])) cptr.push_back(h_grp_coff[g]);
+      }
+      lamb_ncvar = (int)cptr.size();
+      cptr.push_back(ncoef);
+      lamb_nvar = 2 * nslices + 2 * lamb_ncvar;
+      std::vector<LambVar> vars;
+      for (int t = 0; t < nslices; ++t)
+        for (int c = 0; c < 2; ++c) vars.push_back(LambVar{(long long)t * na_slice * fpad * 2 + c, (long long)na_slice * fpad, 2, 0});
+      for (int plane = 0; plane < 2; ++plane)
+        for (int k = 0; k < lamb_ncvar; ++k) vars.push_back(LambVar{(long long)plane * ncoef + cptr[k], (long long)(cptr[k + 1] - cptr[k]), 1, 1});
+      CAL_TRY(lamb_vars.alloc(vars.size() * sizeof(LambVar), false));
+      HIP_TRY(copy_sync(lamb_vars.p, vars.data(), vars.size() * sizeof(LambVar), hipMemcpyHostToDevice));
+      CAL_TRY(lamb_cvar_ptr.alloc(cptr.size() * sizeof(int), false));
+      HIP_TRY(copy_sync(lamb_cvar_ptr.p, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
+      CAL_TRY(lamb_partial.alloc((size_t)lamb_nvar * kLambSeg * 2 * sizeof(double)));
+      CAL_TRY(lamb_ratio.alloc((size_t)lamb_nvar * sizeof(double)));
+    }
     // ---- baselines that read another baseline's tiles (STREAM layout): the same physical baseline in several time slices
     std::vector<int> alias_root(nbls, -1);  // -1: owns its tiles
     if (d->bl_alias && layout == CAL_LAYOUT_STREAM) {
@@ -1219,8 +1248,11 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipSetDevice(device));
     if (!has_problem) return fail(CAL_ERR_STATE, "set_optimizer before set_problem");
     if (!d) return fail(CAL_ERR_INVALID, "set_optimizer: null");
-    if (d->optimizer < CAL_OPT_ADAM || d->optimizer > CAL_OPT_FTRL)
+    if (d->optimizer < CAL_OPT_ADAM || d->optimizer > CAL_OPT_LAMB)
       return fail(CAL_ERR_INVALID, "set_optimizer: unknown optimizer id %d", d->optimizer);
+    if (d->optimizer == CAL_OPT_LAMB && !lamb_ok)
+      return fail(CAL_ERR_UNSUPPORTED, "set_optimizer: LAMB takes one trust ratio per variable; the groups of a variable (cal_problem_desc::grp_var) must be "
+                  "contiguous inside a time slice");
     opt = *d;
     HIP_TRY(hipMemsetAsync(gains_m.p, 0, gains_m.bytes, stream));
     HIP_TRY(hipMemsetAsync(coef_m.p, 0, coef_m.bytes, stream));
@@ -1555,7 +1587,10 @@ struct SolverT final : cal_solver {
   // tail of a step; with millions of parameters the per-block decision prologue of the fused kernel costs more than the two
   // kernel boundaries it saves (HERA-350: 105 us against 5 + 56 us), so those keep finalize_kernel + adam2_kernel.
   // (CAL_LAUNCH_KERNELS keeps every kernel its own launch: finalize_kernel + adam2_kernel at any size)
-  bool tail_fits_one_launch() const { return 2LL * nants * fpad + 2LL * ncoef <= (1LL << 20) && launch_mode != CAL_LAUNCH_KERNELS; }
+  // (... and LAMB's update is four launches of its own: per-variable norms sit between the moments and the parameters)
+  bool tail_fits_one_launch() const {
+    return 2LL * nants * fpad + 2LL * ncoef <= (1LL << 20) && launch_mode != CAL_LAUNCH_KERNELS && opt.optimizer != CAL_OPT_LAMB;
+  }
   // Problems whose step is tens of microseconds: the whole tail as ONE launch (step_tail_kernel) -- no communicator (the
   // exchange sits between the reduction and the update), general kernels, and not when every kernel is asked to be its own launch
   // (... nor with the regulariser over baselines that share tiles: alpha is needed between that path's two passes)
@@ -1627,6 +1662,20 @@ struct SolverT final : cal_solver {
       hipLaunchKernelGGL((step_update_kernel<T>), dim3(nb), dim3(256), (size_t)nslices * sizeof(SliceStep<T>), stream, ga, ca, ps, st, st_nxt(),
                          scal.as<double>(), losses.as<double>(), losses_cap, smap(mf_ok), fpad, ncoef);
       st_par ^= 1;
+      HIP_TRY(hipGetLastError());
+      return CAL_OK;
+    }
+    if (opt.optimizer == CAL_OPT_LAMB) {
+      // moments + u (in place of the gradients), per-variable norms, trust ratios, parameters.  (With a frozen model the
+      // coefficient variables are not touched: their set is empty and their ratios are never read.)
+      T* ua = comm.as<T>();
+      T* ub = grad_c0();
+      hipLaunchKernelGGL((lamb_moments_kernel<T>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st, smap(mf_ok), fpad, ncoef, ua, ub);
+      hipLaunchKernelGGL((lamb_norm_kernel<T>), dim3((unsigned)(lamb_nvar * kLambSeg)), dim3(256), 0, stream, lamb_vars.as<LambVar>(), gains.as<T>(), ua,
+                         coef.as<T>(), ub, lamb_partial.as<double>());
+      hipLaunchKernelGGL(lamb_ratio_kernel, dim3((lamb_nvar + 63) / 64), dim3(64), 0, stream, lamb_partial.as<double>(), lamb_ratio.as<double>(), lamb_nvar);
+      hipLaunchKernelGGL((lamb_apply_kernel<T>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st, smap(mf_ok), fpad, ncoef, ua, ub,
+                         lamb_ratio.as<double>(), lamb_cvar_ptr.as<int>(), lamb_ncvar);
       HIP_TRY(hipGetLastError());
       return CAL_OK;
     }
@@ -1707,7 +1756,7 @@ struct SolverT final : cal_solver {
       h.nesterov = opt.nesterov;
       h.momentum = opt.momentum;
       h.rho = opt.rho;
-      h.ftrl[0] = opt.learning_rate_power;
+      h.ftrl[0] = opt.optimizer == CAL_OPT_LAMB ? opt.weight_decay_rate : opt.learning_rate_power;
       h.ftrl[1] = opt.l1_regularization_strength;
       h.ftrl[2] = opt.l2_regularization_strength + opt.beta / (2.0 * opt.learning_rate);
       h.ftrl[3] = opt.l2_shrinkage_regularization_strength;
@@ -1933,7 +1982,7 @@ struct SolverT final : cal_solver {
     const DevBuf* all[] = {&tiles, &bl_tile, &bl_ant, &items, &ant_ptr, &ant_ent, &coef_grp, &grp_coff, &grp_item_ptr, &item_goff,
                            &data_r, &data_i, &wgts, &gains, &gains_alt, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
                            &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf,
-                           &mf_ops, &mf_panels, &mf_map, &members, &heads, &slice_coff, &slice_ipart_ptr, &slice_ipart_idx,
+                           &mf_ops, &mf_panels, &mf_map, &members, &heads, &lamb_vars, &lamb_cvar_ptr, &lamb_partial, &lamb_ratio, &slice_coff, &slice_ipart_ptr, &slice_ipart_idx,
                            &slice_ppart_ptr, &slice_ppart_idx, &slice_cblk};
     int64_t n = 0;
     for (auto* d : all) n += (int64_t)d->bytes;

@@ -67,7 +67,7 @@ struct DevState {
   double ftrl[4];            // Ftrl: learning_rate_power, l1, l2 + beta / (2 lr), l2_shrinkage
   double k[6];               // the current step's update coefficients, per optimizer: see optimizer_step
 };
-enum { OPT_ADAM = 0, OPT_ADAMAX = 1, OPT_SGD = 2, OPT_RMSPROP = 3, OPT_ADAGRAD = 4, OPT_NADAM = 5, OPT_ADADELTA = 6, OPT_FTRL = 7 };
+enum { OPT_ADAM = 0, OPT_ADAMAX = 1, OPT_SGD = 2, OPT_RMSPROP = 3, OPT_ADAGRAD = 4, OPT_NADAM = 5, OPT_ADADELTA = 6, OPT_FTRL = 7, OPT_LAMB = 8 };
 
 // Time slices (cal_problem_desc::nslices): one solver may hold several independent fits -- the (polarization, time) slices the
 // reference fits one after another (calibration.py:1160-1167) -- each with its own gains (antennas [t na_slice, (t + 1) na_slice)),
@@ -1454,6 +1454,7 @@ __device__ inline bool advance_state(DevState& s, double l0, double l1, double l
     case OPT_RMSPROP: s.k[1] = s.rho; s.k[2] = s.momentum; break;
     case OPT_ADADELTA: s.k[1] = s.rho; break;
     case OPT_FTRL: s.k[1] = s.ftrl[0]; s.k[2] = s.ftrl[1]; s.k[3] = s.ftrl[2]; s.k[4] = s.ftrl[3]; break;
+    case OPT_LAMB: s.k[1] = 1.0 - s.b1t; s.k[2] = 1.0 - s.b2t; s.k[3] = s.ftrl[0]; break;  // bias corrections, weight decay rate
     case OPT_NADAM: {
       const double mu_t = s.beta1 * (1.0 - 0.5 * pow(0.96, 0.004 * (double)s.t));
       const double mu_t1 = s.beta1 * (1.0 - 0.5 * pow(0.96, 0.004 * (double)(s.t + 1)));
@@ -1663,6 +1664,105 @@ __global__ __launch_bounds__(256) void adam2_kernel(const AdamSet<T> a, const Ad
   const T pi = optimizer_step<T>(S.p[i], S.g[i], mi, vi, c);
   S.m[i] = mi;
   S.v[i] = vi;
+  S.p[i] = pi;
+  if (st->improved) S.snap[i] = pi;
+}
+
+// ---- LAMB (tensorflow_addons.optimizers.LAMB, calibration.py:26): Adam moments, then a trust ratio PER VARIABLE -- the reference's
+// variables are g_r, g_i and one fg_r[chunk], fg_i[chunk] per chunk (calibration.py:596-603) --
+//   m <- b1 m + (1 - b1) g; v <- b2 v + (1 - b2) g^2; u = (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps) + wd p;
+//   ratio = |p| > 0 and |u| > 0 ? |p| / |u| : 1 (2-norms over the variable);  p <- p - lr ratio u.
+// Four launches: moments + u (u overwrites the gradient), per-variable partial norms (LAMB_NSEG segments per variable, fixed
+// order), the ratios, the update.  A variable is a strided run of one of the two parameter arrays.
+struct LambVar { long long off; long long n; int stride; int set; };  // set 0: gains [nants][fpad][2], 1: coefficient planes
+constexpr int kLambSeg = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void lamb_moments_kernel(const AdamSet<T> a, const AdamSet<T> b, int nblk_a, const DevState* st, const SliceMap M,
+                                                           int fpad, int ncoef, T* __restrict__ ua, T* __restrict__ ub) {
+#pragma clang fp contract(off)
+  const bool first = (int)blockIdx.x < nblk_a;
+  const AdamSet<T>& S = first ? a : b;
+  T* u_out = first ? ua : ub;
+  const long long i = (long long)(first ? blockIdx.x : blockIdx.x - nblk_a) * blockDim.x + threadIdx.x;
+  if (i >= S.n) return;
+  if (M.nslices > 1) st += first ? slice_of_gain_real(M, i, fpad) : slice_of_coef_real(M, i, ncoef);
+  if (st->done) return;
+  const StepCoef<T> c = step_coef<T>(*st);
+  const T g = S.g[i];
+  const T mi = c.b1 * S.m[i] + ((T)1 - c.b1) * g;
+  const T vi = c.b2 * S.v[i] + ((T)1 - c.b2) * g * g;
+  S.m[i] = mi;
+  S.v[i] = vi;
+  u_out[i] = (mi / c.k[1]) / (sqrt(vi / c.k[2]) + c.eps) + c.k[3] * S.p[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lamb_norm_kernel(const LambVar* __restrict__ vars, const T* __restrict__ pa, const T* __restrict__ ua,
+                                                        const T* __restrict__ pb, const T* __restrict__ ub, double* __restrict__ partial) {
+  const int v = blockIdx.x / kLambSeg, seg = blockIdx.x - v * kLambSeg;
+  const LambVar V = vars[v];
+  const T* p = V.set ? pb : pa;
+  const T* u = V.set ? ub : ua;
+  const long long per = (V.n + kLambSeg - 1) / kLambSeg;
+  const long long e0 = seg * per, e1 = e0 + per < V.n ? e0 + per : V.n;
+  double sw = 0, su = 0;
+  for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const long long idx = V.off + e * V.stride;
+    const double x = (double)p[idx], y = (double)u[idx];
+    sw += x * x;
+    su += y * y;
+  }
+  __shared__ double sh[8];
+  sw = ldsum(sw);
+  su = ldsum(su);
+  if ((threadIdx.x & 63) == 0) {
+    sh[(threadIdx.x >> 6) * 2 + 0] = sw;
+    sh[(threadIdx.x >> 6) * 2 + 1] = su;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[(size_t)blockIdx.x * 2 + 0] = ((sh[0] + sh[2]) + sh[4]) + sh[6];
+    partial[(size_t)blockIdx.x * 2 + 1] = ((sh[1] + sh[3]) + sh[5]) + sh[7];
+  }
+}
+__global__ void lamb_ratio_kernel(const double* __restrict__ partial, double* __restrict__ ratio, int nvar) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvar) return;
+  double sw = 0, su = 0;
+  for (int s = 0; s < kLambSeg; ++s) {
+    sw += partial[((size_t)v * kLambSeg + s) * 2 + 0];
+    su += partial[((size_t)v * kLambSeg + s) * 2 + 1];
+  }
+  const double wn = sqrt(sw), un = sqrt(su);
+  ratio[v] = wn > 0.0 ? (un > 0.0 ? wn / un : 1.0) : 1.0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lamb_apply_kernel(const AdamSet<T> a, const AdamSet<T> b, int nblk_a, const DevState* st, const SliceMap M,
+                                                         int fpad, int ncoef, const T* __restrict__ ua, const T* __restrict__ ub,
+                                                         const double* __restrict__ ratio, const int* __restrict__ cvar_ptr, int ncvar) {
+#pragma clang fp contract(off)
+  const bool first = (int)blockIdx.x < nblk_a;
+  const AdamSet<T>& S = first ? a : b;
+  const long long i = (long long)(first ? blockIdx.x : blockIdx.x - nblk_a) * blockDim.x + threadIdx.x;
+  if (i >= S.n) return;
+  int var;
+  if (first) {
+    const int sl = slice_of_gain_real(M, i, fpad);
+    if (M.nslices > 1) st += sl;
+    var = 2 * sl + (int)(i & 1);
+  } else {
+    const int plane = i >= ncoef ? 1 : 0;
+    const int n = (int)(i - (long long)plane * ncoef);
+    if (M.nslices > 1) st += slice_of_coef(M, n);
+    int lo = 0, hi = ncvar - 1;  // largest k with cvar_ptr[k] <= n
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (cvar_ptr[mid] <= n) lo = mid; else hi = mid - 1;
+    }
+    var = 2 * M.nslices + plane * ncvar + lo;
+  }
+  if (st->done) return;
+  const T u = first ? ua[i] : ub[i];
+  const T pi = S.p[i] - (T)(st->k[0] * ratio[var]) * u;
   S.p[i] = pi;
   if (st->improved) S.snap[i] = pi;
 }

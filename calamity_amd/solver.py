@@ -6,12 +6,12 @@ import numpy as np
 from . import _lib
 from .problem import FitProblem
 
-# OPTIMIZERS of /root/reference/calamity/calibration.py:17-27 that the HIP fitter implements (the tensorflow-addons "LAMB"
-# is not provided); any other name raises KeyError exactly like ``OPTIMIZERS[optimizer]`` at
+# OPTIMIZERS of /root/reference/calamity/calibration.py:17-27 -- the whole table, "LAMB" being tensorflow_addons.optimizers.LAMB;
+# any other name raises KeyError exactly like ``OPTIMIZERS[optimizer]`` at
 # calibration.py:571.  Constructor arguments and defaults are those of tf.keras.optimizers.* (OptimizerV2, TF 2.4 - 2.10);
 # an argument the optimizer does not take raises TypeError, as the Keras constructor would.
 OPTIMIZERS = {"Adam": _lib.CAL_OPT_ADAM, "Adamax": _lib.CAL_OPT_ADAMAX, "SGD": _lib.CAL_OPT_SGD, "RMSprop": _lib.CAL_OPT_RMSPROP,
-              "Adagrad": _lib.CAL_OPT_ADAGRAD, "Nadam": _lib.CAL_OPT_NADAM, "Adadelta": _lib.CAL_OPT_ADADELTA, "Ftrl": _lib.CAL_OPT_FTRL}
+              "Adagrad": _lib.CAL_OPT_ADAGRAD, "Nadam": _lib.CAL_OPT_NADAM, "Adadelta": _lib.CAL_OPT_ADADELTA, "Ftrl": _lib.CAL_OPT_FTRL, "LAMB": _lib.CAL_OPT_LAMB}
 _MOMENTS = dict(learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
 _OPT_DEFAULTS = {
     "Adam": _MOMENTS,
@@ -23,6 +23,7 @@ _OPT_DEFAULTS = {
     "Adadelta": dict(learning_rate=1e-3, rho=0.95, epsilon=1e-7),
     "Ftrl": dict(learning_rate=1e-3, learning_rate_power=-0.5, initial_accumulator_value=0.1, l1_regularization_strength=0.0,
                  l2_regularization_strength=0.0, l2_shrinkage_regularization_strength=0.0, beta=0.0),
+    "LAMB": dict(learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-6, weight_decay_rate=0.0),
 }
 
 
@@ -81,12 +82,14 @@ class HipFitSolver:
             np.ascontiguousarray(prob.bl_ant1, dtype=np.int32),
             np.ascontiguousarray(prob.bl_rowblk, dtype=np.int32),
             None if getattr(prob, "bl_alias", None) is None else np.ascontiguousarray(prob.bl_alias, dtype=np.int32),
+            # the reference's variables fg_r[chunk] / fg_i[chunk] (a layer-wise optimizer -- LAMB -- takes one trust ratio per variable)
+            None if getattr(prob, "chunk_of_grp", None) is None else np.ascontiguousarray(prob.chunk_of_grp, dtype=np.int32),
         ]
         d = _lib.ProblemDesc(
             nants=prob.nants, nfreqs=prob.nfreqs, ngrps=prob.ngrps, nbls=prob.nbls, nbasis=len(basis),
             basis_offset=_ptr(offs), basis_nvec=_ptr(nvec), basis_nrowblk=_ptr(nrb), basis_data=_ptr(flat),
             grp_basis=_ptr(keep[4]), grp_bl_start=_ptr(keep[5]), bl_ant0=_ptr(keep[6]), bl_ant1=_ptr(keep[7]),
-            bl_rowblk=_ptr(keep[8]), bl_alias=_ptr(keep[9]), nslices=int(getattr(prob, "nslices", 1) or 1),
+            bl_rowblk=_ptr(keep[8]), bl_alias=_ptr(keep[9]), nslices=int(getattr(prob, "nslices", 1) or 1), grp_var=_ptr(keep[10]),
             layout={"stream": _lib.CAL_LAYOUT_STREAM, "shared": _lib.CAL_LAYOUT_SHARED}[layout],
             kernel_path={"auto": _lib.CAL_PATH_AUTO, "general": _lib.CAL_PATH_GENERAL, "dense": _lib.CAL_PATH_DENSE}[kernel_path],
         )
@@ -126,7 +129,7 @@ class HipFitSolver:
                                kw.get("rho", 0.9), kw.get("momentum", 0.0), kw.get("initial_accumulator_value", 0.1),
                                int(bool(kw.get("nesterov", False))), 0, kw.get("learning_rate_power", -0.5),
                                kw.get("l1_regularization_strength", 0.0), kw.get("l2_regularization_strength", 0.0),
-                               kw.get("l2_shrinkage_regularization_strength", 0.0), kw.get("beta", 0.0))
+                               kw.get("l2_shrinkage_regularization_strength", 0.0), kw.get("beta", 0.0), kw.get("weight_decay_rate", 0.0))
         if optimizer == "Ftrl" and (kw["learning_rate_power"] > 0.0 or kw["initial_accumulator_value"] < 0.0):
             raise ValueError("Ftrl: learning_rate_power must be <= 0 and initial_accumulator_value >= 0 (as the Keras constructor checks)")
         _lib.check(self._lib.cal_solver_set_optimizer(self._h, C.byref(d)))

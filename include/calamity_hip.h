@@ -39,9 +39,9 @@ enum cal_status {
 };
 
 enum cal_dtype { CAL_F32 = 0, CAL_F64 = 1 };                 /* dtype kwarg, calibration.py:464, :974 */
-enum cal_optimizer { /* OPTIMIZERS, calibration.py:17-27 (the tensorflow-addons LAMB is not provided) */
+enum cal_optimizer { /* OPTIMIZERS, calibration.py:17-27: the whole table */
   CAL_OPT_ADAM = 0, CAL_OPT_ADAMAX = 1, CAL_OPT_SGD = 2, CAL_OPT_RMSPROP = 3, CAL_OPT_ADAGRAD = 4, CAL_OPT_NADAM = 5, CAL_OPT_ADADELTA = 6,
-  CAL_OPT_FTRL = 7
+  CAL_OPT_FTRL = 7, CAL_OPT_LAMB = 8 /* tensorflow_addons.optimizers.LAMB, :26 */
 };
 enum cal_regularization { CAL_REG_NONE = 0, CAL_REG_SUM = 1 }; /* model_regularization, calibration.py:619-661 */
 enum cal_layout {
@@ -108,6 +108,10 @@ typedef struct cal_problem_desc {
                                     regulariser sums and priors, tolerance stop, use_min snapshot and optimizer iteration count
                                     (cal_solver_run_slices); a stopped slice's parameters freeze while the others go on. */
   int32_t reserved;
+  const int32_t* grp_var;        /* [ngrps] or NULL: which optimizer VARIABLE a group's coefficients belong to -- the chunk of the reference's
+                                    fg_r[chunk] / fg_i[chunk] tensors (calibration.py:596-603).  Only a layer-wise optimizer (LAMB: one trust
+                                    ratio per variable) looks at it; groups of a variable are contiguous inside a time slice.  NULL: the
+                                    coefficients of a slice are one variable per component. */
 } cal_problem_desc;
 #define CAL_MAX_SLICES 256
 
@@ -129,6 +133,7 @@ typedef struct cal_optimizer_desc { /* **opt_kwargs -> tf.optimizers.X(...), cal
   double l2_regularization_strength;           /* 0 */
   double l2_shrinkage_regularization_strength; /* 0 */
   double beta;                                 /* 0 */
+  double weight_decay_rate;                    /* LAMB: 0 (epsilon defaults to 1e-6 there) */
 } cal_optimizer_desc;
 
 typedef struct cal_run_desc { /* loop controls of fit_gains_and_foregrounds, calibration.py:457-461 */
@@ -193,7 +198,7 @@ int cal_solver_get_params(cal_solver* s, int which, void* g_r, void* g_i, void* 
  * set_params + set_moments (after set_optimizer, whose betas the bias corrections are rebuilt from) continues bit for bit.
  * The two slots per parameter, (m, v): Adam / Nadam first and second moment; Adamax (m, u); SGD (momentum accumulator, unused);
  * RMSprop (momentum accumulator, mean square); Adagrad (unused, accumulator); Adadelta (accumulated updates, accumulated gradients);
- * Ftrl (linear, accumulator). */
+ * Ftrl (linear, accumulator); LAMB (first, second moment). */
 int cal_solver_get_moments(cal_solver* s, void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i,
                            void* cv_r, void* cv_i, int64_t* t);
 int cal_solver_set_moments(cal_solver* s, const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i,

@@ -363,8 +363,32 @@ class Ftrl(_SlotOptimizer):
             accum[...] = new_accum
 
 
+class LAMB(_SlotOptimizer):
+    """tensorflow_addons.optimizers.LAMB (calibration.py:26): Adam moments with bias correction, then one trust ratio PER VARIABLE:
+    m = beta_1 m + (1 - beta_1) g; v = beta_2 v + (1 - beta_2) g^2; update = (m / (1 - beta_1^t)) / (sqrt(v / (1 - beta_2^t)) + epsilon)
+    + weight_decay_rate var; ratio = |var| > 0 and |update| > 0 ? |var| / |update| : 1 (2-norms over the variable);
+    var -= ratio learning_rate update."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-6, weight_decay_rate=0.0):
+        super().__init__()
+        self.lr, self.b1, self.b2, self.eps, self.wd = learning_rate, beta_1, beta_2, epsilon, weight_decay_rate
+
+    def apply_gradients(self, grads_and_vars):
+        self.t += 1
+        for n, (g, var) in enumerate(grads_and_vars):
+            m, v = self.slots(n, var)
+            m *= self.b1
+            m += (1.0 - self.b1) * g
+            v *= self.b2
+            v += (1.0 - self.b2) * g * g
+            update = (m / (1.0 - self.b1**self.t)) / (np.sqrt(v / (1.0 - self.b2**self.t)) + self.eps) + self.wd * var
+            wn, un = np.sqrt(np.sum(np.square(var.astype(np.float64)))), np.sqrt(np.sum(np.square(update.astype(np.float64))))
+            ratio = (wn / un if un > 0.0 else 1.0) if wn > 0.0 else 1.0
+            var -= (ratio * self.lr * update).astype(var.dtype)
+
+
 OPTIMIZERS = {"Adam": Adam, "Adamax": Adamax, "SGD": SGD, "RMSprop": RMSprop, "Adagrad": Adagrad, "Adadelta": Adadelta, "Nadam": Nadam,
-              "Ftrl": Ftrl}
+              "Ftrl": Ftrl, "LAMB": LAMB}
 
 
 # --------------------------------------------------------------------------------------------------

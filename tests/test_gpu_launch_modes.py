@@ -138,6 +138,8 @@ OPT_CASES = [
     ("Ftrl", dict(learning_rate=0.5)),  # (Ftrl sets the parameter from its accumulators: a small rate leaves coefficients of 1e-5, all cancellation in float32)
     ("Ftrl", dict(learning_rate=5e-2, learning_rate_power=-0.3, l1_regularization_strength=1e-4, l2_regularization_strength=1e-3,
                   l2_shrinkage_regularization_strength=1e-3, beta=0.05, initial_accumulator_value=0.2)),
+    ("LAMB", dict(learning_rate=1e-2)),
+    ("LAMB", dict(learning_rate=1e-2, weight_decay_rate=1e-2, epsilon=1e-5)),
 ]
 
 
@@ -179,7 +181,7 @@ def test_optimizer_arguments_are_checked_like_keras():
     p, start = make_case(seed=1)
     s = make_solver(p, start, np.float32)
     with pytest.raises(KeyError):
-        s.set_optimizer("LAMB")
+        s.set_optimizer("Lamb")
     with pytest.raises(ValueError):
         s.set_optimizer("Ftrl", learning_rate_power=0.5)  # Keras: learning_rate_power must be <= 0
     with pytest.raises(TypeError):
@@ -187,3 +189,54 @@ def test_optimizer_arguments_are_checked_like_keras():
     with pytest.raises(TypeError):
         s.set_optimizer("Adam", momentum=0.9)
     s.close()
+
+
+def test_lamb_takes_one_trust_ratio_per_variable():
+    """LAMB (tensorflow-addons, calibration.py:26) scales each VARIABLE's step by |var| / |update|: the reference's variables are
+    g_r, g_i and one fg_r[chunk], fg_i[chunk] per chunk (:596-603).  A problem with two chunks (a three-baseline fitting group +
+    single-baseline groups): six variables, against the oracle's LAMB over the reference loop; then three time slices of it in one
+    solver (eighteen variables) against the slices fitted alone."""
+    from calamity_amd import distributed, problem
+    from calamity_amd.solver import HipFitSolver
+    from oracle import ref_numpy as R
+    from test_gpu_parity import oracle_inputs, relnorm
+
+    p, start = make_case(seed=11, with_sky=True, redundant=True)
+    ch, fg_r, fg_i = oracle_inputs(p, start)
+    assert len(ch["fg_comps"]) == 2 and sorted(set(p.chunk_of_grp.tolist())) == [0, 1]
+    kw = dict(learning_rate=2e-2, weight_decay_rate=1e-3)
+    ref = R.fit_gains_and_foregrounds(start["g_r"], start["g_i"], fg_r, fg_i, ch["data_r"], ch["data_i"], ch["wgts"], ch["fg_comps"],
+                                      ch["corr_inds"], maxsteps=20, tol=0.0, optimizer="LAMB", **kw)
+    s = make_solver(p, start, np.float64)
+    s.set_optimizer("LAMB", **kw)
+    s.run(1, record=False)
+    losses, _, _ = s.run(20, record=True, tol=0.0)
+    g_r, g_i, c_r, c_i = s.get_params()
+    s.close()
+    np.testing.assert_allclose(losses, np.asarray(ref[4]["loss"], dtype=np.float64), rtol=1e-8)
+    assert relnorm(g_r + 1j * g_i, ref[0] + 1j * ref[1]) <= 1e-8
+    assert relnorm(c_r, problem.coeffs_from_chunks(p, ref[2])) <= 1e-8 and relnorm(c_i, problem.coeffs_from_chunks(p, ref[3])) <= 1e-8
+
+    parts = []
+    for t in range(3):
+        q, st = make_case(seed=11 + t, redundant=True)
+        problem.chunks_from_problem(q)  # (fills chunk_of_grp: the variables)
+        parts.append((q, st))
+    alone = []
+    for q, st in parts:
+        s = make_solver(q, st, np.float64)
+        s.set_optimizer("LAMB", **kw)
+        alone.append((s.run(12, record=True, tol=0.0)[0], s.get_params()))
+        s.close()
+    big, bstart = distributed.batch_time_slices(parts, per_slice=True)
+    big.chunk_of_grp = np.concatenate([q.chunk_of_grp for q, _ in parts])
+    s = HipFitSolver(dtype=np.float64)
+    s.set_problem(big, layout="stream")
+    s.set_params(bstart["g_r"], bstart["g_i"], bstart["c_r"], bstart["c_i"])
+    s.set_optimizer("LAMB", **kw)
+    res = s.run_slices(12, record=True, tol=0.0)
+    bg_r = s.get_params()[0]
+    s.close()
+    for t, (q, _) in enumerate(parts):
+        np.testing.assert_allclose(res[t][0], alone[t][0], rtol=1e-12)
+        assert relnorm(bg_r[t * q.nants : (t + 1) * q.nants], alone[t][1][0]) <= 1e-12

@@ -227,7 +227,7 @@ def test_errors_are_reported():
     p, start = make_case(seed=1)
     s.set_problem(p)
     with pytest.raises(KeyError):
-        s.set_optimizer("LAMB")
+        s.set_optimizer("NotAnOptimizer")
     bad = synthetic.make_problem(5, 32, seed=0)[0]
     bad.bl_ant1 = bad.bl_ant1.copy()
     bad.bl_ant1[0] = 99

@@ -214,6 +214,21 @@ def test_other_keras_optimizers_known_answers():
     z2 = z1 + g2 + 2 * 0.05 * x1 - (n2**0.4 - n1**0.4) / lr * x1
     np.testing.assert_allclose(b, np.where(np.abs(z2) > 0.3, (np.sign(z2) * 0.3 - z2) / (n2**0.4 / lr + 2 * l2), 0.0), rtol=1e-14)
 
+    # LAMB (tensorflow-addons): Adam's bias-corrected step direction, scaled per variable by |var| / |update| (1 while var = 0)
+    x = np.array([1.0, -2.0])
+    opt = R.OPTIMIZERS["LAMB"](learning_rate=lr)
+    opt.apply_gradients([(g1, x)])
+    u1 = (0.1 * g1 / 0.1) / (np.sqrt(0.001 * g1**2 / 0.001) + 1e-6)
+    r1 = np.linalg.norm([1.0, -2.0]) / np.linalg.norm(u1)
+    x1 = np.array([1.0, -2.0]) - lr * r1 * u1
+    np.testing.assert_allclose(x, x1, rtol=1e-14)
+    opt.apply_gradients([(g2, x)])
+    m2, v2 = 0.9 * 0.1 * g1 + 0.1 * g2, 0.999 * 0.001 * g1**2 + 0.001 * g2**2
+    u2 = (m2 / (1 - 0.81)) / (np.sqrt(v2 / (1 - 0.999**2)) + 1e-6)
+    np.testing.assert_allclose(x, x1 - lr * np.linalg.norm(x1) / np.linalg.norm(u2) * u2, rtol=1e-13)
+    a, b = two_steps("LAMB", learning_rate=lr)  # from var = 0: ratio 1
+    np.testing.assert_allclose(a, -lr * u1, rtol=1e-14)
+
 
 def test_loop_semantics():
     p, ch, g_r, g_i, fg_r, fg_i = _setup(seed=2)
