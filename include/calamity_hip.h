@@ -41,7 +41,8 @@ enum cal_status {
 enum cal_dtype { CAL_F32 = 0, CAL_F64 = 1 };                 /* dtype kwarg, calibration.py:464, :974 */
 enum cal_optimizer { /* OPTIMIZERS, calibration.py:17-27: the whole table */
   CAL_OPT_ADAM = 0, CAL_OPT_ADAMAX = 1, CAL_OPT_SGD = 2, CAL_OPT_RMSPROP = 3, CAL_OPT_ADAGRAD = 4, CAL_OPT_NADAM = 5, CAL_OPT_ADADELTA = 6,
-  CAL_OPT_FTRL = 7, CAL_OPT_LAMB = 8 /* tensorflow_addons.optimizers.LAMB, :26 */
+  CAL_OPT_FTRL = 7, CAL_OPT_LAMB = 8 /* tensorflow_addons.optimizers.LAMB, :26.  One trust ratio per VARIABLE (cal_problem_desc::grp_var);
+                                        its norms are those of the solver's own groups: not for a fit sharded over several ranks */
 };
 enum cal_regularization { CAL_REG_NONE = 0, CAL_REG_SUM = 1 }; /* model_regularization, calibration.py:619-661 */
 enum cal_layout {
