@@ -163,3 +163,90 @@ def test_batched_time_slices_equal_independent_fits():
         np.testing.assert_allclose(joint[0][t * 6 : (t + 1) * 6], sep[0], rtol=1e-12)
         tot += np.asarray(sep[4]["loss"])
     np.testing.assert_allclose(joint[4]["loss"], tot, rtol=1e-12)
+
+
+def test_dealt_partition_balances_every_cost_at_hera350():
+    """The 8 shares of the HERA-350 job (61 075 single-baseline groups, 122 delay classes): dealing the basis-and-size-ordered list
+    gives every rank the same number of baselines and of basis vectors to well under 1 %, and every delay class to within one
+    baseline -- whatever a step costs per group, the shares cost the same (round 3's contiguous cut: 16 009 against 4 310 baselines)."""
+    from calamity_amd import modeling
+
+    antpos = synthetic.hex_positions(350)
+    i, j = np.triu_indices(350, k=1)
+    dly = np.asarray([modeling.dly_ns(L) for L in np.linalg.norm(antpos[i] - antpos[j], axis=1)])
+    classes, grp_basis = np.unique(dly, return_inverse=True)
+    nvec = (np.ceil(2.0 * 1024 * 97656.25 * classes * 1e-9) + 8).astype(int)[grp_basis]  # about the DPSS term count of the delay class
+    parts = D.partition_groups(nvec, grp_basis, np.ones(len(nvec)), 8)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(len(nvec)))
+    nb = np.asarray([len(x) for x in parts])
+    nv = np.asarray([nvec[x].sum() for x in parts], dtype=np.float64)
+    assert nb.max() - nb.min() <= 1 and nv.max() / nv.min() <= 1.005, (nb, nv)
+    for u in range(len(classes)):
+        per = np.asarray([np.count_nonzero(grp_basis[x] == u) for x in parts])
+        assert per.max() - per.min() <= 1
+    old = D.partition_groups(nvec, grp_basis, np.ones(len(nvec)), 8, mode="contiguous")
+    assert max(len(x) for x in old) > 3 * min(len(x) for x in old)  # what the cost-model-free deal replaced
+
+
+def test_host_exchange_between_worker_threads():
+    """The in-process all-reduce of batched.SliceBatchFitter's workers that share a device (the callback handed to
+    cal_solver_set_exchange_hook): every worker ends with the same sum / minimum, computed in rank order; an aborting worker
+    releases the others."""
+    import threading
+
+    from calamity_amd.batched import _HostExchange
+
+    n = 3
+    ex = _HostExchange(n)
+    rng = np.random.default_rng(0)
+    bufs = [rng.standard_normal(1000).astype(np.float32) for _ in range(n)]
+    ints = [np.asarray([r + 2, 7 - r], dtype=np.int32) for r in range(n)]
+    want = bufs[0].copy()
+    for r in range(1, n):
+        want += bufs[r]
+    hooks = [ex.hook(r) for r in range(n)]
+
+    def work(r):
+        for _ in range(5):  # repeated exchanges: the slots are reused
+            a = bufs[r].copy()
+            hooks[r](a, "sum")
+            assert np.array_equal(a, want)
+        b = ints[r].copy()
+        hooks[r](b, "min")
+        assert b.tolist() == [2, 5]
+
+    errs = []
+
+    def guarded(r):
+        try:
+            work(r)
+        except BaseException as e:  # noqa: BLE001 -- an assertion inside a thread must fail the test
+            errs.append(e)
+            ex.abort()
+
+    threads = [threading.Thread(target=guarded, args=(r,), daemon=True) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+        assert not t.is_alive()
+    assert not errs, errs
+    # a worker that dies aborts the exchange: the others get an error instead of waiting for ever
+    ex2 = _HostExchange(2)
+    out = []
+
+    def waiter():
+        try:
+            ex2.hook(0)(np.zeros(4, dtype=np.float32), "sum")
+            out.append("returned")
+        except threading.BrokenBarrierError:
+            out.append("broken")
+
+    t = threading.Thread(target=waiter, daemon=True)
+    t.start()
+    import time as _t
+
+    _t.sleep(0.2)
+    ex2.abort()
+    t.join(timeout=10)
+    assert out == ["broken"]
