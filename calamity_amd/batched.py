@@ -97,7 +97,10 @@ class SliceBatchFitter:
     repeat, the workers then share that GPU and exchange through host memory).  Arrays handed in and out are GLOBAL and
     slice-major: per-sample arrays ``[nt * nbls, nfreqs]``, gains ``[nt * nants, nfreqs]``, coefficients ``[nt * ncoeffs]``."""
 
-    def __init__(self, prob, nt, dtype=np.float32, layout="shared", devices=(0,), kernel_path="auto"):
+    def __init__(self, prob, nt, dtype=np.float32, layout="shared", devices=(0,), kernel_path="auto", communicator_of_one=False):
+        """``communicator_of_one``: with a single device, join a one-rank RCCL communicator anyway (from the worker thread, like the
+        workers of several devices do) so that the exchange path -- the set-up agreement, an all-reduce per step -- runs on a
+        one-GPU box; the numbers are those of the plain fit."""
         self.prob, self.nt, self.dtype = prob, int(nt), np.dtype(dtype)
         self.devices = [int(d) for d in devices]
         D = self.nworkers = len(self.devices)
@@ -116,6 +119,9 @@ class SliceBatchFitter:
             self.cidx.append(np.concatenate([cidx + t * prob.ncoeffs for t in range(self.nt)]))
         self.solvers = [HipFitSolver(dtype=self.dtype, device=d) for d in self.devices]
         self._host_exchange = None
+        if D == 1 and communicator_of_one:
+            uid = comm_unique_id()
+            self._each_threaded(lambda r, s: s.comm_init(uid, 0, 1))
         if D > 1:
             if len(set(self.devices)) == D:
                 uid = comm_unique_id()
@@ -132,6 +138,9 @@ class SliceBatchFitter:
         """fn(rank, solver) on every worker, side by side; the first exception is raised in the caller."""
         if self.nworkers == 1:
             return [fn(0, self.solvers[0])]
+        return self._each_threaded(fn)
+
+    def _each_threaded(self, fn):
         out, errs = [None] * self.nworkers, [None] * self.nworkers
 
         def work(r):

@@ -151,3 +151,33 @@ def test_two_polarizations_batched():
     _same(g2.gain_array, g1.gain_array, 1e-10)
     _same(r2.data_array, r1.data_array, 1e-8)
     assert np.array_equal(g1.flag_array, g2.flag_array) and np.array_equal(m1.flag_array, m2.flag_array)
+
+
+def test_batch_fitter_through_a_one_rank_rccl_communicator():
+    """The batch fitter's exchange path over RCCL on a one-GPU box: a single worker joins a one-rank communicator from its own
+    thread (what the workers of several devices do), so the set-up agreement and an RCCL all-reduce of the gain gradients and the
+    per-slice sums run every step -- same losses and parameters as the plain batched fit, bit for bit."""
+    from calamity_amd.batched import SliceBatchFitter
+
+    p, _, start = synthetic.make_problem(9, 96, f0=150e6, df=400e3, seed=3, with_sky=True)
+    nt = 3
+    outs = []
+    for comm in (False, True):
+        f = SliceBatchFitter(p, nt, dtype=np.float64, layout="shared", devices=[0], communicator_of_one=comm)
+        assert f.solvers[0].comm_size() == 1
+        cat = lambda a: np.concatenate([a * (1.0 + 0.1 * t) for t in range(nt)])  # noqa: E731
+        w = np.concatenate([p.wgts] * nt)
+        f.set_data(cat(p.data_r), cat(p.data_i), w)
+        f.set_params(np.concatenate([start["g_r"]] * nt), np.concatenate([start["g_i"]] * nt), cat(start["c_r"]), cat(start["c_i"]))
+        pr = np.asarray([float(np.sum(p.sky_r * (1.0 + 0.1 * t) * p.wgts)) for t in range(nt)])
+        pi = np.asarray([float(np.sum(p.sky_i * (1.0 + 0.1 * t) * p.wgts)) for t in range(nt)])
+        f.set_regularization("sum", pr, pi)
+        f.set_optimizer("Adamax", learning_rate=1e-2)
+        f.run_slices(1, record=False)
+        res = f.run_slices(30, record=True, tol=0.0, use_min=True)
+        outs.append((res, f.get_params(0), f.get_params(1)))
+        f.close()
+    for t in range(nt):
+        assert np.array_equal(outs[0][0][t][0], outs[1][0][t][0])
+    for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+        assert np.array_equal(a, b)
