@@ -263,6 +263,11 @@ struct SolverT final : cal_solver {
   DevBuf lamb_vars, lamb_cvar_ptr, lamb_partial, lamb_ratio;
   int lamb_nvar = 0, lamb_ncvar = 0;
   bool lamb_ok = true;
+  // ... over several ranks: a coefficient variable (slice t, grp_var w) is spread over the ranks that own its groups -> its two sums of
+  // squares are all-reduced in slot t * lamb_nv + w of lamb_glob (the gain variables are replicated: every rank already holds their norms)
+  DevBuf lamb_glob, lamb_slot;
+  std::vector<int> lamb_cvar_slice, lamb_cvar_id;
+  int lamb_nv = 0;
   int reg = CAL_REG_NONE;
   // timing
   bool timing = false;
@@ -371,9 +376,15 @@ struct SolverT final : cal_solver {
   int set_problem(const cal_problem_desc* d) override {
     const int rc = set_problem_local(d);
     if (!comm_on()) return rc;
+    return agree_problem(rc);
+  }
+  // the agreement: {set-up ok ? dense kernels built : -1, steps per host synchronisation, -(variables per slice), LAMB possible}
+  int agree_problem(int rc) {
     const std::string msg = g_err;
-    int v[2] = {rc == CAL_OK ? (mf_ok ? 1 : 0) : -1, rc == CAL_OK ? steps_per_sync : (1 << 30)};
-    const int arc = agree_min(v, 2);
+    int local_nv = 0;
+    for (int w : lamb_cvar_id) local_nv = std::max(local_nv, w + 1);
+    int v[4] = {rc == CAL_OK ? (mf_ok ? 1 : 0) : -1, rc == CAL_OK ? steps_per_sync : (1 << 30), -local_nv, rc == CAL_OK && lamb_ok ? 1 : 0};
+    const int arc = agree_min(v, 4);
     if (arc != CAL_OK) {
       has_problem = false;
       return arc;
@@ -388,6 +399,15 @@ struct SolverT final : cal_solver {
     }
     if (!v[0]) mf_ok = false;
     steps_per_sync = v[1];
+    lamb_nv = -v[2];
+    if (!v[3]) lamb_ok = false;
+    if (lamb_ok) {
+      std::vector<int> slot(std::max(lamb_ncvar, 1), 0);
+      for (int k = 0; k < lamb_ncvar; ++k) slot[k] = lamb_cvar_slice[k] * lamb_nv + lamb_cvar_id[k];
+      CAL_TRY(lamb_slot.alloc(slot.size() * sizeof(int), false));
+      HIP_TRY(copy_sync(lamb_slot.p, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+      CAL_TRY(lamb_glob.alloc((size_t)std::max(1, 2 * nslices * lamb_nv) * 2 * sizeof(double)));
+    }
     return CAL_OK;
   }
   int set_problem_local(const cal_problem_desc* d) {
@@ -505,11 +525,18 @@ struct SolverT final : cal_solver {
       // the optimizer's variables (LAMB): a new coefficient variable wherever the (slice, grp_var) of the groups changes
       lamb_ok = true;
       std::vector<int> cptr;
+      lamb_cvar_slice.clear();
+      lamb_cvar_id.clear();
       for (int g = 0; g < ngrps; ++g) {
         const int var = d->grp_var ? d->grp_var[g] : 0;
+        if (var < 0) return fail(CAL_ERR_INVALID, "set_problem: grp_var[%d] = %d is negative", g, var);
         // (groups of one variable scattered over a slice: fine for every element-wise optimizer; LAMB is refused in set_optimizer)
         if (g > 0 && grp_slice[g] == grp_slice[g - 1] && d->grp_var && var < d->grp_var[g - 1]) lamb_ok = false;
-        if (g == 0 || grp_slice[g] != grp_slice[g - 1] || (d->grp_var && var != d->grp_var[g - 1])) cptr.push_back(h_grp_coff[g]);
+        if (g == 0 || grp_slice[g] != grp_slice[g - 1] || (d->grp_var && var != d->grp_var[g - 1])) {
+          cptr.push_back(h_grp_coff[g]);
+          lamb_cvar_slice.push_back(grp_slice[g]);
+          lamb_cvar_id.push_back(var);
+        }
       }
       lamb_ncvar = (int)cptr.size();
       cptr.push_back(ncoef);
@@ -1673,13 +1700,28 @@ struct SolverT final : cal_solver {
       hipLaunchKernelGGL((lamb_moments_kernel<T>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st, smap(mf_ok), fpad, ncoef, ua, ub);
       hipLaunchKernelGGL((lamb_norm_kernel<T>), dim3((unsigned)(lamb_nvar * kLambSeg)), dim3(256), 0, stream, lamb_vars.as<LambVar>(), gains.as<T>(), ua,
                          coef.as<T>(), ub, lamb_partial.as<double>());
-      hipLaunchKernelGGL(lamb_ratio_kernel, dim3((lamb_nvar + 63) / 64), dim3(64), 0, stream, lamb_partial.as<double>(), lamb_ratio.as<double>(), lamb_nvar);
+      const double* glob = nullptr;
+      if (comm_on() && !freeze_model) {
+        // a coefficient variable's groups are spread over the ranks: its sums of squares are summed over them (a few doubles per slice)
+        const size_t nglob = (size_t)2 * nslices * lamb_nv * 2;
+        HIP_TRY(hipMemsetAsync(lamb_glob.p, 0, nglob * sizeof(double), stream));
+        hipLaunchKernelGGL(lamb_fold_kernel, dim3((2 * lamb_ncvar + 63) / 64), dim3(64), 0, stream, lamb_partial.as<double>(), lamb_glob.as<double>(),
+                           lamb_slot.as<int>(), 2 * nslices, lamb_ncvar, nslices * lamb_nv);
+        CAL_TRY(all_reduce(lamb_glob.p, nglob, CAL_XCHG_F64, CAL_XCHG_SUM));
+        glob = lamb_glob.as<double>();
+      }
+      hipLaunchKernelGGL(lamb_ratio_kernel, dim3((lamb_nvar + 63) / 64), dim3(64), 0, stream, lamb_partial.as<double>(), lamb_ratio.as<double>(), lamb_nvar,
+                         glob, lamb_slot.as<int>(), 2 * nslices, lamb_ncvar, nslices * lamb_nv);
       hipLaunchKernelGGL((lamb_apply_kernel<T>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st, smap(mf_ok), fpad, ncoef, ua, ub,
                          lamb_ratio.as<double>(), lamb_cvar_ptr.as<int>(), lamb_ncvar);
       HIP_TRY(hipGetLastError());
       return CAL_OK;
     }
-    hipLaunchKernelGGL((adam2_kernel<T>), dim3((unsigned)(nblk_a + nblk_b)), dim3(256), 0, stream, ga, ca, nblk_a, st, smap(mf_ok), fpad, ncoef);
+    {
+      constexpr long long per = 256LL * kAdamVec<T>;  // elements per block
+      const int va = (int)((ga.n + per - 1) / per), vb = (int)((ca.n + per - 1) / per);
+      hipLaunchKernelGGL((adam2_kernel<T>), dim3((unsigned)(va + vb)), dim3(256), 0, stream, ga, ca, va, st, smap(mf_ok), fpad, ncoef);
+    }
     HIP_TRY(hipGetLastError());
     return CAL_OK;
   }
@@ -1982,7 +2024,7 @@ struct SolverT final : cal_solver {
     const DevBuf* all[] = {&tiles, &bl_tile, &bl_ant, &items, &ant_ptr, &ant_ent, &coef_grp, &grp_coff, &grp_item_ptr, &item_goff,
                            &data_r, &data_i, &wgts, &gains, &gains_alt, &gains_m, &gains_v, &gains_snap, &coef, &coef_m, &coef_v, &coef_snap,
                            &q0, &q1, &comm, &scal, &gcp0, &gcp1, &gc0, &gc1, &part, &state, &losses, &scratch, &model_buf,
-                           &mf_ops, &mf_panels, &mf_map, &members, &heads, &lamb_vars, &lamb_cvar_ptr, &lamb_partial, &lamb_ratio, &slice_coff, &slice_ipart_ptr, &slice_ipart_idx,
+                           &mf_ops, &mf_panels, &mf_map, &members, &heads, &lamb_vars, &lamb_cvar_ptr, &lamb_partial, &lamb_ratio, &lamb_glob, &lamb_slot, &slice_coff, &slice_ipart_ptr, &slice_ipart_idx,
                            &slice_ppart_ptr, &slice_ppart_idx, &slice_cblk};
     int64_t n = 0;
     for (auto* d : all) n += (int64_t)d->bytes;
@@ -2041,10 +2083,7 @@ struct SolverT final : cal_solver {
     if (has_problem) {
       // a problem set before the communicator existed: agree now (fpad is rank-independent by construction; a rank
       // that chose the dense path falls back to the general kernel, which runs on the same buffers)
-      int v[2] = {mf_ok ? 1 : 0, steps_per_sync};
-      CAL_TRY(agree_min(v, 2));
-      if (!v[0]) mf_ok = false;
-      steps_per_sync = v[1];
+      CAL_TRY(agree_problem(CAL_OK));
     }
     return CAL_OK;
   }

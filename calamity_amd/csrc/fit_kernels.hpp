@@ -1650,22 +1650,55 @@ struct AdamSet { T* p; const T* g; T* m; T* v; T* snap; long long n; };
 __device__ __forceinline__ int slice_of_gain_real(const SliceMap& M, long long i, int fpad) { return (int)(i / (2LL * fpad)) / M.na_slice; }
 __device__ __forceinline__ int slice_of_coef_real(const SliceMap& M, long long i, int ncoef) { return slice_of_coef(M, (int)(i >= ncoef ? i - ncoef : i)); }
 
+// A thread takes kAdamVec<T> = 16 bytes of consecutive elements of every array (four 16-byte loads, three or four 16-byte stores per
+// thread; one element per thread ran the same update at 4.3 TB/s of the 8).  The arithmetic is per element and unchanged; a thread
+// whose elements straddle two time slices, the end of the set, or arrays that are not 16-byte aligned takes them one by one.
+template <typename T> constexpr int kAdamVec = 16 / (int)sizeof(T);
 template <typename T>
 __global__ __launch_bounds__(256) void adam2_kernel(const AdamSet<T> a, const AdamSet<T> b, int nblk_a, const DevState* st, const SliceMap M,
                                                     int fpad, int ncoef) {
+  constexpr int V = kAdamVec<T>;
+  typedef T vec_t __attribute__((ext_vector_type(V)));
   const bool first = (int)blockIdx.x < nblk_a;
   const AdamSet<T>& S = first ? a : b;
-  const long long i = (long long)(first ? blockIdx.x : blockIdx.x - nblk_a) * blockDim.x + threadIdx.x;
-  if (i >= S.n) return;
-  if (M.nslices > 1) st += first ? slice_of_gain_real(M, i, fpad) : slice_of_coef_real(M, i, ncoef);
-  if (st->done) return;
-  const StepCoef<T> c = step_coef<T>(*st);
-  T mi = S.m[i], vi = S.v[i];
-  const T pi = optimizer_step<T>(S.p[i], S.g[i], mi, vi, c);
-  S.m[i] = mi;
-  S.v[i] = vi;
-  S.p[i] = pi;
-  if (st->improved) S.snap[i] = pi;
+  const long long i0 = ((long long)(first ? blockIdx.x : blockIdx.x - nblk_a) * blockDim.x + threadIdx.x) * V;
+  if (i0 >= S.n) return;
+  const int t0 = M.nslices > 1 ? (first ? slice_of_gain_real(M, i0, fpad) : slice_of_coef_real(M, i0, ncoef)) : 0;
+  bool together = i0 + V <= S.n;
+  if (together && M.nslices > 1) together = t0 == (first ? slice_of_gain_real(M, i0 + V - 1, fpad) : slice_of_coef_real(M, i0 + V - 1, ncoef));
+  const unsigned long long align = (unsigned long long)S.p | (unsigned long long)S.g | (unsigned long long)S.m | (unsigned long long)S.v | (unsigned long long)S.snap;
+  if (together && (align & 15) == 0) {
+    const DevState* s = st + t0;
+    if (s->done) return;
+    const StepCoef<T> c = step_coef<T>(*s);
+    vec_t p = *reinterpret_cast<const vec_t*>(S.p + i0);
+    const vec_t g = *reinterpret_cast<const vec_t*>(S.g + i0);
+    vec_t m = *reinterpret_cast<const vec_t*>(S.m + i0), v = *reinterpret_cast<const vec_t*>(S.v + i0);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      T mi = m[e], vi = v[e];
+      p[e] = optimizer_step<T>(p[e], g[e], mi, vi, c);
+      m[e] = mi;
+      v[e] = vi;
+    }
+    *reinterpret_cast<vec_t*>(S.m + i0) = m;
+    *reinterpret_cast<vec_t*>(S.v + i0) = v;
+    *reinterpret_cast<vec_t*>(S.p + i0) = p;
+    if (s->improved) *reinterpret_cast<vec_t*>(S.snap + i0) = p;
+    return;
+  }
+  for (long long i = i0; i < i0 + V && i < S.n; ++i) {
+    const DevState* s = st;
+    if (M.nslices > 1) s += first ? slice_of_gain_real(M, i, fpad) : slice_of_coef_real(M, i, ncoef);
+    if (s->done) continue;
+    const StepCoef<T> c = step_coef<T>(*s);
+    T mi = S.m[i], vi = S.v[i];
+    const T pi = optimizer_step<T>(S.p[i], S.g[i], mi, vi, c);
+    S.m[i] = mi;
+    S.v[i] = vi;
+    S.p[i] = pi;
+    if (s->improved) S.snap[i] = pi;
+  }
 }
 
 // ---- LAMB (tensorflow_addons.optimizers.LAMB, calibration.py:26): Adam moments, then a trust ratio PER VARIABLE -- the reference's
@@ -1724,13 +1757,36 @@ __global__ __launch_bounds__(256) void lamb_norm_kernel(const LambVar* __restric
     partial[(size_t)blockIdx.x * 2 + 1] = ((sh[1] + sh[3]) + sh[5]) + sh[7];
   }
 }
-__global__ void lamb_ratio_kernel(const double* __restrict__ partial, double* __restrict__ ratio, int nvar) {
+// (several ranks: the coefficient variables' sums go through `glob`, all-reduced between lamb_fold_kernel and lamb_ratio_kernel: local
+// variable k of plane p -> glob[p * nslot + slot[k]]; the gain variables [0, ngvar) are replicated and keep their local sums)
+__global__ void lamb_fold_kernel(const double* __restrict__ partial, double* __restrict__ glob, const int* __restrict__ slot, int ngvar, int ncvar,
+                                 int nslot) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // (plane, local coefficient variable)
+  if (c >= 2 * ncvar) return;
+  const int plane = c / ncvar, k = c - plane * ncvar;
+  const size_t v = (size_t)ngvar + c;
+  double sw = 0, su = 0;
+  for (int s = 0; s < kLambSeg; ++s) {
+    sw += partial[(v * kLambSeg + s) * 2 + 0];
+    su += partial[(v * kLambSeg + s) * 2 + 1];
+  }
+  glob[((size_t)plane * nslot + slot[k]) * 2 + 0] = sw;
+  glob[((size_t)plane * nslot + slot[k]) * 2 + 1] = su;
+}
+__global__ void lamb_ratio_kernel(const double* __restrict__ partial, double* __restrict__ ratio, int nvar, const double* __restrict__ glob,
+                                  const int* __restrict__ slot, int ngvar, int ncvar, int nslot) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvar) return;
   double sw = 0, su = 0;
-  for (int s = 0; s < kLambSeg; ++s) {
-    sw += partial[((size_t)v * kLambSeg + s) * 2 + 0];
-    su += partial[((size_t)v * kLambSeg + s) * 2 + 1];
+  if (glob && v >= ngvar) {
+    const int plane = (v - ngvar) / ncvar, k = (v - ngvar) - plane * ncvar;
+    sw = glob[((size_t)plane * nslot + slot[k]) * 2 + 0];
+    su = glob[((size_t)plane * nslot + slot[k]) * 2 + 1];
+  } else {
+    for (int s = 0; s < kLambSeg; ++s) {
+      sw += partial[((size_t)v * kLambSeg + s) * 2 + 0];
+      su += partial[((size_t)v * kLambSeg + s) * 2 + 1];
+    }
   }
   const double wn = sqrt(sw), un = sqrt(su);
   ratio[v] = wn > 0.0 ? (un > 0.0 ? wn / un : 1.0) : 1.0;

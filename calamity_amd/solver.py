@@ -46,7 +46,6 @@ class HipFitSolver:
         self._h = C.c_void_p()
         _lib.check(self._lib.cal_solver_create(C.byref(self._h), int(device), code))
         self.problem = None
-        self._nranks = 1
 
     def close(self):
         if getattr(self, "_h", None):
@@ -121,10 +120,6 @@ class HipFitSolver:
 
     def set_optimizer(self, optimizer="Adamax", **opt_kwargs):
         opt_id = OPTIMIZERS[optimizer]  # KeyError for anything else, like calibration.py:571
-        if optimizer == "LAMB" and self._nranks > 1:
-            # a variable's coefficients are spread over the ranks and the library does not exchange LAMB's per-variable norms
-            raise NotImplementedError("LAMB takes one trust ratio per variable; with the fitting groups shared out over several ranks "
-                                      "its norms would have to be exchanged: fit with one device, or another optimizer")
         defaults = _OPT_DEFAULTS[optimizer]
         unknown = set(opt_kwargs) - set(defaults)
         if unknown:
@@ -247,7 +242,6 @@ class HipFitSolver:
         "sum" or "min".  ``None`` detaches.  (cal_solver_set_exchange_hook)"""
         if all_reduce is None:
             self._hook = None
-            self._nranks = 1
             _lib.check(self._lib.cal_solver_set_exchange_hook(self._h, None, None, 0, 1))
             return
         dtypes = {_lib.CAL_XCHG_F32: np.float32, _lib.CAL_XCHG_F64: np.float64, _lib.CAL_XCHG_I32: np.int32}
@@ -266,7 +260,6 @@ class HipFitSolver:
 
         self._hook = _lib.EXCHANGE_FN(trampoline)  # keep the callback alive as long as the solver uses it
         _lib.check(self._lib.cal_solver_set_exchange_hook(self._h, C.cast(self._hook, C.c_void_p), None, int(rank), int(nranks)))
-        self._nranks = int(nranks)
 
     def comm_size(self):
         """Ranks that take part in the exchange, counted by an all-reduce of ones over it (cal_solver_comm_size)."""
@@ -277,7 +270,6 @@ class HipFitSolver:
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(bytes(unique_id), _lib.CAL_COMM_ID_BYTES)
         _lib.check(self._lib.cal_solver_comm_init(self._h, buf, int(rank), int(nranks)))
-        self._nranks = int(nranks)
 
 
 def comm_unique_id() -> bytes:

@@ -181,3 +181,34 @@ def test_batch_fitter_through_a_one_rank_rccl_communicator():
         assert np.array_equal(outs[0][0][t][0], outs[1][0][t][0])
     for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("nworkers", [2, 3])
+def test_lamb_over_several_workers(nworkers):
+    """LAMB takes one trust ratio per VARIABLE (g_r, g_i, fg_r[chunk], fg_i[chunk]: calibration.py:596-603, :26).  With the fitting
+    groups of a chunk shared out over several workers the two sums of squares of every (slice, chunk) are exchanged each step
+    (a second, small all-reduce): same losses, gains and coefficients as ONE worker holding everything.  Three chunks, two time
+    slices, workers sharing the one GPU (exchange through host memory)."""
+    from calamity_amd.batched import SliceBatchFitter
+
+    p, _, start = synthetic.make_problem(9, 96, f0=150e6, df=400e3, seed=5, with_sky=True)
+    p.chunk_of_grp = (np.arange(p.ngrps) // 12).astype(np.int32)
+    assert p.chunk_of_grp.max() == 2
+    nt = 2
+    cat = lambda a: np.concatenate([a * (1.0 + 0.2 * t) for t in range(nt)])  # noqa: E731
+    outs = []
+    for devices in ([0], [0] * nworkers):
+        f = SliceBatchFitter(p, nt, dtype=np.float64, layout="stream", devices=devices)
+        f.set_data(cat(p.data_r), cat(p.data_i), np.concatenate([p.wgts] * nt))
+        f.set_params(np.concatenate([start["g_r"]] * nt), np.concatenate([start["g_i"]] * nt), cat(start["c_r"]), cat(start["c_i"]))
+        f.set_regularization(None)
+        f.set_optimizer("LAMB", learning_rate=2e-2, weight_decay_rate=1e-3)
+        f.run_slices(1, record=False)
+        res = f.run_slices(25, record=True, tol=0.0)
+        outs.append((res, f.get_params()))
+        f.close()
+    for t in range(nt):
+        np.testing.assert_allclose(outs[1][0][t][0], outs[0][0][t][0], rtol=1e-9)
+        assert outs[0][0][t][0][-1] < 0.9 * outs[0][0][t][0][0]  # (it does descend)
+    for a, b in zip(outs[1][1], outs[0][1]):
+        assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b)

@@ -94,13 +94,13 @@ def test_two_ranks_on_one_gpu_equal_the_single_solver_fit(case, tmp_path):
     np.testing.assert_array_equal(ranks[0]["g_r"], ranks[1]["g_r"])
     np.testing.assert_array_equal(ranks[0]["g_i"], ranks[1]["g_i"])
     np.testing.assert_array_equal(ranks[0]["losses"], ranks[1]["losses"])
-    # what was exchanged: the set-up agreement (2 ints, min), then per step the gain-gradient parts and 4 double scalars
+    # what was exchanged: the set-up agreement (4 ints, min), then per step the gain-gradient parts and 4 double scalars
     from calamity_amd import distributed as D
 
     reg = case.endswith("_sum")
     spec = D.exchange_spec(p.nants, 128, reg_sum=reg and want_path == "general")
     sizes, ops = ranks[0]["call_sizes"], [str(o) for o in ranks[0]["call_ops"]]
-    assert sizes[0] == 2 and ops[0] == "min" and all(o == "sum" for o in ops[1:])
+    assert sizes[0] == 4 and ops[0] == "min" and all(o == "sum" for o in ops[1:])
     per_step = [spec["gain_grad_reals"], 4] if not (reg and want_path == "dense") else [4, spec["gain_grad_reals"], 4]
     body = list(sizes[1:])
     assert len(body) % len(per_step) == 0 and body == per_step * (len(body) // len(per_step)), (case, body[:8])
