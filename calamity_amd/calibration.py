@@ -369,6 +369,24 @@ def _flatten(chunks, prob):
 _DEVICE = {"index": None, "memory_limit_gib": None}
 
 
+def _wake_device(devices=None):
+    """Start the HIP runtime on the devices a fit is going to use, on a thread of its own: the first HIP call of a process costs
+    0.2 s (runtime start-up, device properties), and the entry points have half a second of host work -- the modeling components
+    -- in front of their first solver.  Nothing depends on the thread: the fit creates its solvers as ever (and fails there,
+    loudly, when there is no usable device)."""
+    from . import _lib
+
+    def wake():
+        try:
+            for d in devices or [_DEVICE["index"] or 0]:
+                _lib.device_info(int(d))
+                HipFitSolver(dtype=np.float32, device=int(d)).close()  # (a stream on the device: its queues exist afterwards)
+        except Exception:  # noqa: BLE001 -- reported by the solver that needs the device
+            pass
+
+    threading.Thread(target=wake, daemon=True).start()
+
+
 def get_solver(fg_model_comps, dtype=np.float32, layout=None, device=None):
     """The HipFitSolver that holds these components on the GPU (created once per component set and dtype)."""
     dtype = np.dtype(dtype)
@@ -1134,6 +1152,7 @@ def calibrate_and_model_dpss(
 ):
     """Simultaneously solve for gains and model foregrounds with per-baseline DPSS vectors -- the kept entry point,
     calibration.py:1503-1584.  ``fg_model_comps_dict`` is accepted and ignored, as in the reference (:1564)."""
+    _wake_device(fitting_kwargs.get("devices"))
     dpss_model_comps_dict = modeling.yield_pbl_dpss_model_comps(
         uvdata, horizon=horizon, min_dly=min_dly, offset=offset, include_autos=include_autos, red_tol=red_tol,
         notebook_progressbar=notebook_progressbar, verbose=verbose,
@@ -1178,6 +1197,7 @@ def calibrate_and_model_mixed(
         angle_match_tol=angle_match_tol,
     )
     if model_comps_dict is None:
+        _wake_device(fitting_kwargs.get("devices"))
         freqs = uvdata.freq_array[0] if np.ndim(uvdata.freq_array) == 2 else uvdata.freq_array
         model_comps_dict = modeling.yield_mixed_comps(
             fitting_grps, blvecs, freqs, eigenval_cutoff=eigenval_cutoff, ant_dly=ant_dly, horizon=horizon, offset=offset,
