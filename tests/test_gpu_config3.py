@@ -118,3 +118,39 @@ def test_every_share_of_the_eight_gpu_job_against_the_c_oracle():
         assert abs(each[3] - l3) <= 2e-5 * abs(l3), (r, each[3], l3)
         del c, prob, start, single, one
     assert max(nbl) - min(nbl) <= 0.01 * min(nbl) and max(nvec) - min(nvec) <= 0.01 * min(nvec), (nbl, nvec)
+
+
+@pytest.mark.parametrize("world,rank", [(2, 1), (4, 2)])
+def test_a_share_of_the_two_and_four_gpu_jobs_against_the_c_oracle(world, rank):
+    """The driver's scaling run also starts `bench.py --gpus 2` and `--gpus 4`: N time slices x a dealt 1 / N of every slice's
+    baselines per rank (2 and 4 right-hand-side sets per shared tile instead of 8).  One rank's share of each, on a bounded sample
+    of the baselines, against the C restatement: loss, every slice's own loss, all gradients, a short Adam trajectory."""
+    import bench
+    from calamity_amd.solver import HipFitSolver
+    from oracle.ref_c import CRef
+
+    prob, start, na = bench.build_sharded_job("hera350", rank, world, world, per_slice=True, max_bls=8000)
+    assert prob.nslices == world and prob.bl_alias is not None
+    rng = np.random.default_rng(7 + world)
+    start["g_r"] = 1.0 + 0.05 * rng.standard_normal(start["g_r"].shape)
+    start["g_i"] = 0.05 * rng.standard_normal(start["g_i"].shape)
+    s = HipFitSolver(dtype=np.float32)
+    s.set_problem(prob, layout="stream")
+    s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    loss, g_r, g_i, c_r, c_i = s.eval_grads()
+    each = s.slice_losses()
+    s.set_optimizer("Adam", learning_rate=1e-2)
+    res = s.run_slices(5, record=True, tol=0.0)
+    fg_r, fg_i, fc_r, fc_i = s.get_params()
+    s.close()
+    single = D.FitProblem(**{k: getattr(prob, k) for k in ("nants", "nfreqs", "basis", "grp_basis", "grp_bl_start", "bl_ant0", "bl_ant1", "bl_rowblk",
+                                                            "data_r", "data_i", "wgts")})
+    c = CRef(single, np.float64, nthreads=16)
+    l, og_r, og_i, oc_r, oc_i = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    assert abs(loss - l) <= 2e-5 * abs(l) and abs(each.sum() - loss) <= 1e-12 * abs(loss)
+    for a, b in ((g_r, og_r), (g_i, og_i), (c_r, oc_r), (c_i, oc_i)):
+        assert relnorm(a, b) <= 2e-4
+    tg_r, tg_i, tc_r, tc_i, tl, _ = c.fit(start["g_r"], start["g_i"], start["c_r"], start["c_i"], 5, optimizer="Adam", learning_rate=1e-2)
+    assert np.allclose(np.sum([r[0] for r in res], axis=0), tl, rtol=1e-4)
+    for a, b in ((fg_r, tg_r), (fg_i, tg_i), (fc_r, tc_r), (fc_i, tc_i)):
+        assert relnorm(a, b) <= 1e-3
