@@ -118,6 +118,8 @@ SYMBOLS = {
     "cal_solver_run": (C.c_int, [_P, C.POINTER(RunDesc), _P, C.POINTER(RunResult)]),
     "cal_solver_run_slices": (C.c_int, [_P, C.POINTER(RunDesc), _P, C.POINTER(RunResult)]),
     "cal_solver_model": (C.c_int, [_P, _P, _P]),
+    "cal_solver_data_model": (C.c_int, [_P, _P, _P]),
+    "cal_weighted_square_error": (C.c_int, [C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(C.c_double)]),
     "cal_solver_init_coeffs": (C.c_int, [_P, _P, _P]),
     "cal_solver_synchronize": (C.c_int, [_P]),
     "cal_solver_set_launch_mode": (C.c_int, [_P, C.c_int]),

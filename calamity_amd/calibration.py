@@ -484,6 +484,113 @@ def yield_fg_model_array(nants, nfreqs, fg_model_comps, fg_coeffs, corr_inds, dt
 # ------------------------------------------------------------------------------------------------------------------
 # the fit loop: calibration.py:447-738
 # ------------------------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's graph functions under their own names and signatures (calibration.py:1587-1656), on NumPy arrays in the
+# reference's zero-padded chunk layout -- fg_comps[chunk]: (nvecs, ngrps, nbls, nfreqs); fg_r / fg_i[chunk]: (nvecs, ngrps, 1, 1);
+# data / weights[chunk]: (ngrps, nbls, nfreqs); ant0_inds / ant1_inds[chunk]: (ngrps, nbls).  Every one of them is evaluated by the
+# HIP library (the fused kernels of the fit in their loss-only / model form); the fit itself never calls them -- it runs forward,
+# adjoints and update without materialising a model.
+_GRAPH_SOLVERS = []  # [(key, arrays kept alive, FitProblem)]: the last few chunk sets seen, so that repeated calls reuse the uploaded basis
+
+
+def _graph_problem(fg_comps, ant0_inds, ant1_inds, nants):
+    key = (tuple(id(c) for c in fg_comps), tuple(id(a) for a in ant0_inds), tuple(id(a) for a in ant1_inds), int(nants))
+    for k, _, prob in _GRAPH_SOLVERS:
+        if k == key:
+            return prob
+    corr_inds = [[[(int(i), int(j)) for i, j in zip(r0, r1)] for r0, r1 in zip(np.asarray(a0), np.asarray(a1))] for a0, a1 in zip(ant0_inds, ant1_inds)]
+    prob = _as_problem(list(fg_comps), corr_inds, int(nants))
+    _GRAPH_SOLVERS.append((key, (list(fg_comps), list(ant0_inds), list(ant1_inds)), prob))
+    while len(_GRAPH_SOLVERS) > 4:
+        _, _, old = _GRAPH_SOLVERS.pop(0)
+        for sv in old.__dict__.get("_solvers", {}).values():
+            sv.close()
+    return prob
+
+
+def _graph_dtype(*arrays):
+    return np.dtype(np.float64) if any(np.asarray(a).dtype == np.float64 for a in arrays) else np.dtype(np.float32)
+
+
+def fg_model(fg_r, fg_i, fg_comps):
+    """Foreground model of ONE chunk, ``v = sum_vec fg * fg_comps`` separately for re and im (calibration.py:1587-1590):
+    ``(vr, vi)``, each ``(ngrps, nbls, nfreqs)``."""
+    fg_comps = np.asarray(fg_comps)
+    _, ngrps, nbls, nfreqs = fg_comps.shape
+    zeros = np.zeros((ngrps, nbls), dtype=np.int64)
+    prob = _graph_problem([fg_comps], [zeros], [zeros], 1)
+    solver = get_solver(prob, _graph_dtype(fg_comps, fg_r))
+    solver.set_params(None, None, coeffs_from_chunks(prob, [np.asarray(fg_r)]), coeffs_from_chunks(prob, [np.asarray(fg_i)]))
+    vr, vi = solver.model()
+    return vr.reshape(ngrps, nbls, nfreqs), vi.reshape(ngrps, nbls, nfreqs)
+
+
+def data_model(g_r, g_i, fg_r, fg_i, fg_comps, ant0_inds, ant1_inds):
+    """Model visibilities of ONE chunk: the foreground model times ``g_ant0 conj(g_ant1)`` (calibration.py:1593-1605):
+    ``(model_r, model_i)``, each ``(ngrps, nbls, nfreqs)``."""
+    fg_comps, g_r, g_i = np.asarray(fg_comps), np.asarray(g_r), np.asarray(g_i)
+    _, ngrps, nbls, nfreqs = fg_comps.shape
+    prob = _graph_problem([fg_comps], [ant0_inds], [ant1_inds], g_r.shape[0])
+    solver = get_solver(prob, _graph_dtype(fg_comps, g_r))
+    solver.set_params(g_r, g_i, coeffs_from_chunks(prob, [np.asarray(fg_r)]), coeffs_from_chunks(prob, [np.asarray(fg_i)]))
+    m_r, m_i = solver.data_model()
+    return m_r.reshape(ngrps, nbls, nfreqs), m_i.reshape(ngrps, nbls, nfreqs)
+
+
+def mse(model_r, model_i, data_r, data_i, wgts):
+    """``sum(w ((d_r - m_r)^2 + (d_i - m_i)^2))`` (calibration.py:1608-1609) -- cal_weighted_square_error on the device."""
+    import ctypes as C
+
+    from . import _lib
+
+    dtype = _graph_dtype(model_r, data_r, wgts)
+    arrs = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=dtype), np.shape(data_r))).ravel() for a in (model_r, model_i, data_r, data_i, wgts)]
+    out = C.c_double(0.0)
+    device = _DEVICE["index"] if _DEVICE["index"] is not None else 0
+    _lib.check(_lib.load().cal_weighted_square_error(int(device), _lib.CAL_F64 if dtype == np.float64 else _lib.CAL_F32, arrs[0].size,
+                                                     *[a.ctypes.data_as(C.c_void_p) for a in arrs], C.byref(out)))
+    return dtype.type(out.value)
+
+
+def _graph_loss(g_r, g_i, fg_r, fg_i, fg_comps, nchunks, data_r, data_i, wgts, ant0_inds, ant1_inds, dtype, priors=None):
+    g_r = np.asarray(g_r)
+    dtype = np.dtype(dtype)
+    prob = _graph_problem(list(fg_comps)[:nchunks], list(ant0_inds)[:nchunks], list(ant1_inds)[:nchunks], g_r.shape[0])
+    solver = get_solver(prob, dtype)
+    solver.set_data(_flatten(list(data_r)[:nchunks], prob), _flatten(list(data_i)[:nchunks], prob), _flatten(list(wgts)[:nchunks], prob))
+    solver.set_params(g_r, np.asarray(g_i), coeffs_from_chunks(prob, list(fg_r)[:nchunks]), coeffs_from_chunks(prob, list(fg_i)[:nchunks]))
+    if priors is None:
+        solver.set_regularization(None)
+    else:
+        solver.set_regularization("sum", float(priors[0]), float(priors[1]))
+    return dtype.type(solver.eval_loss())
+
+
+def mse_chunked(g_r, g_i, fg_r, fg_i, fg_comps, nchunks, data_r, data_i, wgts, ant0_inds, ant1_inds, dtype=np.float32):
+    """The loss of the fit: ``sum_chunks mse(data_model(...))`` (calibration.py:1612-1620) -- one loss-only pass of the fused kernel."""
+    return _graph_loss(g_r, g_i, fg_r, fg_i, fg_comps, nchunks, data_r, data_i, wgts, ant0_inds, ant1_inds, dtype)
+
+
+def mse_chunked_sum_regularized(
+    g_r,
+    g_i,
+    fg_r,
+    fg_i,
+    fg_comps,
+    nchunks,
+    data_r,
+    data_i,
+    wgts,
+    ant0_inds,
+    ant1_inds,
+    prior_r_sum,
+    prior_i_sum,
+    dtype=np.float32,
+):
+    """``mse_chunked + (sum w m_r - prior_r_sum)^2 + (sum w m_i - prior_i_sum)^2`` (calibration.py:1623-1656)."""
+    return _graph_loss(g_r, g_i, fg_r, fg_i, fg_comps, nchunks, data_r, data_i, wgts, ant0_inds, ant1_inds, dtype, priors=(prior_r_sum, prior_i_sum))
+
+
 def fit_gains_and_foregrounds(
     g_r,
     g_i,

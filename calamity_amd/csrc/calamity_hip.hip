@@ -161,7 +161,7 @@ struct cal_solver {
                           const void* cm_i, const void* cv_r, const void* cv_i, int64_t t) = 0;
   virtual int eval(bool grads, double* loss, void* gg_r, void* gg_i, void* gc_r, void* gc_i) = 0;
   virtual int run(const cal_run_desc* r, double* losses_out, cal_run_result* res, bool per_slice) = 0;
-  virtual int model(void* mr, void* mi) = 0;
+  virtual int model(void* mr, void* mi, bool with_gains) = 0;
   virtual int init_coeffs(const void* sr, const void* si) = 0;
   virtual int synchronize() = 0;
   virtual int timing_enable(int e) = 0;
@@ -1942,9 +1942,10 @@ struct SolverT final : cal_solver {
     return CAL_OK;
   }
 
-  int model(void* mr, void* mi) override {
+  int model(void* mr, void* mi, bool with_gains) override {
     HIP_TRY(hipSetDevice(device));
     if (!has_problem || !has_coef) return fail(CAL_ERR_STATE, "model: problem and coefficients must be set");
+    if (with_gains && !has_gains) return fail(CAL_ERR_STATE, "data_model: the gains must be set");
     if (!mr || !mi) return fail(CAL_ERR_INVALID, "model: null output");
     const size_t rowbytes = (size_t)nbls * fpad * sizeof(T);
     if (model_buf.bytes < 2 * rowbytes) CAL_TRY(model_buf.alloc(2 * rowbytes));
@@ -1954,6 +1955,9 @@ struct SolverT final : cal_solver {
     a.model_r = model_buf.as<T>();
     a.model_i = model_buf.as<T>() + (size_t)nbls * fpad;
     launch_fused<MODE_MODEL>(a, false);
+    if (with_gains)
+      hipLaunchKernelGGL(apply_gains_kernel<T>, dim3(grid_for((long long)nbls * fpad)), dim3(256), 0, stream, a.model_r, a.model_i, gains.as<T2>(),
+                         bl_ant.as<int2>(), (long long)nbls, fpad);
     HIP_TRY(hipGetLastError());
     CAL_TRY(download_rows(mr, a.model_r, nbls, 1, 0));
     CAL_TRY(download_rows(mi, a.model_i, nbls, 1, 0));
@@ -2089,6 +2093,36 @@ struct SolverT final : cal_solver {
   }
 };
 
+namespace {
+template <typename T>
+int weighted_square_error(int64_t n, const void* const src[5], double* out) {
+  hipStream_t st;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  T* dev = nullptr;
+  double* part = nullptr;
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048));
+  int rc = CAL_OK;
+  auto step = [&](hipError_t e, const char* what) {
+    if (rc == CAL_OK && e != hipSuccess) rc = fail(CAL_ERR_HIP, "cal_weighted_square_error: %s failed: %s", what, hipGetErrorString(e));
+  };
+  step(hipMalloc((void**)&dev, 5 * (size_t)n * sizeof(T)), "hipMalloc");
+  step(hipMalloc((void**)&part, (size_t)(nblk + 1) * sizeof(double)), "hipMalloc");
+  for (int k = 0; k < 5 && rc == CAL_OK; ++k) step(hipMemcpyAsync(dev + (size_t)k * n, src[k], (size_t)n * sizeof(T), hipMemcpyHostToDevice, st), "upload");
+  if (rc == CAL_OK) {
+    hipLaunchKernelGGL(square_error_kernel<T>, dim3(nblk), dim3(256), 0, st, dev, dev + n, dev + 2 * n, dev + 3 * n, dev + 4 * n, (long long)n, part);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, part, nblk, part + nblk);
+    step(hipGetLastError(), "launch");
+    step(hipMemcpyAsync(out, part + nblk, sizeof(double), hipMemcpyDeviceToHost, st), "download");
+    step(hipStreamSynchronize(st), "synchronize");
+  }
+  (void)hipFree(dev);
+  (void)hipFree(part);
+  (void)hipStreamDestroy(st);
+  return rc;
+}
+
+}  // namespace
+
 // ================================================================================================================
 extern "C" {
 
@@ -2113,6 +2147,24 @@ int cal_device_info(int device, char* name, size_t name_len, int64_t* total_mem_
   if (total_mem_bytes) *total_mem_bytes = (int64_t)p.totalGlobalMem;
   if (compute_units) *compute_units = p.multiProcessorCount;
   return CAL_OK;
+}
+
+int cal_weighted_square_error(int device, int dtype, int64_t n, const void* model_r, const void* model_i, const void* data_r, const void* data_i,
+                              const void* wgts, double* out) {
+  if (!model_r || !model_i || !data_r || !data_i || !wgts || !out) return fail(CAL_ERR_INVALID, "cal_weighted_square_error: null argument");
+  if (n < 0) return fail(CAL_ERR_INVALID, "cal_weighted_square_error: n = %lld", (long long)n);
+  *out = 0.0;
+  if (n == 0) return CAL_OK;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(CAL_ERR_HIP, "no usable HIP device (%s); this library has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(CAL_ERR_INVALID, "cal_weighted_square_error: device %d out of range [0, %d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  const void* const src[5] = {model_r, model_i, data_r, data_i, wgts};
+  if (dtype == CAL_F32) return weighted_square_error<float>(n, src, out);
+  if (dtype == CAL_F64) return weighted_square_error<double>(n, src, out);
+  return fail(CAL_ERR_INVALID, "cal_weighted_square_error: unknown dtype %d", dtype);
 }
 
 int cal_device_stream_peak(int device, size_t bytes, int reps, double* read_gbps, double* copy_gbps) {
@@ -2250,7 +2302,8 @@ int cal_solver_eval_grads(cal_solver* s, double* loss, void* gg_r, void* gg_i, v
 }
 int cal_solver_run(cal_solver* s, const cal_run_desc* r, double* losses_out, cal_run_result* res) { NEED(s); return s->run(r, losses_out, res, false); }
 int cal_solver_run_slices(cal_solver* s, const cal_run_desc* r, double* losses_out, cal_run_result* res) { NEED(s); return s->run(r, losses_out, res, true); }
-int cal_solver_model(cal_solver* s, void* mr, void* mi) { NEED(s); return s->model(mr, mi); }
+int cal_solver_model(cal_solver* s, void* mr, void* mi) { NEED(s); return s->model(mr, mi, false); }
+int cal_solver_data_model(cal_solver* s, void* mr, void* mi) { NEED(s); return s->model(mr, mi, true); }
 int cal_solver_init_coeffs(cal_solver* s, const void* sr, const void* si) { NEED(s); return s->init_coeffs(sr, si); }
 int cal_solver_synchronize(cal_solver* s) { NEED(s); return s->synchronize(); }
 int cal_solver_set_launch_mode(cal_solver* s, int mode) { NEED(s); return s->set_launch_mode(mode); }

@@ -2072,6 +2072,51 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs<T> A) {
   }
 }
 
+// ---- the reference's graph functions under their own names (not on the fit's path, which never materialises a model) -------
+// data_model (calibration.py:1593-1605) on top of MODE_MODEL's A c: m <- g_ant0 conj(g_ant1) m, in place, [nbls][fpad]
+template <typename T>
+__global__ void apply_gains_kernel(T* __restrict__ m_r, T* __restrict__ m_i, const vec2_t<T>* __restrict__ gains, const int2* __restrict__ bl_ant,
+                                   long long nbls, int fpad) {
+#pragma clang fp contract(off)
+  const long long total = nbls * fpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / fpad;
+    const int f = (int)(i - b * fpad);
+    const int2 ant = bl_ant[b];
+    const vec2_t<T> g0 = gains[(long long)ant.x * fpad + f], g1 = gains[(long long)ant.y * fpad + f];
+    const T gr = g0.x * g1.x + g0.y * g1.y, gi = g0.y * g1.x - g0.x * g1.y;  // g0 conj(g1), split as in :1599-1602
+    const T vr = m_r[i], vi = m_i[i];
+    m_r[i] = gr * vr - gi * vi;
+    m_i[i] = gr * vi + gi * vr;
+  }
+}
+// mse (calibration.py:1608-1609): per-block partial sums (double, fixed order) of w ((d_r - m_r)^2 + (d_i - m_i)^2); a second launch
+// with one block adds the partials
+template <typename T>
+__global__ __launch_bounds__(256) void square_error_kernel(const T* __restrict__ m_r, const T* __restrict__ m_i, const T* __restrict__ d_r,
+                                                           const T* __restrict__ d_i, const T* __restrict__ w, long long n, double* __restrict__ part) {
+#pragma clang fp contract(off)
+  double acc = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const T er = d_r[i] - m_r[i], ei = d_i[i] - m_i[i];
+    acc += (double)((er * er + ei * ei) * w[i]);
+  }
+  __shared__ double sh[4];
+  acc = ldsum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+  __shared__ double sh[4];
+  acc = ldsum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
 // ---- setup kernels -------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void fill_kernel(T* __restrict__ dst, long long n, T value) {

@@ -206,6 +206,13 @@ class HipFitSolver:
         _lib.check(self._lib.cal_solver_model(self._h, _ptr(m_r), _ptr(m_i)))
         return m_r, m_i
 
+    def data_model(self):
+        """data_model (calibration.py:1593-1605): ``g_ant0 conj(g_ant1) (A c)`` of every baseline, ``[nbls, nfreqs]``."""
+        m_r = np.empty((self.nbls, self.nfreqs), dtype=self.dtype)
+        m_i = np.empty_like(m_r)
+        _lib.check(self._lib.cal_solver_data_model(self._h, _ptr(m_r), _ptr(m_i)))
+        return m_r, m_i
+
     def init_coeffs(self, src_r, src_i):
         shp = (self.nbls, self.nfreqs)
         a, b = self._real(src_r, shp), self._real(src_i, shp)

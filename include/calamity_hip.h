@@ -175,6 +175,11 @@ int cal_device_stream_peak(int device, size_t bytes, int reps, double* read_gbps
 /* Shader clock the device sustains while every CU is busy with vector FMAs for a few milliseconds (MHz): boxes of the
  * same model differ in the clock they hold under load, and compute-side kernel times scale with it. */
 int cal_device_busy_clock_mhz(int device, double* mhz);
+/* mse, calibration.py:1608-1609, on its own: sum over n samples of w ((d_r - m_r)^2 + (d_i - m_i)^2) for five host arrays of n
+ * reals of type dtype (CAL_F32 / CAL_F64), evaluated on `device` (products in dtype as the reference's graph does, partial sums
+ * in double, fixed order).  The fit itself never materialises a model: this is the reference's building block under its own name. */
+int cal_weighted_square_error(int device, int dtype, int64_t n, const void* model_r, const void* model_i, const void* data_r,
+                              const void* data_i, const void* wgts, double* out);
 
 /* tf.device / GPU selection of read_calibrate_and_model_dpss, calibration.py:1741-1753, :1796-1804 */
 int cal_solver_create(cal_solver** out, int device, int dtype);
@@ -222,6 +227,9 @@ int cal_solver_run(cal_solver* s, const cal_run_desc* run, double* losses_out, c
 int cal_solver_run_slices(cal_solver* s, const cal_run_desc* run, double* losses_out, cal_run_result* results);
 /* yield_fg_model_array, calibration.py:402-444, per baseline instead of a nants x nants cube: [nbls][nfreqs] */
 int cal_solver_model(cal_solver* s, void* model_r, void* model_i);
+/* data_model, calibration.py:1593-1605: the foreground model of every baseline times its antennas' current gains,
+ * g_ant0 conj(g_ant1) (A c): [nbls][nfreqs] (gains and coefficients must be set) */
+int cal_solver_data_model(cal_solver* s, void* model_r, void* model_i);
 /* tensorize_fg_coeffs, calibration.py:828-913: per group least squares of src on the basis with samples of zero
  * weight zeroed; the result becomes the current coefficients.  src_*: [nbls][nfreqs] real. */
 int cal_solver_init_coeffs(cal_solver* s, const void* src_r, const void* src_i);
