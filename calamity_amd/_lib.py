@@ -155,6 +155,9 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C calamity_amd/csrc`.  calamity_amd has no CPU fallback."
         )
+    # RCCL between processes / devices shares buffers by IPC handles; hosts whose driver only supports dmabuf IPC need the legacy
+    # mode off BEFORE the HSA runtime starts (first HIP call), else communicator set-up fails with "hipIpcGetMemHandle: invalid argument"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

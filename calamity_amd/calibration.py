@@ -494,13 +494,15 @@ _GRAPH_SOLVERS = []  # [(key, arrays kept alive, FitProblem)]: the last few chun
 
 
 def _graph_problem(fg_comps, ant0_inds, ant1_inds, nants):
-    key = (tuple(id(c) for c in fg_comps), tuple(id(a) for a in ant0_inds), tuple(id(a) for a in ant1_inds), int(nants))
+    # (the component tensors by identity -- they are kept alive below --, the small index arrays by content)
+    key = (tuple(id(c) for c in fg_comps), tuple(np.asarray(a, dtype=np.int64).tobytes() for a in ant0_inds),
+           tuple(np.asarray(a, dtype=np.int64).tobytes() for a in ant1_inds), int(nants))
     for k, _, prob in _GRAPH_SOLVERS:
         if k == key:
             return prob
     corr_inds = [[[(int(i), int(j)) for i, j in zip(r0, r1)] for r0, r1 in zip(np.asarray(a0), np.asarray(a1))] for a0, a1 in zip(ant0_inds, ant1_inds)]
     prob = _as_problem(list(fg_comps), corr_inds, int(nants))
-    _GRAPH_SOLVERS.append((key, (list(fg_comps), list(ant0_inds), list(ant1_inds)), prob))
+    _GRAPH_SOLVERS.append((key, list(fg_comps), prob))
     while len(_GRAPH_SOLVERS) > 4:
         _, _, old = _GRAPH_SOLVERS.pop(0)
         for sv in old.__dict__.get("_solvers", {}).values():
