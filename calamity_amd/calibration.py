@@ -373,7 +373,8 @@ def _wake_device(devices=None):
     """Start the HIP runtime on the devices a fit is going to use, on a thread of its own: the first HIP call of a process costs
     0.2 s (runtime start-up, device properties), and the entry points have half a second of host work -- the modeling components
     -- in front of their first solver.  Nothing depends on the thread: the fit creates its solvers as ever (and fails there,
-    loudly, when there is no usable device)."""
+    loudly, when there is no usable device).  Returns the thread; the entry points join it before they return or raise (it has
+    long finished by then), so that it never outlives their call."""
     from . import _lib
 
     def wake():
@@ -384,7 +385,9 @@ def _wake_device(devices=None):
         except Exception:  # noqa: BLE001 -- reported by the solver that needs the device
             pass
 
-    threading.Thread(target=wake, daemon=True).start()
+    t = threading.Thread(target=wake, daemon=True)
+    t.start()
+    return t
 
 
 def get_solver(fg_model_comps, dtype=np.float32, layout=None, device=None):
@@ -1261,15 +1264,18 @@ def calibrate_and_model_dpss(
 ):
     """Simultaneously solve for gains and model foregrounds with per-baseline DPSS vectors -- the kept entry point,
     calibration.py:1503-1584.  ``fg_model_comps_dict`` is accepted and ignored, as in the reference (:1564)."""
-    _wake_device(fitting_kwargs.get("devices"))
-    dpss_model_comps_dict = modeling.yield_pbl_dpss_model_comps(
-        uvdata, horizon=horizon, min_dly=min_dly, offset=offset, include_autos=include_autos, red_tol=red_tol,
-        notebook_progressbar=notebook_progressbar, verbose=verbose,
-    )
-    (model, resid, gains, fitted_info) = calibrate_and_model_tensor(
-        uvdata=uvdata, fg_model_comps_dict=dpss_model_comps_dict, include_autos=include_autos, verbose=verbose,
-        notebook_progressbar=notebook_progressbar, **fitting_kwargs,
-    )
+    waker = _wake_device(fitting_kwargs.get("devices"))
+    try:
+        dpss_model_comps_dict = modeling.yield_pbl_dpss_model_comps(
+            uvdata, horizon=horizon, min_dly=min_dly, offset=offset, include_autos=include_autos, red_tol=red_tol,
+            notebook_progressbar=notebook_progressbar, verbose=verbose,
+        )
+        (model, resid, gains, fitted_info) = calibrate_and_model_tensor(
+            uvdata=uvdata, fg_model_comps_dict=dpss_model_comps_dict, include_autos=include_autos, verbose=verbose,
+            notebook_progressbar=notebook_progressbar, **fitting_kwargs,
+        )
+    finally:
+        waker.join()
     return model, resid, gains, fitted_info
 
 
@@ -1306,13 +1312,16 @@ def calibrate_and_model_mixed(
         angle_match_tol=angle_match_tol,
     )
     if model_comps_dict is None:
-        _wake_device(fitting_kwargs.get("devices"))
-        freqs = uvdata.freq_array[0] if np.ndim(uvdata.freq_array) == 2 else uvdata.freq_array
-        model_comps_dict = modeling.yield_mixed_comps(
-            fitting_grps, blvecs, freqs, eigenval_cutoff=eigenval_cutoff, ant_dly=ant_dly, horizon=horizon, offset=offset,
-            min_dly=min_dly, verbose=verbose, dtype=dtype_matinv, notebook_progressbar=notebook_progressbar,
-            grp_size_threshold=grp_size_threshold,
-        )
+        waker = _wake_device(fitting_kwargs.get("devices"))
+        try:
+            freqs = uvdata.freq_array[0] if np.ndim(uvdata.freq_array) == 2 else uvdata.freq_array
+            model_comps_dict = modeling.yield_mixed_comps(
+                fitting_grps, blvecs, freqs, eigenval_cutoff=eigenval_cutoff, ant_dly=ant_dly, horizon=horizon, offset=offset,
+                min_dly=min_dly, verbose=verbose, dtype=dtype_matinv, notebook_progressbar=notebook_progressbar,
+                grp_size_threshold=grp_size_threshold,
+            )
+        finally:
+            waker.join()
     if save_dict_to is not None:
         np.save(save_dict_to, model_comps_dict)
     (model, resid, gains, fitted_info) = calibrate_and_model_tensor(
