@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/fit_small.npz.
+"""Generates tests/golden/fit_small.npz and tests/golden/optimizers_small.npz.
 
 RESTATEMENT-DERIVED, not reference-derived: the reference (TensorFlow + pyuvdata + hera_filters) cannot be imported in
 the build container (ModuleNotFoundError: tensorflow -- an ordinary error), and its tests hold no golden numbers for
@@ -73,5 +73,67 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+OPT_RUNS = {  # the rest of OPTIMIZERS (calibration.py:17-27): 8 recorded steps each, plain loss
+    "sgd_nesterov": ("SGD", dict(learning_rate=5e-2, momentum=0.9, nesterov=True)),
+    "rmsprop_momentum": ("RMSprop", dict(learning_rate=1e-2, momentum=0.5)),
+    "adagrad": ("Adagrad", dict(learning_rate=5e-2)),
+    "adadelta": ("Adadelta", dict(learning_rate=1.0)),
+    "nadam": ("Nadam", dict(learning_rate=1e-2)),
+    "ftrl_l1_l2": ("Ftrl", dict(learning_rate=0.5, l1_regularization_strength=1e-4, l2_regularization_strength=1e-3)),
+    "lamb_decay": ("LAMB", dict(learning_rate=2e-2, weight_decay_rate=1e-3)),
+}
+
+
+def main_optimizers():
+    """tests/golden/optimizers_small.npz: the same problem (read back from fit_small.npz's generator), the optimizers the first
+    fixture does not cover, and the graph functions (calibration.py:1587-1656) on the chunk tensors: per-chunk sums of
+    fg_model / data_model outputs, mse per chunk, mse_chunked, mse_chunked_sum_regularized."""
+    # the problem AS STORED in fit_small.npz (the frozen fixture; regenerating it would move its basis in the 15th digit)
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fit_small.npz")))
+    basis, off = [], 0
+    for shp in g["basis_shapes"]:
+        basis.append(g["basis_flat"][off : off + int(shp[0] * shp[1])].reshape(shp))
+        off += int(shp[0] * shp[1])
+    p = problem.FitProblem(nants=int(g["nants"]), nfreqs=int(g["nfreqs"]), basis=basis, grp_basis=g["grp_basis"], grp_bl_start=g["grp_bl_start"],
+                           bl_ant0=g["bl_ant0"], bl_ant1=g["bl_ant1"], bl_rowblk=g["bl_rowblk"], data_r=g["data_r"], data_i=g["data_i"], wgts=g["wgts"],
+                           sky_r=g["sky_r"], sky_i=g["sky_i"])
+    start = {k: g[k] for k in ("g_r", "g_i", "c_r", "c_i")}
+    ch = problem.chunks_from_problem(p)
+    fg_r = problem.coeffs_to_chunks(p, start["c_r"], np.float64)
+    fg_i = problem.coeffs_to_chunks(p, start["c_i"], np.float64)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    out = {}
+    kw = dict(data_r=ch["data_r"], data_i=ch["data_i"], wgts=ch["wgts"], fg_comps=ch["fg_comps"], corr_inds=ch["corr_inds"], maxsteps=8, tol=0.0)
+    for tag, (name, okw) in OPT_RUNS.items():
+        res = R.fit_gains_and_foregrounds(start["g_r"], start["g_i"], fg_r, fg_i, optimizer=name, **dict(kw, **okw))
+        out[f"{tag}_loss_hist"] = np.asarray(res[4]["loss"])
+        out[f"{tag}_g_r"], out[f"{tag}_g_i"] = res[0], res[1]
+        out[f"{tag}_c_r"] = problem.coeffs_from_chunks(p, res[2])
+        out[f"{tag}_c_i"] = problem.coeffs_from_chunks(p, res[3])
+    n = len(ch["fg_comps"])
+    out["nchunks"] = n
+    for c in range(n):
+        vr, vi = R.fg_model(fg_r[c], fg_i[c], ch["fg_comps"][c])
+        mr, mi = R.data_model(start["g_r"], start["g_i"], fg_r[c], fg_i[c], ch["fg_comps"][c], a0[c], a1[c])
+        out[f"chunk{c}_fg_model"] = np.asarray([vr.sum(), vi.sum(), np.abs(vr).sum(), np.abs(vi).sum()])
+        out[f"chunk{c}_data_model_r"], out[f"chunk{c}_data_model_i"] = mr, mi
+        out[f"chunk{c}_mse"] = R.mse(mr, mi, ch["data_r"][c], ch["data_i"][c], ch["wgts"][c])
+    pri = R.prior_sums(ch["sky_model_r"], ch["sky_model_i"], ch["wgts"])
+    args = (start["g_r"], start["g_i"], fg_r, fg_i, ch["fg_comps"], n, ch["data_r"], ch["data_i"], ch["wgts"], a0, a1)
+    out["mse_chunked"] = R.mse_chunked(*args)
+    out["mse_chunked_sum_regularized"] = R.mse_chunked_sum_regularized(*args, *pri)
+    out["mse_chunked_sum_regularized_shifted"] = R.mse_chunked_sum_regularized(*args, pri[0] + 0.25, pri[1] - 0.5)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "optimizers_small.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    # usage: make_golden.py fit | optimizers   (fit_small.npz is frozen: regenerate it only on purpose)
+    which = sys.argv[1] if len(sys.argv) > 1 else ""
+    if which == "fit":
+        main()
+    elif which == "optimizers":
+        main_optimizers()
+    else:
+        raise SystemExit("usage: make_golden.py fit | optimizers")

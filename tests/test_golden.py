@@ -94,3 +94,86 @@ def test_hip_matches_golden(dtype, tol, layout):
             np.testing.assert_array_equal(c_r, g["c_r"].astype(dtype))
         else:
             assert rel(c_r, g[f"{tag}_c_r"]) <= 10 * tol
+
+
+# ---- second fixture: the optimizers the first one does not cover + the graph functions (tests/golden/optimizers_small.npz) --------
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optimizers_small.npz")
+
+
+def opt_runs():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(GOLD2), "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.OPT_RUNS
+
+
+def test_oracle_reproduces_the_optimizer_fixture():
+    g, p = load()
+    g2 = dict(np.load(GOLD2))
+    ch = problem.chunks_from_problem(p)
+    fg_r = problem.coeffs_to_chunks(p, g["c_r"], np.float64)
+    fg_i = problem.coeffs_to_chunks(p, g["c_i"], np.float64)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    kw = dict(data_r=ch["data_r"], data_i=ch["data_i"], wgts=ch["wgts"], fg_comps=ch["fg_comps"], corr_inds=ch["corr_inds"], maxsteps=8, tol=0.0)
+    for tag, (name, okw) in opt_runs().items():
+        res = R.fit_gains_and_foregrounds(g["g_r"], g["g_i"], fg_r, fg_i, optimizer=name, **dict(kw, **okw))
+        np.testing.assert_allclose(res[4]["loss"], g2[f"{tag}_loss_hist"], rtol=1e-11, err_msg=tag)
+        np.testing.assert_allclose(res[0], g2[f"{tag}_g_r"], rtol=1e-10, err_msg=tag)
+        np.testing.assert_allclose(problem.coeffs_from_chunks(p, res[3]), g2[f"{tag}_c_i"], rtol=1e-9, atol=1e-14, err_msg=tag)
+    n = int(g2["nchunks"])
+    assert n == len(ch["fg_comps"])
+    args = (g["g_r"], g["g_i"], fg_r, fg_i, ch["fg_comps"], n, ch["data_r"], ch["data_i"], ch["wgts"], a0, a1)
+    assert np.isclose(R.mse_chunked(*args), g2["mse_chunked"], rtol=1e-12)
+    assert np.isclose(R.mse_chunked_sum_regularized(*args, float(g["prior_r"]), float(g["prior_i"])), g2["mse_chunked_sum_regularized"], rtol=1e-12)
+    assert np.isclose(sum(float(g2[f"chunk{c}_mse"]) for c in range(n)), g2["mse_chunked"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 2e-4)])
+def test_hip_matches_the_optimizer_fixture(dtype, tol):
+    from calamity_amd import calibration as cal
+    from calamity_amd.solver import HipFitSolver
+
+    g, p = load()
+    g2 = dict(np.load(GOLD2))
+    ch = problem.chunks_from_problem(p)  # (also fills p.chunk_of_grp: LAMB's variables)
+
+    def rel(a, b):
+        return np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / np.linalg.norm(b)
+
+    for tag, (name, okw) in opt_runs().items():
+        s = HipFitSolver(dtype=dtype)
+        s.set_problem(p, layout="stream")
+        s.set_params(g["g_r"], g["g_i"], g["c_r"], g["c_i"])
+        s.set_optimizer(name, **okw)
+        s.run(1, record=False)
+        losses, _, _ = s.run(8, record=True, tol=0.0)
+        np.testing.assert_allclose(losses, g2[f"{tag}_loss_hist"], rtol=max(10 * tol, 1e-7), err_msg=tag)
+        g_r, g_i, c_r, c_i = s.get_params()
+        s.close()
+        # (Ftrl's coefficients pass through a cancellation: a looser bound on the float32 parameters, the losses above pin it)
+        ptol = 10 * tol if not (name == "Ftrl" and dtype == np.float32) else 5e-2
+        assert rel(g_r, g2[f"{tag}_g_r"]) <= ptol and rel(g_i, g2[f"{tag}_g_i"]) <= ptol, tag
+        assert rel(c_r, g2[f"{tag}_c_r"]) <= ptol and rel(c_i, g2[f"{tag}_c_i"]) <= ptol, tag
+    # the graph functions under the reference's names, on the chunk tensors
+    cast = lambda xs: [np.asarray(x, dtype=dtype) for x in xs]  # noqa: E731
+    fg_r, fg_i = cast(problem.coeffs_to_chunks(p, g["c_r"], np.float64)), cast(problem.coeffs_to_chunks(p, g["c_i"], np.float64))
+    comps, d_r, d_i, w = cast(ch["fg_comps"]), cast(ch["data_r"]), cast(ch["data_i"]), cast(ch["wgts"])
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    gr, gi = np.asarray(g["g_r"], dtype=dtype), np.asarray(g["g_i"], dtype=dtype)
+    n = int(g2["nchunks"])
+    for c in range(n):
+        vr, vi = cal.fg_model(fg_r[c], fg_i[c], comps[c])
+        want = g2[f"chunk{c}_fg_model"]
+        assert abs(vr.sum(dtype=np.float64) - want[0]) <= 10 * tol * want[2] and abs(vi.sum(dtype=np.float64) - want[1]) <= 10 * tol * want[3]
+        mr, mi = cal.data_model(gr, gi, fg_r[c], fg_i[c], comps[c], a0[c], a1[c])
+        assert rel(mr, g2[f"chunk{c}_data_model_r"]) <= tol and rel(mi, g2[f"chunk{c}_data_model_i"]) <= tol
+        assert abs(cal.mse(mr, mi, d_r[c], d_i[c], w[c]) - g2[f"chunk{c}_mse"]) <= 20 * tol * g2[f"chunk{c}_mse"]
+    args = (gr, gi, fg_r, fg_i, comps, n, d_r, d_i, w, a0, a1)
+    assert abs(cal.mse_chunked(*args, dtype=dtype) - g2["mse_chunked"]) <= max(tol, 1e-10) * g2["mse_chunked"]
+    assert abs(cal.mse_chunked_sum_regularized(*args, float(g["prior_r"]), float(g["prior_i"]), dtype=dtype) - g2["mse_chunked_sum_regularized"]) \
+        <= max(tol, 1e-10) * g2["mse_chunked_sum_regularized"]
+    assert abs(cal.mse_chunked_sum_regularized(*args, float(g["prior_r"]) + 0.25, float(g["prior_i"]) - 0.5, dtype=dtype)
+               - g2["mse_chunked_sum_regularized_shifted"]) <= max(tol, 1e-10) * g2["mse_chunked_sum_regularized_shifted"]
