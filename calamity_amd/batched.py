@@ -117,8 +117,17 @@ class SliceBatchFitter:
             # rows / coefficients of this worker in the global slice-major arrays
             self.rows.append(np.concatenate([bl + t * prob.nbls for t in range(self.nt)]))
             self.cidx.append(np.concatenate([cidx + t * prob.ncoeffs for t in range(self.nt)]))
-        self.solvers = [HipFitSolver(dtype=self.dtype, device=d) for d in self.devices]
-        self._host_exchange = None
+        self.solvers, self._host_exchange = [], None
+        try:
+            self._set_up(prob, layout, kernel_path, communicator_of_one)
+        except BaseException:
+            self.close()  # (the solvers created so far: their device memory goes back at once)
+            raise
+
+    def _set_up(self, prob, layout, kernel_path, communicator_of_one):
+        D = self.nworkers
+        for d in self.devices:  # (every device index is checked here, before any worker waits for a peer in the communicator set-up)
+            self.solvers.append(HipFitSolver(dtype=self.dtype, device=d))
         if D == 1 and communicator_of_one:
             uid = comm_unique_id()
             self._each_threaded(lambda r, s: s.comm_init(uid, 0, 1))

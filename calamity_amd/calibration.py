@@ -1115,7 +1115,8 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
                 flag_poltime(model, time=time, polarization=pol)
                 continue
             todo.append(dict(polnum=polnum, pol=pol, time_index=time_index, time=time, rmsdata=rmsdata, bltsel=bltsel))
-    if devices is None:
+    chose_devices = devices is None
+    if chose_devices:
         devices = _default_devices(float(min(len(todo), max_batch)) * prob.nbls * prob.nfreqs)
     for lo in range(0, len(todo), max_batch):
         batch = todo[lo : lo + max_batch]
@@ -1139,7 +1140,20 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
             a, b = tensorize_gains(gains, dtype=dtype, time=sl["time"], polarization=sl["pol"])
             g_r.append(a)
             g_i.append(b)
-        fitter = _batch_fitter(prob, nt, dtype, layout, devices)
+        try:
+            fitter = _batch_fitter(prob, nt, dtype, layout, devices)
+        except Exception as err:  # noqa: BLE001
+            # several devices were this function's own choice, not the caller's: when they cannot be set up together (communicator,
+            # memory of a peer) the fit runs on the one selected device instead -- said aloud, never silently; an explicit devices=[...]
+            # or a single device fails as it stands
+            if not (chose_devices and len(devices) > 1):
+                raise
+            import warnings
+
+            warnings.warn(f"calamity_amd: the fit could not be set up on devices {devices} ({type(err).__name__}: {err}); continuing on device {devices[0]}",
+                          RuntimeWarning, stacklevel=2)
+            devices = devices[:1]
+            fitter = _batch_fitter(prob, nt, dtype, layout, devices)
         cat = lambda parts_: parts_[0] if len(parts_) == 1 else np.concatenate(parts_)  # noqa: E731
         w_all, d_r, d_i, s_r, s_i = cat(w), cat(d_r), cat(d_i), cat(s_r), cat(s_i)
         # tensorize_fg_coeffs x 2 (calibration.py:1219-1233) for every slice: one device pass gives both components (the weights

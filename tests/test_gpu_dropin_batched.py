@@ -212,3 +212,16 @@ def test_lamb_over_several_workers(nworkers):
         assert outs[0][0][t][0][-1] < 0.9 * outs[0][0][t][0][0]  # (it does descend)
     for a, b in zip(outs[1][1], outs[0][1]):
         assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b)
+
+
+def test_a_failed_set_up_gives_its_solvers_back():
+    """A batch fitter whose set-up fails (here: a device that does not exist) closes the solvers it had created and raises."""
+    from calamity_amd import _lib
+    from calamity_amd.batched import SliceBatchFitter
+
+    p, _, _ = synthetic.make_problem(6, 32, f0=150e6, df=400e3, seed=1)
+    with pytest.raises(_lib.CalamityHipError):
+        SliceBatchFitter(p, 2, dtype=np.float32, devices=[0, 99])
+    f = SliceBatchFitter(p, 2, dtype=np.float32, devices=[0])  # (and the device is as usable as before)
+    assert f.memory_bytes() > 0
+    f.close()
