@@ -194,3 +194,54 @@ def test_slice_losses_and_errors():
     with pytest.raises(_lib.CalamityHipError):
         s.set_problem(bad)
     s.close()
+
+
+@pytest.mark.parametrize("layout", ["shared", "stream"])
+def test_as_many_slices_as_the_library_takes(layout):
+    """CAL_MAX_SLICES (256) time slices in ONE solver -- the batches the drop-in makes of tutorial-scale data -- each with its own
+    noise level and tolerance stop: a sample of the slices against the same slices fitted alone; one slice more is refused."""
+    from calamity_amd import _lib
+    from calamity_amd.batched import replicate_slices
+    from calamity_amd.solver import HipFitSolver
+
+    nt = _lib.CAL_MAX_SLICES
+    p, _, start = synthetic.make_problem(6, 32, f0=150e6, df=400e3, seed=9, with_sky=False)
+    rng = np.random.default_rng(9)
+    scale = 1.0 + 0.5 * rng.random(nt)                      # every slice its own sky level ...
+    noise = 10.0 ** rng.uniform(-4, -1.5, nt)               # ... and noise: they stop at different steps
+    d_r = np.concatenate([p.data_r * scale[t] + noise[t] * rng.standard_normal(p.data_r.shape) for t in range(nt)])
+    d_i = np.concatenate([p.data_i * scale[t] + noise[t] * rng.standard_normal(p.data_i.shape) for t in range(nt)])
+    w = np.concatenate([p.wgts] * nt)
+    big, _, _ = replicate_slices(p, nt)
+    run_kw = dict(record=True, tol=1e-9, use_min=False)
+    s = HipFitSolver(dtype=np.float64)
+    s.set_problem(big, layout=layout)
+    s.set_data(d_r, d_i, w)
+    s.set_params(np.concatenate([start["g_r"]] * nt), np.concatenate([start["g_i"]] * nt),
+                 np.concatenate([start["c_r"] * scale[t] for t in range(nt)]), np.concatenate([start["c_i"] * scale[t] for t in range(nt)]))
+    s.set_optimizer("Adam", learning_rate=2e-2)
+    s.run_slices(1, record=False)
+    res = s.run_slices(400, **run_kw)
+    g_r = s.get_params()[0]
+    s.close()
+    nstop = sorted({len(r[0]) for r in res})
+    assert len(nstop) > 8, nstop  # (the slices really stop on their own)
+    one = HipFitSolver(dtype=np.float64)
+    one.set_problem(FitProblem(**{k: getattr(p, k) for k in ("nants", "nfreqs", "basis", "grp_basis", "grp_bl_start", "bl_ant0", "bl_ant1", "bl_rowblk")},
+                               data_r=None, data_i=None, wgts=None), layout=layout)
+    nb = p.nbls
+    for t in (0, 1, 77, 128, nt - 1):
+        one.set_data(d_r[t * nb : (t + 1) * nb], d_i[t * nb : (t + 1) * nb], p.wgts)
+        one.set_params(start["g_r"], start["g_i"], start["c_r"] * scale[t], start["c_i"] * scale[t])
+        one.set_optimizer("Adam", learning_rate=2e-2)
+        one.run(1, record=False)
+        losses, stopped, _ = one.run(400, **run_kw)
+        assert len(losses) == len(res[t][0]) and bool(stopped) == bool(res[t][1]), t
+        np.testing.assert_allclose(res[t][0], losses, rtol=1e-11)
+        assert np.linalg.norm(g_r[t * p.nants : (t + 1) * p.nants] - one.get_params()[0]) <= 1e-11 * np.linalg.norm(one.get_params()[0])
+    one.close()
+    too_many, _, _ = replicate_slices(p, nt + 1)
+    s = HipFitSolver(dtype=np.float64)
+    with pytest.raises(_lib.CalamityHipError):
+        s.set_problem(too_many, layout=layout)
+    s.close()
