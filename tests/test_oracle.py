@@ -278,3 +278,85 @@ def test_fit_quality_reference_criterion():
     resid = np.sqrt(np.mean(((ch["data_r"][0] - mr) ** 2 + (ch["data_i"][0] - mi) ** 2)[w]))
     rms_data = np.sqrt(np.mean((ch["data_r"][0] ** 2 + ch["data_i"][0] ** 2)[w]))
     assert rms_data >= 100 * resid
+
+
+def test_optimizers_against_torch_optim():
+    """The oracle's optimizer classes against an independent implementation of the same published update rules: torch.optim on the
+    CPU (float64), twelve steps on a fixed sequence of gradients from a moving quadratic.  Where Keras and torch place epsilon
+    differently (Adam, Adamax, RMSprop with momentum) both run with a vanishing epsilon, where the rules coincide; SGD (+ momentum,
+    + Nesterov), Adagrad, Adadelta, plain RMSprop and Nadam (same momentum schedule, mu_t = b1 (1 - 0.5 * 0.96^(0.004 t))) are
+    compared with the defaults both libraries share.  (Ftrl and LAMB have no torch.optim counterpart: hand-computed answers above.)"""
+    import torch
+
+    rng = np.random.default_rng(11)
+    x0 = rng.standard_normal(7)
+    targets = [rng.standard_normal(7) for _ in range(12)]
+    scale = 0.5 + rng.random(7)
+
+    def grads_at(x, k):  # gradient of 0.5 * sum scale (x - target_k)^2: depends on the iterate, so errors would compound
+        return scale * (x - targets[k])
+
+    cases = [
+        ("SGD", dict(learning_rate=0.05), torch.optim.SGD, dict(lr=0.05)),
+        ("SGD", dict(learning_rate=0.05, momentum=0.9), torch.optim.SGD, dict(lr=0.05, momentum=0.9)),
+        ("SGD", dict(learning_rate=0.05, momentum=0.9, nesterov=True), torch.optim.SGD, dict(lr=0.05, momentum=0.9, nesterov=True)),
+        ("Adagrad", dict(learning_rate=0.1, initial_accumulator_value=0.1, epsilon=1e-7), torch.optim.Adagrad,
+         dict(lr=0.1, initial_accumulator_value=0.1, eps=1e-7)),
+        ("Adadelta", dict(learning_rate=1.0, rho=0.95, epsilon=1e-7), torch.optim.Adadelta, dict(lr=1.0, rho=0.95, eps=1e-7)),
+        ("RMSprop", dict(learning_rate=0.01, rho=0.9, epsilon=1e-7), torch.optim.RMSprop, dict(lr=0.01, alpha=0.9, eps=1e-7)),
+        ("RMSprop", dict(learning_rate=0.01, rho=0.9, momentum=0.5, epsilon=1e-30), torch.optim.RMSprop, dict(lr=0.01, alpha=0.9, momentum=0.5, eps=1e-30)),
+        ("Adam", dict(learning_rate=0.05, epsilon=1e-30), torch.optim.Adam, dict(lr=0.05, eps=1e-30)),
+        ("Adamax", dict(learning_rate=0.05, epsilon=1e-30), torch.optim.Adamax, dict(lr=0.05, eps=1e-30)),
+        ("Nadam", dict(learning_rate=0.05, epsilon=1e-7), torch.optim.NAdam, dict(lr=0.05, eps=1e-7, momentum_decay=0.004)),
+    ]
+    for name, kw, topt, tkw in cases:
+        x = x0.copy()
+        opt = R.OPTIMIZERS[name](**kw)
+        xt = torch.tensor(x0.copy(), dtype=torch.float64, requires_grad=True)
+        o = topt([xt], **tkw)
+        for k in range(12):
+            opt.apply_gradients([(grads_at(x, k), x)])
+            o.zero_grad()
+            xt.grad = torch.tensor(grads_at(xt.detach().numpy(), k))
+            o.step()
+            # (torch keeps NAdam's running product of the momentum schedule in float32: 1e-8 relative per step)
+            rtol = 2e-6 if name == "Nadam" else 1e-9
+            np.testing.assert_allclose(x, xt.detach().numpy(), rtol=rtol, atol=1e-12, err_msg=f"{name} {kw} step {k}")
+
+
+@pytest.mark.parametrize("optimizer,reg", [("Adamax", True), ("Adam", False), ("SGD", False)])
+def test_whole_fit_against_torch_autograd_and_torch_optim(optimizer, reg):
+    """End to end without any code of the oracle: the reference's forward written in torch (above), torch's reverse mode for
+    tape.gradient (calibration.py:664-666), torch.optim for apply_gradients (:667) and the loop of :681-717 (one unrecorded update,
+    then the loss recorded BEFORE each update) -- against oracle fit_gains_and_foregrounds on the same inputs: the recorded losses and
+    every fitted parameter.  (Adam / Adamax with a vanishing epsilon, where the Keras and torch rules coincide.)"""
+    import torch
+
+    p, ch, g_r, g_i, fg_r, fg_i = _setup(seed=5, with_sky=reg, redundant=True)
+    a0, a1 = R.ant_inds_from_corr_inds(ch["corr_inds"])
+    priors = R.prior_sums(ch["sky_model_r"], ch["sky_model_i"], ch["wgts"]) if reg else None
+    nsteps = 12
+    okw = dict(learning_rate=2e-2) if optimizer == "SGD" else dict(learning_rate=2e-2, epsilon=1e-30)
+    res = R.fit_gains_and_foregrounds(g_r, g_i, fg_r, fg_i, ch["data_r"], ch["data_i"], ch["wgts"], ch["fg_comps"], ch["corr_inds"], maxsteps=nsteps,
+                                      tol=0.0, optimizer=optimizer, sky_model_r=ch["sky_model_r"], sky_model_i=ch["sky_model_i"],
+                                      model_regularization="sum" if reg else None, **okw)
+    tg_r, tg_i = torch.tensor(g_r, requires_grad=True), torch.tensor(g_i, requires_grad=True)
+    tf_r = [torch.tensor(a, requires_grad=True) for a in fg_r]
+    tf_i = [torch.tensor(a, requires_grad=True) for a in fg_i]
+    params = [tg_r, tg_i] + tf_r + tf_i
+    topt = {"Adamax": lambda: torch.optim.Adamax(params, lr=2e-2, eps=1e-30), "Adam": lambda: torch.optim.Adam(params, lr=2e-2, eps=1e-30),
+            "SGD": lambda: torch.optim.SGD(params, lr=2e-2)}[optimizer]()
+    losses = []
+    for k in range(nsteps + 1):
+        topt.zero_grad()
+        loss = _torch_loss(tg_r, tg_i, tf_r, tf_i, ch, a0, a1, priors)
+        loss.backward()
+        if k > 0:  # (step 0 is the unrecorded "graph building" update of :693)
+            losses.append(loss.item())
+        topt.step()
+    np.testing.assert_allclose(res[4]["loss"], losses, rtol=1e-9)
+    np.testing.assert_allclose(res[0], tg_r.detach().numpy(), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(res[1], tg_i.detach().numpy(), rtol=1e-8, atol=1e-12)
+    for c in range(len(fg_r)):
+        np.testing.assert_allclose(res[2][c], tf_r[c].detach().numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(res[3][c], tf_i[c].detach().numpy(), rtol=1e-8, atol=1e-12)
