@@ -829,15 +829,16 @@ def calibrate_and_model_tensor(
     if init_guesses_from_previous_time_step:
         batch_slices = False  # every time starts from the previous one's result: a chain, not a batch
     if batch_slices:
-        max_batch = _auto_batch(prob, dtype) if batch_slices is True else max(1, min(int(batch_slices), _lib_max_slices()))
+        max_batch = _auto_batch(prob, dtype, layout) if batch_slices is True else max(1, min(int(batch_slices), _lib_max_slices()))
         fit_history = _fit_slices_batched(
             uvdata=uvdata, sky_model=sky_model, gains=gains, resid=resid, model=model, prob=prob, corr_inds=corr_inds, ants_map=ants_map,
             times=times, weights=weights, nsamples_in_weights=nsamples_in_weights, dtype=dtype, skip_threshold=skip_threshold,
             use_model_snr_weights=use_model_snr_weights, optimizer=optimizer, use_min=use_min, freeze_model=freeze_model, tol=tol,
             maxsteps=maxsteps, n_profile_steps=n_profile_steps, profile_log_dir=profile_log_dir, model_regularization=model_regularization,
             verbose=verbose, max_batch=max_batch, devices=devices, layout=layout, opt_kwargs=opt_kwargs,
+            correct_model=correct_model, correct_resid=correct_resid,
         )
-        return _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, correct_resid)
+        return model, resid, gains, fit_history  # (every slice left _fit_slices_batched in its final state)
     if layout is not None:
         prob.__dict__["_layout"] = layout
     if devices is not None:
@@ -939,12 +940,12 @@ def calibrate_and_model_tensor(
     return _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, correct_resid)
 
 
-def _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, correct_resid):
-    """Residual and model in the requested calibration state -- calibration.py:1322-1331:
-    ``model_with_gains = apply_gains(model, gains, inverse=True)``; ``resid = data - model_with_gains``, zero where the model
-    (with gains) or the data are flagged; ``correct_resid``: ``resid / (g_i conj(g_j))``, flags or-ed with the gain flags;
-    ``correct_model=False`` returns the model with gains.  The same arithmetic in the same order as those calls, in ONE pass over
-    the baseline-times (row chunks on the host's cores) instead of four passes and three container copies."""
+def _output_finisher(uvdata, model, resid, gains, correct_model, correct_resid):
+    """``finish(pnum, time)``: residual and model of ONE (polarization, time) in the requested calibration state --
+    calibration.py:1322-1331: ``model_with_gains = apply_gains(model, gains, inverse=True)``; ``resid = data - model_with_gains``,
+    zero where the model (with gains) or the data are flagged; ``correct_resid``: ``resid / (g_i conj(g_j))``, flags or-ed with
+    the gain flags; ``correct_model=False`` returns the model with gains.  The same arithmetic in the same order as those calls, in
+    ONE pass over the slice's baseline-times (row chunks on the host's cores) instead of four passes and three container copies."""
     ants = np.asarray(gains.ant_array).astype(np.int64)
     order = np.argsort(ants)
 
@@ -961,35 +962,49 @@ def _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, cor
     tind = np.asarray([np.where(np.isclose(gtimes, t, rtol=0.0, atol=1e-7))[0][0] for t in utimes])
     gt = tind[np.searchsorted(utimes, np.asarray(uvdata.time_array))]
     udata, uflag = vis3(np.asarray(uvdata.data_array)), vis3(np.asarray(uvdata.flag_array))
-    mdata, mflag = vis3(model.data_array), vis3(model.flag_array)
-    rdata, rflag = vis3(resid.data_array), vis3(resid.flag_array)
-    garr, gflags = gain4(gains.gain_array), gain4(gains.flag_array)
-    for pnum, pol in enumerate(uvdata.get_pols()):
-        gindp = np.where(np.asarray(gains.jones_array) == polstr2num(pol, x_orientation=gains.x_orientation))[0][0]
-        for t in np.unique(gt):
-            gplane = np.ascontiguousarray(garr[:, :, t, gindp])
-            fplane = np.ascontiguousarray(gflags[:, :, t, gindp])
-            sel = np.where(gt == t)[0]
-            contiguous = len(sel) == sel[-1] - sel[0] + 1
+    pols = list(uvdata.get_pols())
 
-            def rows(lo, hi, pnum=pnum, sel=sel, gplane=gplane, fplane=fplane, contiguous=contiguous):
-                r = slice(sel[0] + lo, sel[0] + hi) if contiguous else sel[lo:hi]
-                gg = np.take(gplane, a0[r], axis=0)
-                gg *= np.conj(np.take(gplane, a1[r], axis=0))
-                gf = np.take(fplane, a0[r], axis=0) | np.take(fplane, a1[r], axis=0)
-                mwg = mdata[r, :, pnum] * gg  # apply_gains(model, gains, inverse=True)
-                mwf = mflag[r, :, pnum] | gf
-                d = udata[r, :, pnum] - mwg
-                d[mwf | uflag[r, :, pnum]] = 0.0
-                if correct_resid:  # apply_gains(resid, gains)
-                    d /= gg
-                    rflag[r, :, pnum] |= gf
-                rdata[r, :, pnum] = d
-                if not correct_model:
-                    mdata[r, :, pnum] = mwg
-                    mflag[r, :, pnum] = mwf
+    def finish(pnum, time):
+        # (the containers' arrays as they are NOW: the write-backs before this call may have attached new ones)
+        mdata, mflag = vis3(model.data_array), vis3(model.flag_array)
+        rdata, rflag = vis3(resid.data_array), vis3(resid.flag_array)
+        garr, gflags = gain4(gains.gain_array), gain4(gains.flag_array)
+        gindp = np.where(np.asarray(gains.jones_array) == polstr2num(pols[pnum], x_orientation=gains.x_orientation))[0][0]
+        t = tind[np.where(np.isclose(utimes, time, rtol=0.0, atol=1e-7))[0][0]]
+        gplane = np.ascontiguousarray(garr[:, :, t, gindp])
+        fplane = np.ascontiguousarray(gflags[:, :, t, gindp])
+        sel = np.where(gt == t)[0]
+        contiguous = len(sel) == sel[-1] - sel[0] + 1
 
-            utils.for_row_chunks(rows, len(sel))
+        def rows(lo, hi):
+            r = slice(sel[0] + lo, sel[0] + hi) if contiguous else sel[lo:hi]
+            gg = np.take(gplane, a0[r], axis=0)
+            gg *= np.conj(np.take(gplane, a1[r], axis=0))
+            gf = np.take(fplane, a0[r], axis=0) | np.take(fplane, a1[r], axis=0)
+            mwg = mdata[r, :, pnum] * gg  # apply_gains(model, gains, inverse=True)
+            mwf = mflag[r, :, pnum] | gf
+            d = udata[r, :, pnum] - mwg
+            d[mwf | uflag[r, :, pnum]] = 0.0
+            if correct_resid:  # apply_gains(resid, gains)
+                d /= gg
+                rflag[r, :, pnum] |= gf
+            rdata[r, :, pnum] = d
+            if not correct_model:
+                mdata[r, :, pnum] = mwg
+                mflag[r, :, pnum] = mwf
+
+        utils.for_row_chunks(rows, len(sel))
+
+    finish.times, finish.npols = utimes, len(pols)
+    return finish
+
+
+def _finish_outputs(uvdata, model, resid, gains, fit_history, correct_model, correct_resid):
+    """Every (polarization, time) through _output_finisher: the outputs of calibrate_and_model_tensor."""
+    finish = _output_finisher(uvdata, model, resid, gains, correct_model, correct_resid)
+    for pnum in range(finish.npols):
+        for time in finish.times:
+            finish(pnum, time)
     return model, resid, gains, fit_history
 
 
@@ -1035,13 +1050,17 @@ def _lib_max_slices():
     return _lib.CAL_MAX_SLICES
 
 
-def _auto_batch(prob, dtype):
+def _auto_batch(prob, dtype, layout=None):
     """How many slices one batch may hold when the caller does not say: what fits a quarter of the host memory now available (five
     per-sample arrays per slice and their concatenation) and half a device's memory (about eight per-sample arrays per slice), at
-    most the library's CAL_MAX_SLICES.  Tutorial-scale arrays batch hundreds of slices; at HERA-350 (0.25 GB per array and slice)
-    the batches are a few slices -- where a step is bound by arithmetic, not by launches, and batching buys nothing anyway."""
+    most the library's CAL_MAX_SLICES.  Tutorial-scale arrays batch hundreds of slices.  In the SHARED layout a slice of 10^7 samples
+    or more goes alone: its step is bound by arithmetic, not by launches (HERA-350: 1.29 s per 1 000 steps and slice whether four
+    slices are fitted together or one by one), and batches of one let the host work of neighbouring slices run under the fits
+    (_fit_slices_batched).  The STREAM layout keeps batching at every size: its slices share the basis tiles they stream."""
     from . import _lib
 
+    if (layout or "shared") == "shared" and float(prob.nbls) * prob.nfreqs >= 1.0e7:
+        return 1
     per_array = float(prob.nbls) * prob.nfreqs * np.dtype(dtype).itemsize
     host_avail = 8.0e9
     try:
@@ -1093,37 +1112,44 @@ def _batch_fitter(prob, nt, dtype, layout, devices):
 
 def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds, ants_map, times, weights, nsamples_in_weights, dtype,
                         skip_threshold, use_model_snr_weights, optimizer, use_min, freeze_model, tol, maxsteps, n_profile_steps,
-                        profile_log_dir, model_regularization, verbose, max_batch, devices, layout, opt_kwargs):
-    """The pol x time loop of calibration.py:1160-1320 with the fits of all unskipped slices issued as batches: per slice
+                        profile_log_dir, model_regularization, verbose, max_batch, devices, layout, opt_kwargs, correct_model=True,
+                        correct_resid=False):
+    """The pol x time loop of calibration.py:1160-1331 with the fits of all unskipped slices issued as batches: per slice
     exactly the host-side steps of the loop body (skip test :1173-1177, rms scale :1178-1182, tensorize :1184-1233, write-back
-    :1271-1300, post-hoc renormalisation :1311-1319), the gradient descent of :1244-1269 for up to ``max_batch`` slices at once
-    with per-slice loop control.  Returns ``fit_history``."""
+    :1271-1300, post-hoc renormalisation :1311-1319, residual and calibration state of the outputs :1322-1331), the gradient
+    descent of :1244-1269 for up to ``max_batch`` slices at once with per-slice loop control.  Returns ``fit_history``; model,
+    resid and gains are complete when it returns."""
     OPTIMIZERS[optimizer]  # unknown optimizer -> KeyError, like calibration.py:571
     dtype = np.dtype(dtype)
     layout = layout or "shared"
     pols = list(uvdata.get_pols())
     fit_history = {polnum: {} for polnum in range(len(pols))}
-    todo = []
-    for polnum, pol in enumerate(pols):
-        for time_index, time in enumerate(times):
-            bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
-            frac_unflagged, rmsdata = _slice_stats(uvdata, bltsel, polnum)
-            if frac_unflagged < skip_threshold:
-                echo(f"{datetime.datetime.now()}: Only {frac_unflagged * 100}-percent of data unflagged. Skipping...\n", verbose=verbose)
-                flag_poltime(resid, time=time, polarization=pol)
-                flag_poltime(gains, time=time, polarization=pol)
-                flag_poltime(model, time=time, polarization=pol)
-                continue
-            todo.append(dict(polnum=polnum, pol=pol, time_index=time_index, time=time, rmsdata=rmsdata, bltsel=bltsel))
+    todo = [dict(polnum=polnum, pol=pol, time_index=time_index, time=time) for polnum, pol in enumerate(pols) for time_index, time in enumerate(times)]
+    finish = _output_finisher(uvdata, model, resid, gains, correct_model, correct_resid)
     chose_devices = devices is None
     if chose_devices:
         devices = _default_devices(float(min(len(todo), max_batch)) * prob.nbls * prob.nfreqs)
-    for lo in range(0, len(todo), max_batch):
-        batch = todo[lo : lo + max_batch]
-        nt = len(batch)
-        echo(f"{datetime.datetime.now()} Working on {nt} (polarization, time) slices together...\n", verbose=verbose)
+    cat = lambda parts_: parts_[0] if len(parts_) == 1 else np.concatenate(parts_)  # noqa: E731
+
+    # One batch goes through three stages: prep (host: the slices' rows out of the containers), fit (device), post (host: the model
+    # rows and gains back into the containers).  The stages of neighbouring batches overlap -- while the device fits batch k, one
+    # host thread prepares batch k + 1 and another writes batch k - 1 back (NumPy and the library both release the GIL): with several
+    # batches the host work of all but the first and the last disappears behind the fits.  The (polarization, time) slices of
+    # different batches are disjoint parts of the containers, so the stages never touch the same rows.
+    def prep(candidates):
         d_r, d_i, w, s_r, s_i, g_r, g_i = [], [], [], [], [], [], []
-        for sl in batch:
+        batch = []
+        for sl in candidates:
+            # skip test and rms scale of the slice (:1168-1182)
+            bltsel = np.isclose(uvdata.time_array, sl["time"], atol=1e-7, rtol=0.0)
+            frac_unflagged, sl["rmsdata"] = _slice_stats(uvdata, bltsel, sl["polnum"])
+            if frac_unflagged < skip_threshold:
+                echo(f"{datetime.datetime.now()}: Only {frac_unflagged * 100}-percent of data unflagged. Skipping...\n", verbose=verbose)
+                flag_poltime(resid, time=sl["time"], polarization=sl["pol"])
+                flag_poltime(gains, time=sl["time"], polarization=sl["pol"])
+                flag_poltime(model, time=sl["time"], polarization=sl["pol"])
+                continue
+            batch.append(sl)
             dr_t, di_t, w_t = _tensorize_flat(uvdata, prob, ants_map, sl["pol"], sl["time"], data_scale_factor=sl["rmsdata"], weights=weights,
                                               nsamples_in_weights=nsamples_in_weights, dtype=dtype)
             d_r.append(dr_t)
@@ -1140,6 +1166,18 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
             a, b = tensorize_gains(gains, dtype=dtype, time=sl["time"], polarization=sl["pol"])
             g_r.append(a)
             g_i.append(b)
+        echo(f"{datetime.datetime.now()} {len(batch)} of {len(candidates)} (polarization, time) slices tensorized.\n", verbose=verbose)
+        if not batch:
+            return dict(batch=batch)
+        pri = None
+        if model_regularization == "sum" and not use_model_snr_weights:  # (with model-SNR weights the priors wait for the new weights: fit)
+            pri = np.asarray([_prior_sums(a, b, c) for a, b, c in zip(s_r, s_i, w)])
+        return dict(batch=batch, w=cat(w), d_r=cat(d_r), d_i=cat(d_i), s_r=cat(s_r), s_i=cat(s_i), g_r=cat(g_r), g_i=cat(g_i), pri=pri)
+
+    def fit(batch, arrs):
+        nonlocal devices
+        nt = len(batch)
+        echo(f"{datetime.datetime.now()} Working on {nt} (polarization, time) slices together...\n", verbose=verbose)
         try:
             fitter = _batch_fitter(prob, nt, dtype, layout, devices)
         except Exception as err:  # noqa: BLE001
@@ -1154,8 +1192,7 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
                           RuntimeWarning, stacklevel=2)
             devices = devices[:1]
             fitter = _batch_fitter(prob, nt, dtype, layout, devices)
-        cat = lambda parts_: parts_[0] if len(parts_) == 1 else np.concatenate(parts_)  # noqa: E731
-        w_all, d_r, d_i, s_r, s_i = cat(w), cat(d_r), cat(d_i), cat(s_r), cat(s_i)
+        w_all, d_r, d_i, s_r, s_i = arrs["w"], arrs["d_r"], arrs["d_i"], arrs["s_r"], arrs["s_i"]
         # tensorize_fg_coeffs x 2 (calibration.py:1219-1233) for every slice: one device pass gives both components (the weights
         # it masks with are those of set_data; the sky model arrives as the pass's own source rows)
         fitter.set_data(d_r, d_i, w_all)
@@ -1172,11 +1209,13 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
                 w_new[rows] /= np.sum(w_new[rows])
             w_all = w_new.astype(dtype)
             fitter.set_data(d_r, d_i, w_all)
-        fitter.set_params(cat(g_r), cat(g_i), c_r, c_i)
+        fitter.set_params(arrs["g_r"], arrs["g_i"], c_r, c_i)
         if model_regularization == "sum":
             # priors of calibration.py:619-625, one pair per slice (accumulated in float64 on the host)
             nb = prob.nbls
-            pri = np.asarray([_prior_sums(s_r[t * nb : (t + 1) * nb], s_i[t * nb : (t + 1) * nb], w_all[t * nb : (t + 1) * nb]) for t in range(nt)])
+            pri = arrs["pri"]
+            if pri is None:
+                pri = np.asarray([_prior_sums(s_r[t * nb : (t + 1) * nb], s_i[t * nb : (t + 1) * nb], w_all[t * nb : (t + 1) * nb]) for t in range(nt)])
             fitter.set_regularization("sum", pri[:, 0], pri[:, 1])
         else:
             fitter.set_regularization(None)
@@ -1206,20 +1245,49 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
         # yield_fg_model_array x 2 + insert_model_into_uvdata_tensor (:1271-1292) for every slice from one A c pass
         fitter.set_params(c_r=cm_r, c_i=cm_i)
         m_r, m_i = fitter.model()
-        for t, (sl, res) in enumerate(zip(batch, results)):
+        echo(f"{datetime.datetime.now()} ... fitted.\n", verbose=verbose)
+        return dict(results=results, m_r=m_r, m_i=m_i, gm_r=gm_r, gm_i=gm_i)
+
+    def post(batch, out):
+        for t, (sl, res) in enumerate(zip(batch, out["results"])):
             rows, ga = slice(t * prob.nbls, (t + 1) * prob.nbls), slice(t * prob.nants, (t + 1) * prob.nants)
-            _insert_model_rows(model, sl["time"], sl["pol"], ants_map, prob, m_r[rows], m_i[rows], scale_factor=sl["rmsdata"])
-            insert_gains_into_uvcal(uvcal=gains, time=sl["time"], polarization=sl["pol"], gains_re=gm_r[ga], gains_im=gm_i[ga])
+            _insert_model_rows(model, sl["time"], sl["pol"], ants_map, prob, out["m_r"][rows], out["m_i"][rows], scale_factor=sl["rmsdata"])
+            insert_gains_into_uvcal(uvcal=gains, time=sl["time"], polarization=sl["pol"], gains_re=out["gm_r"][ga], gains_im=out["gm_i"][ga])
             fit_history[sl["polnum"]][sl["time_index"]] = {"loss": [dtype.type(l) for l in res[0]]}
             if res[1]:
                 echo(f"Tolerance thresshold met for time {sl['time_index']}. Terminating...\n ", verbose=verbose)
-    if not freeze_model and model_regularization == "post_hoc":
-        for polnum, pol in enumerate(pols):
-            for time in times:
-                bltsel = np.isclose(uvdata.time_array, time, atol=1e-7, rtol=0.0)
+            if not freeze_model and model_regularization == "post_hoc":  # (:1311-1319)
+                bltsel = np.isclose(uvdata.time_array, sl["time"], atol=1e-7, rtol=0.0)
                 if np.any(~model.flag_array[bltsel]):
-                    renormalize(uvdata_reference_model=sky_model, uvdata_deconv=model, gains=gains, polarization=pol, time=time,
+                    renormalize(uvdata_reference_model=sky_model, uvdata_deconv=model, gains=gains, polarization=sl["pol"], time=sl["time"],
                                 additional_flags=uvdata.flag_array)
+            finish(sl["polnum"], sl["time"])  # (:1322-1331)
+        echo(f"{datetime.datetime.now()} {len(batch)} (polarization, time) slices written back.\n", verbose=verbose)
+
+    batches = [todo[lo : lo + max_batch] for lo in range(0, len(todo), max_batch)]
+    if len(batches) <= 1:
+        for candidates in batches:
+            arrs = prep(candidates)
+            if arrs["batch"]:
+                post(arrs["batch"], fit(arrs["batch"], arrs))
+    else:
+        with concurrent.futures.ThreadPoolExecutor(1) as prep_pool, concurrent.futures.ThreadPoolExecutor(1) as post_pool:
+            ahead, written = prep_pool.submit(prep, batches[0]), []
+            for k in range(len(batches)):
+                arrs = ahead.result()
+                if k + 1 < len(batches):
+                    ahead = prep_pool.submit(prep, batches[k + 1])
+                batch = arrs["batch"]
+                if not batch:  # (every slice of it was skipped)
+                    continue
+                out = fit(batch, arrs)
+                del arrs
+                written.append(post_pool.submit(post, batch, out))
+                for f in written[:-2]:  # (an exception of a write-back surfaces here, not at the end of the whole job)
+                    f.result()
+                written = written[-2:]
+            for f in written:
+                f.result()
     return fit_history
 
 
@@ -1244,8 +1312,10 @@ def _blank_copy(uvdata, keep_flags=False):
     data, flags = uvdata.data_array, uvdata.flag_array
     hold_d, hold_f = np.zeros(0, dtype=np.asarray(data).dtype), np.zeros(0, dtype=bool)
     out = copy.deepcopy(uvdata, {id(data): hold_d, id(flags): hold_f})
-    out.data_array = np.zeros_like(data)
-    out.flag_array = np.array(flags, copy=True) if keep_flags else np.zeros_like(flags)
+    # (np.zeros: fresh zero pages from the operating system, touched when they are first written -- the write-back of a slice, which
+    # runs beside the fits; zeros_like fills the gigabytes here and now)
+    out.data_array = np.zeros(np.shape(data), dtype=np.asarray(data).dtype)
+    out.flag_array = np.array(flags, copy=True) if keep_flags else np.zeros(np.shape(flags), dtype=bool)
     return out
 
 

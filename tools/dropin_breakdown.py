@@ -11,6 +11,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -21,7 +22,8 @@ sys.path.insert(0, ROOT)
 from calamity_amd import batched, cal_utils, calibration, modeling, solver as solver_mod, synthetic  # noqa: E402
 from calamity_amd.uvcompat import SimpleUVData  # noqa: E402
 
-STACK, TIMES, CALLS = [], {}, {}
+TIMES, CALLS = {}, {}
+_LOCAL = threading.local()  # (one stack of open timers per thread: the batches' host stages run on threads of their own)
 
 
 def timed(module, name, label=None):
@@ -29,17 +31,18 @@ def timed(module, name, label=None):
     fn = getattr(module, name)
 
     def wrapper(*a, **k):
+        stack = _LOCAL.__dict__.setdefault("stack", [])
         t0 = time.perf_counter()
-        STACK.append(0.0)
+        stack.append(0.0)
         try:
             return fn(*a, **k)
         finally:
             dt = time.perf_counter() - t0
-            inner = STACK.pop()
+            inner = stack.pop()
             TIMES[label] = TIMES.get(label, 0.0) + dt - inner
             CALLS[label] = CALLS.get(label, 0) + 1
-            if STACK:
-                STACK[-1] += dt
+            if stack:
+                stack[-1] += dt
 
     setattr(module, name, wrapper)
 
@@ -57,6 +60,7 @@ def main():
     ap.add_argument("--reg", default="sum", help="model_regularization: sum (the Python API default) | post_hoc | none")
     ap.add_argument("--host-only", action="store_true")
     ap.add_argument("--ntimes", type=int, default=1)
+    ap.add_argument("--verbose", action="store_true", help="the entry point's progress lines (time-stamped) on stderr-free stdout lines that do not start with {")
     ap.add_argument("--loop", action="store_true", help="the sequential time loop (batch_slices=False) instead of the batched call")
     args = ap.parse_args()
     dtype = np.float32 if args.dtype == "f32" else np.float64
@@ -112,6 +116,8 @@ def main():
               model_regularization=None if args.reg == "none" else args.reg)
     if args.loop:
         kw["batch_slices"] = False
+    if args.verbose:
+        kw["verbose"] = True
     if args.reg == "none":
         kw["sky_model"] = uvd  # the reference needs a sky model when there is no regularisation to build one for
     t0 = time.perf_counter()
