@@ -758,6 +758,7 @@ def calibrate_and_model_tensor(
     batch_slices=None,
     devices=None,
     layout=None,
+    device_split=None,
     **opt_kwargs,
 ):
     """Simultaneous calibration and foreground fitting -- calibration.py:963-1331, same arguments, defaults and
@@ -773,8 +774,11 @@ def calibrate_and_model_tensor(
       (``batched.SliceBatchFitter``).  ``fit_history`` and every output equal those of the sequential loop (to rounding:
       the same kernels in the same order).  ``batch_slices=False`` keeps the loop.
     * ``devices``: GPUs to fit on (list of device indices; default: every visible device when the call is large enough
-      to pay for an exchange per step, else the device selected for the process).  With several, each device takes a
-      share of the fitting groups of every slice; the caller's process drives them all.
+      to pay for an exchange per step, else the device selected for the process).  The caller's process drives them all.
+    * ``device_split``: what several devices share out.  "slices": whole batches of slices go to different devices -- no exchange
+      between them, every slice is fitted exactly as on one device (bit for bit); "groups": each device takes a share of the
+      fitting groups of every slice, with one exchange of the gain gradients per step.  Default: "slices" when the call has at
+      least as many batches as devices, else "groups".
     * ``layout``: "shared" (default; baselines alias the distinct basis blocks) or "stream" (every baseline owns its tiles).
     * ``parallel_fits`` (default 1): with ``batch_slices=False``, fits that many slices concurrently, each on its own
       solver and HIP stream.
@@ -836,7 +840,7 @@ def calibrate_and_model_tensor(
             use_model_snr_weights=use_model_snr_weights, optimizer=optimizer, use_min=use_min, freeze_model=freeze_model, tol=tol,
             maxsteps=maxsteps, n_profile_steps=n_profile_steps, profile_log_dir=profile_log_dir, model_regularization=model_regularization,
             verbose=verbose, max_batch=max_batch, devices=devices, layout=layout, opt_kwargs=opt_kwargs,
-            correct_model=correct_model, correct_resid=correct_resid,
+            correct_model=correct_model, correct_resid=correct_resid, device_split=device_split,
         )
         return model, resid, gains, fit_history  # (every slice left _fit_slices_batched in its final state)
     if layout is not None:
@@ -1113,7 +1117,7 @@ def _batch_fitter(prob, nt, dtype, layout, devices):
 def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds, ants_map, times, weights, nsamples_in_weights, dtype,
                         skip_threshold, use_model_snr_weights, optimizer, use_min, freeze_model, tol, maxsteps, n_profile_steps,
                         profile_log_dir, model_regularization, verbose, max_batch, devices, layout, opt_kwargs, correct_model=True,
-                        correct_resid=False):
+                        correct_resid=False, device_split=None):
     """The pol x time loop of calibration.py:1160-1331 with the fits of all unskipped slices issued as batches: per slice
     exactly the host-side steps of the loop body (skip test :1173-1177, rms scale :1178-1182, tensorize :1184-1233, write-back
     :1271-1300, post-hoc renormalisation :1311-1319, residual and calibration state of the outputs :1322-1331), the gradient
@@ -1174,13 +1178,15 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
             pri = np.asarray([_prior_sums(a, b, c) for a, b, c in zip(s_r, s_i, w)])
         return dict(batch=batch, w=cat(w), d_r=cat(d_r), d_i=cat(d_i), s_r=cat(s_r), s_i=cat(s_i), g_r=cat(g_r), g_i=cat(g_i), pri=pri)
 
-    def fit(batch, arrs):
+    def fit(batch, arrs, on=None):
         nonlocal devices
         nt = len(batch)
         echo(f"{datetime.datetime.now()} Working on {nt} (polarization, time) slices together...\n", verbose=verbose)
         try:
-            fitter = _batch_fitter(prob, nt, dtype, layout, devices)
+            fitter = _batch_fitter(prob, nt, dtype, layout, devices if on is None else on)
         except Exception as err:  # noqa: BLE001
+            if on is not None:
+                raise
             # several devices were this function's own choice, not the caller's: when they cannot be set up together (communicator,
             # memory of a peer) the fit runs on the one selected device instead -- said aloud, never silently; an explicit devices=[...]
             # or a single device fails as it stands
@@ -1265,7 +1271,51 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
         echo(f"{datetime.datetime.now()} {len(batch)} (polarization, time) slices written back.\n", verbose=verbose)
 
     batches = [todo[lo : lo + max_batch] for lo in range(0, len(todo), max_batch)]
-    if len(batches) <= 1:
+    if device_split not in (None, "slices", "groups"):
+        raise ValueError(f"device_split={device_split!r}: 'slices', 'groups' or None")
+    D = len(devices)
+    if D > 1 and (device_split == "slices" or (device_split is None and len(batches) >= D)):
+        # Whole batches on different devices: device d fits batches d, d + D, ... on a thread of its own (its solvers live on that
+        # thread), nothing is exchanged between devices, and every slice is fitted exactly as it would be on one device.  One prep
+        # thread runs at most D + 1 batches ahead of the fits (a batch of HERA-350 rows is 1.3 GB); one thread writes back in order.
+        permits, failed = threading.Semaphore(D + 1), threading.Event()
+
+        def prep_when_allowed(candidates):
+            permits.acquire()
+            return dict(batch=[]) if failed.is_set() else prep(candidates)
+
+        def fit_on(batch, arrs, dev):
+            try:
+                return fit(batch, arrs, on=[dev])
+            finally:
+                permits.release()
+
+        pools = [concurrent.futures.ThreadPoolExecutor(1) for _ in range(D + 2)]
+        prep_pool, post_pool, fit_pools = pools[0], pools[1], pools[2:]
+        try:
+            ahead = [prep_pool.submit(prep_when_allowed, c) for c in batches]
+            written, nfit = [], 0
+            for f in ahead:
+                arrs = f.result()
+                batch = arrs["batch"]
+                if not batch:
+                    permits.release()
+                    continue
+                fitted = fit_pools[nfit % D].submit(fit_on, batch, arrs, devices[nfit % D])
+                nfit += 1
+                del arrs
+                written.append(post_pool.submit(lambda b=batch, ff=fitted: post(b, ff.result())))
+            for f in written:
+                f.result()
+        except BaseException:
+            failed.set()
+            for _ in range(len(batches) + D + 2):  # (nobody stays blocked behind the throttle)
+                permits.release()
+            raise
+        finally:
+            for pl in pools:
+                pl.shutdown(wait=True)
+    elif len(batches) <= 1:
         for candidates in batches:
             arrs = prep(candidates)
             if arrs["batch"]:

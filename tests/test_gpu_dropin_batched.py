@@ -225,3 +225,22 @@ def test_a_failed_set_up_gives_its_solvers_back():
     f = SliceBatchFitter(p, 2, dtype=np.float32, devices=[0])  # (and the device is as usable as before)
     assert f.memory_bytes() > 0
     f.close()
+
+
+def test_batches_on_different_devices_equal_one_device_bit_for_bit():
+    """device_split="slices": whole batches of slices go to different devices (here two and three workers on the one GPU, each on a
+    thread of its own with its own solvers), nothing is exchanged, and every slice is fitted exactly as on one device: fit_history,
+    gains, model and residual are IDENTICAL to the one-device call -- with a skipped time, slices that stop at different steps,
+    use_min, the "sum" regulariser, batches of one and of two slices."""
+    uvd, sky = _five_times(seed=21, nants=8)
+    kw = dict(min_dly=2.0 / 0.3, offset=2.0 / 0.3, uvdata=uvd, gains=None, sky_model=None, maxsteps=200, tol=3e-9, correct_resid=True,
+              optimizer="Adam", learning_rate=1e-2, dtype=np.float64, use_min=True)
+    one = calibration.calibrate_and_model_dpss(devices=[0], batch_slices=1, **kw)
+    for devices, per_batch in (([0, 0], 1), ([0, 0, 0], 1), ([0, 0], 2)):
+        many = calibration.calibrate_and_model_dpss(devices=devices, device_split="slices", batch_slices=per_batch, **kw)
+        _equal_outputs(one, many, 5, 0.0 if per_batch == 1 else 1e-10, skipped=(3,))
+    # the default picks "slices" when there are at least as many batches as devices
+    auto = calibration.calibrate_and_model_dpss(devices=[0, 0], batch_slices=1, **kw)
+    _equal_outputs(one, auto, 5, 0.0, skipped=(3,))
+    with pytest.raises(ValueError):
+        calibration.calibrate_and_model_dpss(devices=[0, 0], device_split="times", **kw)
