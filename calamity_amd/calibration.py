@@ -1284,7 +1284,10 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
             permits.acquire()
             return dict(batch=[]) if failed.is_set() else prep(candidates)
 
+        fit_threads = set()
+
         def fit_on(batch, arrs, dev):
+            fit_threads.add(threading.get_ident())
             try:
                 return fit(batch, arrs, on=[dev])
             finally:
@@ -1315,6 +1318,11 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
         finally:
             for pl in pools:
                 pl.shutdown(wait=True)
+            # the fitters of this call's fit threads (kept with the components, keyed by thread): their threads are gone, nobody
+            # could reuse them -- their device memory goes back now
+            cache = prob.__dict__.get("_batch_fitters", {})
+            for key in [k for k in cache if k[4] in fit_threads]:
+                cache.pop(key).close()
     elif len(batches) <= 1:
         for candidates in batches:
             arrs = prep(candidates)
