@@ -19,6 +19,7 @@
 
 #include "fit_kernels.hpp"
 #include "dense_kernels.hpp"
+#include "split_kernels.hpp"
 #include "dense64_kernels.hpp"
 #include "multi_mfma_kernels.hpp"
 #include <cstdlib>
@@ -220,6 +221,7 @@ struct SolverT final : cal_solver {
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
+  bool mf_split = false;                       // fp32: the split-bf16 kernel (split_kernels.hpp: super-panels of 4 panels) instead of fused_dense_kernel
   DevBuf mf_map;                               // [mf_grid] workgroup -> panel (-1: empty slot): XCD-affine dispatch of the dense launch
   int mf_grid = 0;
   size_t mf_lds_grad[2] = {0, 0}, mf_lds_loss[2] = {0, 0};  // per launch class
@@ -445,8 +447,12 @@ struct SolverT final : cal_solver {
     while (pw < 128 && pw < nfreqs) pw *= 2;
     if (fb_used_max > pw) return fail(CAL_ERR_INVALID, "set_problem: internal error: tile width %d exceeds the row padding %d", fb_used_max, pw);
     fpad = (nfreqs + pw - 1) / pw * pw;
-    if (d->kernel_path != CAL_PATH_AUTO && d->kernel_path != CAL_PATH_GENERAL && d->kernel_path != CAL_PATH_DENSE)
+    if (d->kernel_path != CAL_PATH_AUTO && d->kernel_path != CAL_PATH_GENERAL && d->kernel_path != CAL_PATH_DENSE && d->kernel_path != CAL_PATH_DENSE_F32)
       return fail(CAL_ERR_INVALID, "set_problem: bad kernel_path %d", d->kernel_path);
+    if (d->kernel_path == CAL_PATH_DENSE_F32 && !std::is_same<T, float>::value)
+      return fail(CAL_ERR_UNSUPPORTED, "set_problem: CAL_PATH_DENSE_F32 is the fp32 kernel on v_mfma_f32_32x32x2_f32; this solver is fp64");
+    const bool forced_dense = d->kernel_path == CAL_PATH_DENSE || d->kernel_path == CAL_PATH_DENSE_F32;
+    const bool want_split = std::is_same<T, float>::value && d->kernel_path != CAL_PATH_DENSE_F32;
     // dense (matrix-core) path: eligibility, then -- for CAL_PATH_AUTO -- whether the problem fills the chip
     bool dense_ok = layout == CAL_LAYOUT_SHARED && fpad % kChunk == 0;
     for (int g = 0; g < ngrps && dense_ok; ++g) dense_ok = (d->grp_bl_start[g + 1] - d->grp_bl_start[g]) == 1;
@@ -456,18 +462,19 @@ struct SolverT final : cal_solver {
     // ... and its packed operands (two MFMA-native copies of every unique block) with 32-bit byte offsets from one base
     long long dense_op_elems = 0;
     for (int u = 0; u < nbasis && dense_ok; ++u)  // kilobyte positions: forward + adjoint (the same count for both dtypes' layouts up to padding)
-      dense_op_elems += std::is_same<T, float>::value
+      dense_op_elems += want_split ? 2 * split_stream_bytes(fpad, d->basis_nvec[u], kSplitNT) / 4  // (an upper bound: two items per block at most)
+                        : std::is_same<T, float>::value
                             ? (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256 + (long long)(fpad / 32) * ((d->basis_nvec[u] + 31) / 32) * 4 * 256
                             : (long long)(fpad / 16) * ((d->basis_nvec[u] + 7) / 8) * 128 + (long long)(fpad / 16) * ((d->basis_nvec[u] + 15) / 16) * 2 * 128;
-    if (dense_op_elems * (long long)sizeof(T) >= (1LL << 32)) dense_ok = false;
-    if (d->kernel_path == CAL_PATH_DENSE && !dense_ok)
+    if (dense_op_elems * (long long)(want_split ? 4 : sizeof(T)) >= (1LL << 32)) dense_ok = false;
+    if (forced_dense && !dense_ok)
       return fail(CAL_ERR_UNSUPPORTED, "set_problem: CAL_PATH_DENSE needs the SHARED layout, one baseline per fitting group, "
                   "basis_nvec <= %d and nfreqs > 64", DenseCfg<T>::max_nvec);
     // a panel of 16 baselines occupies one CU for 60-70 us whatever the problem size; below ~2000 baselines the panels do
     // not fill the chip and the general kernel (one workgroup per baseline) is 2-3x faster (HERA-37 fp32: 25 vs 71 us)
     // (with a communicator the ranks then agree on ONE path -- the exchange payload of the "sum" regulariser differs between
     // the two -- in set_problem, behind all the rank-local work)
-    const bool want_mfma = dense_ok && d->kernel_path != CAL_PATH_GENERAL && (d->kernel_path == CAL_PATH_DENSE || nbls >= 2048);
+    const bool want_mfma = dense_ok && d->kernel_path != CAL_PATH_GENERAL && (forced_dense || nbls >= 2048);
     lds_bytes = 0;
     for (int u = 0; u < nbasis; ++u) lds_bytes = std::max(lds_bytes, lds_for(fb_u[u]));
     for (int b = 0; b < d->nbls; ++b) {
@@ -636,7 +643,75 @@ struct SolverT final : cal_solver {
       basis_bytes = (double)off / fpad * nfreqs * sizeof(T);
     }
     mf_ok = false;
-    if (want_mfma) {
+    mf_split = false;
+    if (want_mfma && want_split) {
+      if constexpr (std::is_same<T, float>::value) {
+        // ---- fp32, split-bf16 operands (split_kernels.hpp): super-panels of kSpWaves panels (64 baselines) with the same basis block and slice;
+        // an item carries at most kSplitNT vector tiles: a block of more than 128 vectors is two items per super-panel (each with its own packed
+        // stream: the whole forward, half of the adjoint tiles)
+        struct Half { int tile0, ntiles; long long obyte; };
+        std::vector<std::vector<Half>> halves(nbasis);
+        long long obytes = 0;
+        for (int u = 0; u < nbasis; ++u) {
+          const int ntu = (d->basis_nvec[u] + 31) / 32;
+          if (ntu <= kSplitNT) halves[u] = {Half{0, ntu, 0}};
+          else halves[u] = {Half{0, (ntu + 1) / 2, 0}, Half{(ntu + 1) / 2, ntu / 2, 0}};
+          for (Half& h : halves[u]) {
+            h.obyte = obytes;
+            obytes += split_stream_bytes(fpad, d->basis_nvec[u], h.ntiles);
+          }
+        }
+        CAL_TRY(mf_ops.alloc((size_t)obytes, false));
+        for (int u = 0; u < nbasis; ++u)
+          for (const Half& h : halves[u])
+            hipLaunchKernelGGL(split_pack_kernel, dim3(grid_for(split_stream_bytes(fpad, d->basis_nvec[u], h.ntiles) / 6)), dim3(256), 0, stream,
+                               raw.as<float>() + d->basis_offset[u], reinterpret_cast<unsigned short*>(mf_ops.as<unsigned char>() + h.obyte), nfreqs, fpad,
+                               d->basis_nvec[u], h.tile0, h.ntiles);
+        HIP_TRY(hipGetLastError());
+        std::vector<std::vector<int>> by_u((size_t)nbasis * nslices);
+        for (int b = 0; b < nbls; ++b) by_u[(size_t)d->grp_basis[grp_of_bl[b]] * nslices + grp_slice[grp_of_bl[b]]].push_back(b);
+        std::vector<int> uorder((size_t)nbasis * nslices);
+        std::iota(uorder.begin(), uorder.end(), 0);
+        std::stable_sort(uorder.begin(), uorder.end(), [&](int a, int b) { return d->basis_nvec[a / nslices] > d->basis_nvec[b / nslices]; });
+        std::vector<PanelItem> h_panels;
+        std::vector<double> h_cost;
+        const int wide = kPanel * kSpWaves;
+        for (int us : uorder) {
+          const int u = us / nslices;
+          const int nv = d->basis_nvec[u];
+          for (size_t i = 0; i < by_u[us].size(); i += wide) {
+            for (const Half& h : halves[u]) {
+              for (int w = 0; w < kSpWaves; ++w) {
+                PanelItem pi{};
+                pi.slice = us % nslices;
+                for (int k = 0; k < kPanel; ++k) {
+                  const size_t at = i + (size_t)w * kPanel + k;
+                  const int b = at < by_u[us].size() ? by_u[us][at] : -1;
+                  pi.bl[k] = b;
+                  pi.coff[k] = b >= 0 ? h_grp_coff[grp_of_bl[b]] : 0;
+                  pi.ant[k] = b >= 0 ? make_int2(d->bl_ant0[b], d->bl_ant1[b]) : make_int2(0, 0);
+                }
+                pi.a_kf4 = h.obyte / 4;
+                pi.a_fk4 = 0;
+                pi.nvec = nv;
+                pi.nvp2 = (nv + 15) / 16 * 16;
+                pi.nvp32 = 32 * h.ntiles;
+                pi.tile0 = h.tile0;
+                h_panels.push_back(pi);
+              }
+              // an item's time on a CU: per channel-block pair two element stages + its groups of 24 MFMAs
+              h_cost.push_back((fpad / 64) * (3000.0 + 900.0 * split_groups_per_pair(nv, h.ntiles)));
+            }
+          }
+        }
+        CAL_TRY(order_panels(h_panels, h_cost, kSpWaves));
+        mf_lds_grad[0] = mf_lds_loss[0] = split_lds_bytes();
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
+        mf_ok = true;
+        mf_split = true;
+      }
+    } else if (want_mfma) {
       if constexpr (std::is_same<T, float>::value) {
         std::vector<long long> okf4(nbasis + 1, 0), ofk4(nbasis + 1, 0);
         std::vector<int> nvp2(nbasis), nvp32(nbasis);
@@ -1083,7 +1158,7 @@ struct SolverT final : cal_solver {
     gains_snap.release();
     gains_alt.release();
     const size_t cbytes = 2 * (size_t)ncoef * sizeof(T);
-    CAL_TRY(coef.alloc(cbytes));
+    CAL_TRY(coef.alloc(cbytes + 256));  // (the split-bf16 kernel reads whole pairs of 16-vector steps: up to 31 reals past the last group's coefficients)
     CAL_TRY(coef_m.alloc(cbytes));
     CAL_TRY(coef_v.alloc(cbytes));
     coef_snap.release();
@@ -1108,13 +1183,14 @@ struct SolverT final : cal_solver {
   // to ONE of 8 lists, blocks dealt longest-processing-time first so the lists carry equal cost; inside a list the heaviest
   // panels come first (the tail of the pass is made of the lightest).  Workgroup b takes entry b / 8 of list b % 8: the slot
   // map interleaves the lists, -1 where a list is shorter than the longest.  Uploads the records and the map.
-  int order_panels(std::vector<PanelItem>& panels, const std::vector<double>& cost) {
-    const int n = (int)panels.size();
+  // `per` consecutive panel records form one work item (split-bf16 kernel: a super-panel); cost and the map count items.
+  int order_panels(std::vector<PanelItem>& panels, const std::vector<double>& cost, int per = 1) {
+    const int n = (int)panels.size() / per;
     std::vector<long long> keys;
     std::vector<double> kcost;
     std::vector<int> blk(n);
     for (int i = 0; i < n; ++i) {
-      size_t k = std::find(keys.begin(), keys.end(), panels[i].a_kf4) - keys.begin();
+      size_t k = std::find(keys.begin(), keys.end(), panels[(size_t)i * per].a_kf4) - keys.begin();
       if (k == keys.size()) { keys.push_back(panels[i].a_kf4); kcost.push_back(0.0); }
       kcost[k] += cost[i];
       blk[i] = (int)k;
@@ -1139,22 +1215,23 @@ struct SolverT final : cal_solver {
     std::vector<int> h_map(8 * longest, -1);
     for (int x = 0; x < 8; ++x)
       for (size_t j = 0; j < lists[x].size(); ++j) h_map[j * 8 + x] = lists[x][j];
-    mf_npanels = n;
+    const int np = (int)panels.size();
+    mf_npanels = np;
     mf_grid = (int)h_map.size();
     if (nslices > 1) {  // the loss partials (one per panel) of every time slice, in panel order
-      std::vector<int> ptr(nslices + 1, 0), idx(n);
-      for (int i = 0; i < n; ++i) ptr[panels[i].slice + 1]++;
+      std::vector<int> ptr(nslices + 1, 0), idx(np);
+      for (int i = 0; i < np; ++i) ptr[panels[i].slice + 1]++;
       for (int t = 0; t < nslices; ++t) ptr[t + 1] += ptr[t];
       std::vector<int> fill(ptr.begin(), ptr.end() - 1);
-      for (int i = 0; i < n; ++i) idx[fill[panels[i].slice]++] = i;
+      for (int i = 0; i < np; ++i) idx[fill[panels[i].slice]++] = i;
       CAL_TRY(slice_ppart_ptr.alloc(ptr.size() * sizeof(int), false));
       HIP_TRY(hipMemcpyAsync(slice_ppart_ptr.p, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice, stream));
       CAL_TRY(slice_ppart_idx.alloc(idx.size() * sizeof(int), false));
       HIP_TRY(hipMemcpyAsync(slice_ppart_idx.p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, stream));
       HIP_TRY(hipStreamSynchronize(stream));  // (the vectors leave scope)
     }
-    CAL_TRY(mf_panels.alloc((size_t)n * sizeof(PanelItem), false));
-    HIP_TRY(hipMemcpyAsync(mf_panels.p, panels.data(), (size_t)n * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
+    CAL_TRY(mf_panels.alloc((size_t)np * sizeof(PanelItem), false));
+    HIP_TRY(hipMemcpyAsync(mf_panels.p, panels.data(), (size_t)np * sizeof(PanelItem), hipMemcpyHostToDevice, stream));
     CAL_TRY(mf_map.alloc(h_map.size() * sizeof(int), false));
     HIP_TRY(hipMemcpyAsync(mf_map.p, h_map.data(), h_map.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -1477,6 +1554,10 @@ struct SolverT final : cal_solver {
   }
   template <bool GRAD> void launch_dense(MfmaArgs m) {
     m.slot_map = mf_map.as<int>();
+    if (mf_split) {
+      hipLaunchKernelGGL((fused_dense_split_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
+      return;
+    }
     hipLaunchKernelGGL((fused_dense_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
   }
   T* grad_c0() { return gc_direct ? gcp0.as<T>() : gc0.as<T>(); }
@@ -2017,7 +2098,7 @@ struct SolverT final : cal_solver {
     // forward A c and adjoint A^T gbar_v, complex x real: 4 + 4 flops per (channel, vector); the dense path's regularised step
     // runs the forward twice (loss-only pass for S, then the gradient pass) inside the timed region
     out->flops_per_launch = ((mf_ok && reg == CAL_REG_SUM) ? 12.0 : 8.0) * nfreqs * (double)ncoef;
-    out->kernel_path = mf_ok ? CAL_PATH_DENSE : CAL_PATH_GENERAL;
+    out->kernel_path = mf_ok ? ((mf_split || !std::is_same<T, float>::value) ? CAL_PATH_DENSE : CAL_PATH_DENSE_F32) : CAL_PATH_GENERAL;
     // the dense kernels are written for two workgroups per CU (160 KB of LDS): a basis block of ~250 vectors needs more than
     // 80 KB for its coefficient panel + rings and runs one
     out->dense_wg_per_cu = mf_ok ? (mf_lds_grad[0] * 2 <= 160 * 1024 ? 2 : 1) : 0;

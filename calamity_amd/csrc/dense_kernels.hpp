@@ -48,6 +48,8 @@ struct PanelItem {
                       //   [ceil(nvec/8)][64 lanes][4]: lane (c, half), u -> A[32 cb + c][8 g + 2 u + half], then adjoint positions
                       //   [nvp32/32][4][64 lanes][4]: lane (i, half), u -> A[32 cb + 8 q + 4 half + u][32 t + i]
   long long a_fk4;    // (double precision: the adjoint operands are a separate run)
+  int tile0;          // split-bf16 kernel (split_kernels.hpp): the first of the block's vector tiles this item carries (nvp32 / 32 of them)
+  int pad_;
 };
 
 struct MfmaArgs {

@@ -1,0 +1,465 @@
+// split_kernels.hpp -- the dense formulation of the fit step for the SHARED layout (dense_kernels.hpp) on
+// v_mfma_f32_32x32x16_bf16 with split-bf16 operands: the fp32 product a c is formed as
+//     a c ~= a1 c1 + a1 c2 + a2 c1 + a1 c3 + a2 c2 + a3 c1,      x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// (x1 + x2 + x3 == x for a normal fp32 x; every bf16 x bf16 product is exact in the fp32 accumulator; the three dropped terms are
+// <= 2^-24 |a c| each: tools/micro/bf16x3.hip measures the six products MORE accurate than the fp32 MFMA chain they replace, at 2.1-2.2 x its
+// rate).  Same arithmetic as dense_kernels.hpp: fg_model (/root/reference/calamity/calibration.py:1587-1590), data_model (:1593-1604),
+// mse (:1607-1609) and their adjoints, per step of fit_gains_and_foregrounds (:663-668).
+//
+// Partition.  The bf16 instruction is 2.7 x faster per flop and takes three operand planes, so a wave consumes operand bytes four
+// times faster than in the f32 kernel: the basis operands must be SHARED.  A workgroup = 4 waves = a SUPER-PANEL of four panels of 16 baselines
+// with the same basis block; wave w owns panel w (32 columns = (slot, re | im)) for the whole sweep: its coefficient gradients stay in its
+// registers, there is no cross-wave sum.  All four waves walk the same sequence of operand GROUPS (4 positions of 3 KB: three bf16 planes of a
+// 32 x 16 piece of the block each), which stream through ONE LDS ring filled by LDS-DMA: wave w requests position w of every group; per group
+// one counted vmcnt wait for the own request and one s_barrier (which also frees the previous group's slots).  A group is one step of the code:
+// per pair of channel blocks (cb0, cb1 = 2 cp, 2 cp + 1; 32 channels each)
+//   F  per group two K-steps of 16 vectors x two channel blocks: the wave's coefficient operand of the K-step (32 columns x 16 vectors, fp32,
+//      LDS-DMA into a per-wave buffer, split into three planes in registers -- once for BOTH channel blocks), 6 MFMAs each on V(cb0), V(cb1)
+//   E  element stage of cb0 in the accumulator registers, gbar_v split into three planes: the accumulator is, register by register, the B
+//      operand of the adjoint (register 8 q + j of lane (col, half) = channel 16 q + (j & 3) + 8 (j >> 2) + 4 half: the packed adjoint operand is
+//      stored in that k order)
+//   B  per group two vector tiles x two K-steps of 16 channels: 12 MFMAs on dC[t], 12 on dC[t + 1]
+//   E, B of cb1.
+// An item carries at most 4 vector tiles (64 gradient accumulators: two workgroups per CU); a basis block of more than 128 vectors is TWO items
+// per super-panel, each with the whole forward and half of the tiles (the second one writes no loss and no gbar_G).
+// Vector-memory accounting: every asm request is counted (`issued`), every awaited request remembers the count at its issue, and a wait is
+// s_waitcnt vmcnt(issued - mark) -- a jump into a table of s_waitcnt instructions (the instruction takes an immediate).  Operations the compiler
+// issues itself (gain loads, gbar_G stores) are not in the count: they only make a wait stricter -- towards OLDER operations -- never weaker.
+#pragma once
+#include "dense_kernels.hpp"
+
+namespace calk {
+
+constexpr int kSpWaves = 4;            // panels (waves) per super-panel
+constexpr int kPosBytes = 3072;        // one operand position: [3 planes][64 lanes][16 B]
+constexpr int kGroupBytes = 4 * kPosBytes;
+#ifndef CAL_SPLIT_RING
+#define CAL_SPLIT_RING 3
+#endif
+constexpr int kSpRing = CAL_SPLIT_RING;  // groups in the operand ring
+constexpr int kSpCBytes = 4096;          // per-wave coefficient buffer: two K-steps x (32 columns x 16 vectors) fp32
+constexpr int kSplitNT = 4;              // vector tiles per item
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+inline size_t split_lds_bytes() { return (size_t)kSpRing * kGroupBytes + (size_t)kSpWaves * kSpCBytes + (size_t)kSpWaves * kSmpBytes; }
+// groups of one item's packed stream per channel-block pair: forward (two K-steps each), then the adjoint of cb0 and of cb1 (two tiles each)
+inline int split_groups_per_pair(int nvec, int ntiles) { return ((nvec + 15) / 16 + 1) / 2 + 2 * ((ntiles + 1) / 2); }
+inline long long split_stream_bytes(int fpad, int nvec, int ntiles) { return (long long)(fpad / 64) * split_groups_per_pair(nvec, ntiles) * kGroupBytes; }
+
+// s_waitcnt vmcnt(n), n wave-uniform at run time: a jump into a table of (s_waitcnt vmcnt(k); s_branch end) pairs.  ONE asm statement: the
+// compiler sees no control flow (a switch at every wait made the kernel's flow graph -- and its register allocation -- unmanageable).
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+  n = n < 0 ? 0 : (n > 31 ? 31 : n);  // more outstanding requests than the table holds: the wait is stricter, never weaker
+  n = __builtin_amdgcn_readfirstlane(n);  // (hipcc hands an "s" operand it computed in the vector ALU to the asm as a VGPR)
+  asm volatile(
+      "s_getpc_b64 s[98:99]\n\t"        // = address of the next instruction
+      "s_lshl_b32 s97, %0, 3\n\t"       // 8 bytes per table entry
+      "s_add_u32 s97, s97, 20\n\t"      // the five 4-byte instructions from here to the table
+      "s_add_u32 s98, s98, s97\n\t"
+      "s_addc_u32 s99, s99, 0\n\t"
+      "s_setpc_b64 s[98:99]\n\t"
+#define CAL_WV(N) "s_waitcnt vmcnt(" #N ")\n\ts_branch .Lcal_wv_end%=\n\t"
+      CAL_WV(0) CAL_WV(1) CAL_WV(2) CAL_WV(3) CAL_WV(4) CAL_WV(5) CAL_WV(6) CAL_WV(7) CAL_WV(8) CAL_WV(9) CAL_WV(10) CAL_WV(11)
+      CAL_WV(12) CAL_WV(13) CAL_WV(14) CAL_WV(15) CAL_WV(16) CAL_WV(17) CAL_WV(18) CAL_WV(19) CAL_WV(20) CAL_WV(21) CAL_WV(22)
+      CAL_WV(23) CAL_WV(24) CAL_WV(25) CAL_WV(26) CAL_WV(27) CAL_WV(28) CAL_WV(29) CAL_WV(30) CAL_WV(31)
+#undef CAL_WV
+      ".Lcal_wv_end%=:"
+      :
+      : "s"(n)
+      : "memory", "s97", "s98", "s99", "scc");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// x (8 fp32) -> three bf16 planes, round to nearest even at every level (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h1 = (__bf16)x[j];
+    const float r1 = x[j] - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const float r2 = r1 - (float)h2;
+    p1[j] = h1;
+    p2[j] = h2;
+    p3[j] = (__bf16)r2;
+  }
+}
+
+#define CAL_MFMA_BF16(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
+
+typedef float cf2 __attribute__((ext_vector_type(2)));  // (re, im): complex arithmetic as packed fp32 (v_pk_mul / v_pk_fma with op_sel)
+__device__ __forceinline__ cf2 cmul(cf2 a, cf2 b) { return a.xx * b + cf2{-a.y, a.y} * b.yx; }       // a b
+__device__ __forceinline__ cf2 cmul_conj(cf2 a, cf2 b) { return b.xx * a + cf2{b.y, -b.y} * a.yx; }  // a conj(b)
+
+template <bool GRAD>
+__device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* smem_raw) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int NTMAX = kSplitNT;
+  const int sp = A.slot_map[blockIdx.x];  // never negative here
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const PanelItem& P = A.panels[sp * kSpWaves + wave];  // this wave's panel (padding panels of a super-panel: every slot -1, the block's nvec / operands)
+  const int col = lane & 31, half = lane >> 5, slot = col & 15;
+  const bool im_lane = (col & 16) != 0;
+  const int my_bl = P.bl[slot];
+  const int2 my_ant = P.ant[slot];
+  const int my_coff = P.coff[slot];
+  const int nvec = __builtin_amdgcn_readfirstlane(P.nvec);
+  const int NT = __builtin_amdgcn_readfirstlane(P.nvp32 / 32);  // vector tiles of THIS item (<= kSplitNT), the first one being tile0 of the block
+  const int tile0 = __builtin_amdgcn_readfirstlane(P.tile0);
+  const bool primary = tile0 == 0;   // the item that owns the loss and gbar_G of its baselines
+  const int ngk = (nvec + 15) / 16;  // forward K-steps of 16 vectors
+  const int ngd = (ngk + 1) / 2;     // forward groups
+  const int ntd = (NT + 1) / 2;      // adjoint groups per channel block
+  const int ncp = A.fpad / 64;       // channel-block pairs
+  const DevState* sst = A.state;
+  if (A.nslices > 1) sst += P.slice;
+  const int stopped = __builtin_amdgcn_readfirstlane(sst->done | sst->done_after);
+  if (stopped) return;  // (the four panels of a super-panel belong to one slice: workgroup-uniform)
+
+  unsigned char* s_ring = smem_raw;                                 // [kSpRing groups][4 positions][3 KB]
+  unsigned char* s_cr = smem_raw + kSpRing * kGroupBytes;           // [4 waves][4 KB]
+  unsigned char* s_smp = s_cr + kSpWaves * kSpCBytes;               // [4 waves][6 KB]
+  const f32x4* ops = reinterpret_cast<const f32x4*>(A.ops);
+  const unsigned voff = (unsigned)lane * 16u;
+  const unsigned ring_lds = (unsigned)reinterpret_cast<unsigned long long>(s_ring);
+  const f32x4* ring_rd = reinterpret_cast<const f32x4*>(s_ring) + lane;
+  const unsigned cr_lds = (unsigned)reinterpret_cast<unsigned long long>(s_cr + wave * kSpCBytes);
+  const f32x4* cr_rd = reinterpret_cast<const f32x4*>(s_cr + wave * kSpCBytes) + lane;
+
+  int issued = 0;  // vector-memory requests this wave has issued through asm
+
+  // ---- the operand stream: per channel-block pair GP groups, [ngd forward][ntd adjoint of cb0][ntd adjoint of cb1]; the gradient pass
+  // consumes all of them in order, the loss-only pass the forward groups.  Wave w requests position w of a group; past the end the last
+  // group again (the number of requests in flight stays what the marks assume).
+  const int GP = ngd + 2 * ntd;
+  const int g_used = GRAD ? GP : ngd;
+  const unsigned base = (unsigned)P.a_kf4 * 4u + (unsigned)wave * (unsigned)kPosBytes;
+  int rq_cp = 0, rq_d = 0;  // the group this wave requests next
+  int rq_slot = 0;          // ring slot it goes to
+  auto request_group = [&]() {
+    const unsigned off = base + (unsigned)(rq_cp * GP + rq_d) * (unsigned)kGroupBytes;
+    const unsigned lds = ring_lds + (unsigned)(rq_slot * 4 + wave) * (unsigned)kPosBytes;
+    ring_issue(lds, ops, voff, off);
+    ring_issue(lds + 1024u, ops, voff, off + 1024u);
+    ring_issue(lds + 2048u, ops, voff, off + 2048u);
+    issued += 3;
+    if (rq_cp < ncp - 1 || rq_d < g_used - 1) {
+      ++rq_d;
+      if (rq_d == g_used) { rq_d = 0; ++rq_cp; }
+    }
+    rq_slot = rq_slot + 1 == kSpRing ? 0 : rq_slot + 1;
+  };
+  int markA[kSpRing - 1];  // issue counts of the group requests in flight, oldest first
+  // ---- the coefficient operand of a forward group (two K-steps): 4 KB, request i = 0..3 brings K-step i >> 1, vectors 4 (i & 1) .. + 3 of
+  // lane L's eight: c[col L & 31][16 kk + 8 (L >> 5) + 4 (i & 1) ..]
+  const f32x4* cbase = reinterpret_cast<const f32x4*>(A.c_r);
+  const unsigned c_voff = (unsigned)((im_lane ? (int)(A.c_i - A.c_r) : 0) + my_coff + 8 * half) * 4u;
+  int c_d = 0;  // forward group of the next request
+  int markC = 0;
+  auto request_c = [&]() {
+    const unsigned off = (unsigned)c_d * 128u;  // 32 vectors x 4 B
+    ring_issue(cr_lds, cbase, c_voff, off);
+    ring_issue(cr_lds + 1024u, cbase, c_voff, off + 16u);
+    ring_issue(cr_lds + 2048u, cbase, c_voff, off + 64u);
+    ring_issue(cr_lds + 3072u, cbase, c_voff, off + 80u);
+    issued += 4;
+    markC = issued;
+    c_d = c_d + 1 == ngd ? 0 : c_d + 1;
+  };
+  // ---- samples of one channel block (as dense_kernels.hpp): request k fetches array k / 2, register groups 2 (k & 1) + (lane >> 5)
+  const unsigned row = (unsigned)(my_bl >= 0 ? my_bl : A.nbls);
+  const unsigned smp_lds = (unsigned)reinterpret_cast<unsigned long long>(s_smp + wave * kSmpBytes);
+  const unsigned smp_voff = (row * (unsigned)A.fpad + 4u * ((unsigned)(lane >> 4) & 1u)) * 4u + (unsigned)(lane >> 5) * 32u;
+  const unsigned char* smp_rd = s_smp + wave * kSmpBytes + (slot + 16 * half) * 16 + (im_lane ? 8 : 0);
+  int markS = 0;
+  auto smp_issue = [&](int cb) {
+    const unsigned o = (unsigned)cb * (kCB * 4u);
+    ring_issue(smp_lds + 0u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o);
+    ring_issue(smp_lds + 1u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o + 64u);
+    ring_issue(smp_lds + 2u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o);
+    ring_issue(smp_lds + 3u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o + 64u);
+    ring_issue(smp_lds + 4u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o);
+    ring_issue(smp_lds + 5u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o + 64u);
+    issued += 6;
+    markS = issued;
+  };
+
+  RING_WAIT(0);  // the record loads above are the compiler's: nothing of them is in flight when the counting starts
+  smp_issue(0);
+#pragma unroll
+  for (int j = 0; j < kSpRing - 1; ++j) {
+    request_group();
+    markA[j] = issued;
+  }
+  request_c();
+
+  // one step of the code = one group: wait for the wave's own request of it, meet the other waves (their requests have landed too, and they
+  // have left the previous group), request the group kSpRing - 1 ahead into the slots just freed
+  int cur_slot = 0;
+  auto group_begin = [&]() -> int {  // -> f32x4 index (without the lane) of the group's first plane
+    wait_vm_dyn(issued - markA[0]);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j + 1 < kSpRing - 1; ++j) markA[j] = markA[j + 1];
+    request_group();
+    markA[kSpRing - 2] = issued;
+    __builtin_amdgcn_sched_barrier(0);
+    const int at = cur_slot * (kGroupBytes / 16);
+    cur_slot = cur_slot + 1 == kSpRing ? 0 : cur_slot + 1;
+    return at;
+  };
+
+  f32x16 dC[NTMAX];
+#pragma unroll
+  for (int t = 0; t < NTMAX; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dC[t][j] = 0.f;
+  double loss_acc = 0.0, sr_acc = 0.0, si_acc = 0.0;
+  const cf2 alpha = A.use_alpha ? cf2{(float)sst->alpha_r, (float)sst->alpha_i} : cf2{0.f, 0.f};
+  const char* p_g = reinterpret_cast<const char*>(A.gains);
+  char* p_q = reinterpret_cast<char*>(A.q0);
+  // this lane's two channels of every register group: + 0, 1 on the re lane, + 2, 3 on the im lane (see the element stage)
+  const unsigned chan0 = 4u * half + (im_lane ? 2u : 0u);
+  const unsigned obq = (row * (unsigned)A.fpad + chan0) * 8u;                 // gbar_G, (re, im) pairs
+  const unsigned og0 = ((unsigned)my_ant.x * (unsigned)A.fpad + chan0) * 8u;  // gains
+  const unsigned og1 = ((unsigned)my_ant.y * (unsigned)A.fpad + chan0) * 8u;
+
+  // ---- E: element stage of one channel block on its forward accumulator (calibration.py:1593-1609 and their adjoints).  Lane (col, half) holds
+  // v of column col = (slot, re | im) at 16 channels: register 4 g + r -> channel 8 g + 4 half + r.  The re and im lane of a slot sit 16 lanes
+  // apart and share the work: v_permlane16_swap(acc[4 g + i], acc[4 g + i + 2]) hands the re lane (re, im) of channel i and the im lane (re, im)
+  // of channel i + 2; after the arithmetic ONE more swap of (gbar_v.re, gbar_v.im) puts gbar_v back in the layout v had (the re lane keeps the
+  // real part of its channel and receives the real part of the im lane's channel; the im lane the imaginary parts), no selects.
+  auto element_stage = [&](f32x16& acc, int cb, int next_cb) {
+    const unsigned cb8 = (unsigned)cb * (kCB * 8u);
+    cf2 lt = {0.f, 0.f}, st = {0.f, 0.f};
+    wait_vm_dyn(issued - markS);
+    f32x4 ga_n = *reinterpret_cast<const f32x4*>(p_g + (og0 + cb8));
+    f32x4 gb_n = *reinterpret_cast<const f32x4*>(p_g + (og1 + cb8));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 ga = ga_n, gb = gb_n;
+      if (g < 3) {  // the next register group's gains (they come from L2)
+        ga_n = *reinterpret_cast<const f32x4*>(p_g + (og0 + cb8 + 64u * (g + 1)));
+        gb_n = *reinterpret_cast<const f32x4*>(p_g + (og1 + cb8 + 64u * (g + 1)));
+      }
+      // this register group's samples, read when they are needed (all four groups up front cost more registers than the kernel has)
+      const int so = ((g >> 1) * 64 + 32 * (g & 1)) * 16;
+      const cf2 s_dr = *reinterpret_cast<const cf2*>(smp_rd + so);
+      const cf2 s_di = *reinterpret_cast<const cf2*>(smp_rd + 2048 + so);
+      const cf2 s_w = *reinterpret_cast<const cf2*>(smp_rd + 4096 + so);
+      f32x4 qs;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        // (bit_cast applied to a vector ELEMENT expression reads element 0 with this hipcc: go through scalars)
+        const float xa = acc[4 * g + i], xb = acc[4 * g + i + 2];
+        const u2 pr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, xb), false, false);
+        const unsigned p0 = pr[0], p1 = pr[1];
+        const cf2 v = {__builtin_bit_cast(float, p0), __builtin_bit_cast(float, p1)};
+        const cf2 d = {s_dr[i], s_di[i]};
+        const float w = s_w[i];
+        const cf2 g0 = {ga[2 * i], ga[2 * i + 1]}, g1 = {gb[2 * i], gb[2 * i + 1]};
+        const cf2 G = cmul_conj(g0, g1);  // g_i conj(g_j)  (calibration.py:1598-1601)
+        const cf2 m = cmul(G, v);
+        const cf2 r = d - m;
+        lt += (r * r) * w;
+        st += m * w;  // S = sum w m of the "sum" regulariser (calibration.py:1648-1649)
+        if (GRAD) {
+          const cf2 e = (r * -2.f + alpha) * w;
+          const cf2 gv = cmul_conj(e, G);  // gbar_v = conj(G) e
+          const cf2 gq = cmul_conj(e, v);  // gbar_G = conj(v) e
+          const float gvx = gv.x, gvy = gv.y;
+          const u2 qr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, gvx), __builtin_bit_cast(unsigned, gvy), false, false);
+          const unsigned q0b = qr[0], q1b = qr[1];
+          acc[4 * g + i] = __builtin_bit_cast(float, q0b);
+          acc[4 * g + i + 2] = __builtin_bit_cast(float, q1b);
+          qs[2 * i] = gq.x;
+          qs[2 * i + 1] = gq.y;
+        }
+      }
+      if (GRAD && primary) *reinterpret_cast<f32x4*>(p_q + (obq + cb8 + 64u * g)) = qs;
+      __builtin_amdgcn_sched_barrier(0);  // one register group at a time
+    }
+    if (primary) {
+      loss_acc += (double)(lt.x + lt.y);
+      sr_acc += (double)st.x;
+      si_acc += (double)st.y;
+    }
+    if (next_cb >= 0) {
+      // the staging area is free once the reads above have returned: the next block's samples go into it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      smp_issue(next_cb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // ---- B: adjoint of one channel block: dC[t] += A[ch, 32 t ...]^T gbar_v, a group = two tiles x two K-steps of 16 channels
+  auto adjoint = [&](const f32x16& acc) {
+    bf16x8 g1[2], g2[2], g3[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = acc[8 * q + j];
+      split3(x, g1[q], g2[q], g3[q]);
+    }
+#pragma unroll
+    for (int e = 0; e < NTMAX / 2; ++e) {
+      if (e < ntd) {  // wave-uniform
+        const int at = group_begin();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          if (2 * e + tt < NT) {  // wave-uniform
+            f32x16& D = dC[2 * e + tt];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int o = at + ((2 * tt + q) * 3) * 64;
+              const bf16x8 a1 = __builtin_bit_cast(bf16x8, ring_rd[o]), a2 = __builtin_bit_cast(bf16x8, ring_rd[o + 64]),
+                           a3 = __builtin_bit_cast(bf16x8, ring_rd[o + 128]);
+              CAL_MFMA_BF16(a3, g1[q], D);
+              CAL_MFMA_BF16(a2, g2[q], D);
+              CAL_MFMA_BF16(a1, g3[q], D);
+              CAL_MFMA_BF16(a2, g1[q], D);
+              CAL_MFMA_BF16(a1, g2[q], D);
+              CAL_MFMA_BF16(a1, g1[q], D);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  for (int cp = 0; cp < ncp; ++cp) {
+    // ---- F: V(cb0), V(cb1) = A[ch, :] . C
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+    for (int d = 0; d < ngd; ++d) {
+      const int at = group_begin();
+      // the two K-steps' coefficients: wait for the buffer, read it; once the reads have returned it is requested again for the next group
+      wait_vm_dyn(issued - markC);
+      f32x4 cq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cq[j] = cr_rd[j * 64];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      request_c();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks == 0 || 2 * d + 1 < ngk) {  // wave-uniform: the second K-step of the last group may lie past the block's vectors
+          bf16x8 c1, c2, c3;
+          {
+            const float x[8] = {cq[2 * ks][0], cq[2 * ks][1], cq[2 * ks][2], cq[2 * ks][3], cq[2 * ks + 1][0], cq[2 * ks + 1][1], cq[2 * ks + 1][2], cq[2 * ks + 1][3]};
+            split3(x, c1, c2, c3);
+          }
+          bf16x8 a0[3], a1[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            a0[p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks) * 3 + p) * 64]);
+            a1[p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks + 1) * 3 + p) * 64]);
+          }
+          CAL_MFMA_BF16(a0[2], c1, acc0);
+          CAL_MFMA_BF16(a1[2], c1, acc1);
+          CAL_MFMA_BF16(a0[1], c2, acc0);
+          CAL_MFMA_BF16(a1[1], c2, acc1);
+          CAL_MFMA_BF16(a0[0], c3, acc0);
+          CAL_MFMA_BF16(a1[0], c3, acc1);
+          CAL_MFMA_BF16(a0[1], c1, acc0);
+          CAL_MFMA_BF16(a1[1], c1, acc1);
+          CAL_MFMA_BF16(a0[0], c2, acc0);
+          CAL_MFMA_BF16(a1[0], c2, acc1);
+          CAL_MFMA_BF16(a0[0], c1, acc0);
+          CAL_MFMA_BF16(a1[0], c1, acc1);
+        }
+      }
+    }
+    element_stage(acc0, 2 * cp, 2 * cp + 1);
+    if (GRAD) adjoint(acc0);
+    element_stage(acc1, 2 * cp + 1, cp + 1 < ncp ? 2 * cp + 2 : -1);
+    if (GRAD) adjoint(acc1);
+  }
+  RING_WAIT(0);  // nothing may still be writing into this workgroup's LDS when it ends
+
+  // ---- epilogue: the panel's loss partials (double), then its coefficient gradients -- the wave owns them completely
+  {
+    const double l = ldsum(loss_acc), sr = ldsum(sr_acc), si = ldsum(si_acc);
+    if (lane == 0) {
+      const size_t pi = (size_t)(sp * kSpWaves + wave) * 4;
+      A.part[pi + 0] = l;
+      A.part[pi + 1] = sr;
+      A.part[pi + 2] = si;
+    }
+  }
+  if (!GRAD) return;
+  if (my_bl >= 0) {
+    float* gc = (im_lane ? A.gc_i : A.gc_r) + my_coff + 32 * tile0;
+    const int nleft = nvec - 32 * tile0;
+#pragma unroll
+    for (int t = 0; t < NTMAX; ++t) {
+      if (t < NT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n0 = 32 * t + 8 * i + 4 * half;  // registers 4 i .. 4 i + 3 = vectors n0 .. n0 + 3 of the item
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            if (n0 + jj < nleft) gc[n0 + jj] = dC[t][4 * i + jj];
+        }
+      }
+    }
+  }
+}
+
+// One launch for all items; XCD-affine dispatch through slot_map as fused_dense_kernel.
+template <bool GRAD>
+__global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_split_kernel(const MfmaArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int sp = A.slot_map[blockIdx.x];
+  if (sp < 0) return;
+  split_panel<GRAD>(A, smem_raw);
+}
+
+// packed split-bf16 operands of one item class of a basis block (tiles tile0 .. tile0 + ntiles - 1 of its vectors): groups of 4 positions of
+// 3 KB = [3 planes][64 lanes][8 bf16]; per channel-block pair cp, with lane = (row, kg) and j = 0..7
+//   forward group d, position 2 ks + s      -> A[32 (2 cp + s) + row][16 (2 d + ks) + 8 kg + j]
+//   adjoint group e of channel block s (after the ngd forward groups: ngd + s ntd + e), position 2 tt + q
+//                                           -> A[32 (2 cp + s) + 16 q + (j & 3) + 8 (j >> 2) + 4 kg][32 (tile0 + 2 e + tt) + row]
+// zero outside the block (channels >= nfreqs, vectors >= nvec, tiles >= tile0 + ntiles)
+__global__ void split_pack_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int nfreqs, int fpad, int nvec, int tile0, int ntiles) {
+  const int ngk = (nvec + 15) / 16, ngd = (ngk + 1) / 2, ntd = (ntiles + 1) / 2;
+  const int GP = ngd + 2 * ntd;
+  const long long total = (long long)(fpad / 64) * GP * 4 * 512;  // (position, lane, j)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+    const long long pos = i >> 9;
+    const int p = (int)(pos & 3);
+    const long long grp = pos >> 2;
+    const int cp = (int)(grp / GP), gi = (int)(grp % GP);
+    const int row = l & 31, kg = l >> 5;
+    int f, k;
+    if (gi < ngd) {
+      f = 32 * (2 * cp + (p & 1)) + row;
+      k = 16 * (2 * gi + (p >> 1)) + 8 * kg + j;
+    } else {
+      const int s = (gi - ngd) / ntd, e = (gi - ngd) % ntd;
+      const int tt = p >> 1, q = p & 1;
+      f = 32 * (2 * cp + s) + 16 * q + (j & 3) + 8 * (j >> 2) + 4 * kg;
+      k = 2 * e + tt < ntiles ? 32 * (tile0 + 2 * e + tt) + row : nvec;
+    }
+    float x = 0.f;
+    if (f < nfreqs && k < nvec) x = src[(long long)f * nvec + k];
+    const __bf16 h1 = (__bf16)x;
+    const float r1 = x - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const __bf16 h3 = (__bf16)(r1 - (float)h2);
+    unsigned short* o = dst + pos * 1536 + l * 8 + j;
+    o[0] = __builtin_bit_cast(unsigned short, h1);
+    o[512] = __builtin_bit_cast(unsigned short, h2);
+    o[1024] = __builtin_bit_cast(unsigned short, h3);
+  }
+}
+
+}  // namespace calk

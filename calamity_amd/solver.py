@@ -66,7 +66,8 @@ class HipFitSolver:
 
     # ---- problem -------------------------------------------------------------------------------------------
     def set_problem(self, prob: FitProblem, layout="stream", kernel_path="auto"):
-        """``kernel_path``: "auto" (dense matrix-core kernel when eligible and large enough), "general" or "dense"."""
+        """``kernel_path``: "auto" (dense matrix-core kernel when eligible and large enough), "general", "dense", or
+        "dense_f32" (fp32: the v_mfma_f32_32x32x2_f32 kernel the split-bf16 one replaced)."""
         prob.validate()
         basis = [np.ascontiguousarray(b, dtype=self.dtype) for b in prob.basis]
         sizes = np.asarray([b.size for b in basis], dtype=np.int64)
@@ -91,7 +92,8 @@ class HipFitSolver:
             grp_basis=_ptr(keep[4]), grp_bl_start=_ptr(keep[5]), bl_ant0=_ptr(keep[6]), bl_ant1=_ptr(keep[7]),
             bl_rowblk=_ptr(keep[8]), bl_alias=_ptr(keep[9]), nslices=int(getattr(prob, "nslices", 1) or 1), grp_var=_ptr(keep[10]),
             layout={"stream": _lib.CAL_LAYOUT_STREAM, "shared": _lib.CAL_LAYOUT_SHARED}[layout],
-            kernel_path={"auto": _lib.CAL_PATH_AUTO, "general": _lib.CAL_PATH_GENERAL, "dense": _lib.CAL_PATH_DENSE}[kernel_path],
+            kernel_path={"auto": _lib.CAL_PATH_AUTO, "general": _lib.CAL_PATH_GENERAL, "dense": _lib.CAL_PATH_DENSE,
+                         "dense_f32": _lib.CAL_PATH_DENSE_F32}[kernel_path],
         )
         _lib.check(self._lib.cal_solver_set_problem(self._h, C.byref(d)))
         self.problem = prob
@@ -235,7 +237,7 @@ class HipFitSolver:
         _lib.check(self._lib.cal_solver_timing_get(self._h, C.byref(t)))
         return dict(launches=t.launches, total_ms=t.total_ms, algorithmic_bytes_per_launch=t.algorithmic_bytes_per_launch,
                     basis_bytes_per_launch=t.basis_bytes_per_launch, flops_per_launch=t.flops_per_launch,
-                    kernel_path={_lib.CAL_PATH_GENERAL: "general", _lib.CAL_PATH_DENSE: "dense"}[t.kernel_path],
+                    kernel_path={_lib.CAL_PATH_GENERAL: "general", _lib.CAL_PATH_DENSE: "dense", _lib.CAL_PATH_DENSE_F32: "dense_f32"}[t.kernel_path],
                     dense_wg_per_cu=t.dense_wg_per_cu)
 
     def memory_bytes(self):
