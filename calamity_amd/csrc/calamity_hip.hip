@@ -2209,6 +2209,7 @@ extern "C" {
 
 
 #ifdef CAL_STAMP
+int cal_debug_read_split_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(calk::g_split_stamps), sizeof(calk::g_split_stamps)); }
 int cal_debug_read_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(calk::g_dense_stamps), sizeof(calk::g_dense_stamps)); }
 #endif
 const char* cal_last_error(void) { return g_err.c_str(); }

@@ -72,7 +72,15 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
 }
 
 // x (8 fp32) -> three bf16 planes, round to nearest even at every level (v_cvt_pk_bf16_f32)
+template <bool CHEAP = false>
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+  if (CHEAP) {  // (ablation builds: one conversion, the other planes copies)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p1[j] = (__bf16)x[j];
+    p2 = p1;
+    p3 = p1;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const __bf16 h1 = (__bf16)x[j];
@@ -85,17 +93,55 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& p1, bf16x8& 
   }
 }
 
+// ring_issue (dense_kernels.hpp) with the non-temporal hint: data read once per pass (samples) must not displace the operand stream in L2
+__device__ __forceinline__ void ring_issue_nt(unsigned lds_slot, const f32x4_t* sbase, unsigned lane_bytes, unsigned item_bytes) {
+  const unsigned vo = lane_bytes + item_bytes;
+  sbase = uniform_ptr(sbase);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_slot), "v"(vo), "s"(sbase)
+               : "memory");
+}
+#ifdef CAL_X_SMPNT
+#define SMP_ISSUE ring_issue_nt
+#else
+#define SMP_ISSUE ring_issue
+#endif
+#ifdef CAL_X_CNT
+#define C_ISSUE ring_issue_nt
+#else
+#define C_ISSUE ring_issue
+#endif
+
 #define CAL_MFMA_BF16(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
 
 typedef float cf2 __attribute__((ext_vector_type(2)));  // (re, im): complex arithmetic as packed fp32 (v_pk_mul / v_pk_fma with op_sel)
 __device__ __forceinline__ cf2 cmul(cf2 a, cf2 b) { return a.xx * b + cf2{-a.y, a.y} * b.yx; }       // a b
 __device__ __forceinline__ cf2 cmul_conj(cf2 a, cf2 b) { return b.xx * a + cf2{b.y, -b.y} * a.yx; }  // a conj(b)
 
+#ifdef CAL_STAMP
+// diagnostic build only: [item][wave][F, E, B, group waits + barriers, coefficient waits, sample waits, entry time, exit time, HW_ID, XCC_ID] in s_memtime ticks
+__device__ long long g_split_stamps[4096][4][14];
+#define SPL_T(var) const long long var = (long long)__builtin_amdgcn_s_memtime()
+#define SPL_ADD(acc, t0)                                             \
+  do {                                                               \
+    acc += (long long)__builtin_amdgcn_s_memtime() - (t0);           \
+  } while (0)
+#else
+#define SPL_T(var)
+#define SPL_ADD(acc, t0)
+#endif
+
 template <bool GRAD>
 __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* smem_raw) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int NTMAX = kSplitNT;
   const int sp = A.slot_map[blockIdx.x];  // never negative here
+  SPL_T(t_entry);
+#ifdef CAL_STAMP
+  long long cyc_f = 0, cyc_e = 0, cyc_b = 0, cyc_sync = 0, cyc_cw = 0, cyc_sw = 0, cyc_eg = 0, cyc_el = 0, cyc_es = 0, cyc_bs = 0;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,7 +185,11 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   int rq_cp = 0, rq_d = 0;  // the group this wave requests next
   int rq_slot = 0;          // ring slot it goes to
   auto request_group = [&]() {
+#ifdef CAL_X_A0  // (ablation: every pair re-reads the first pair's groups -- an operand stream that always hits L2)
+    const unsigned off = base + (unsigned)(rq_d) * (unsigned)kGroupBytes;
+#else
     const unsigned off = base + (unsigned)(rq_cp * GP + rq_d) * (unsigned)kGroupBytes;
+#endif
     const unsigned lds = ring_lds + (unsigned)(rq_slot * 4 + wave) * (unsigned)kPosBytes;
     ring_issue(lds, ops, voff, off);
     ring_issue(lds + 1024u, ops, voff, off + 1024u);
@@ -155,15 +205,19 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   // ---- the coefficient operand of a forward group (two K-steps): 4 KB, request i = 0..3 brings K-step i >> 1, vectors 4 (i & 1) .. + 3 of
   // lane L's eight: c[col L & 31][16 kk + 8 (L >> 5) + 4 (i & 1) ..]
   const f32x4* cbase = reinterpret_cast<const f32x4*>(A.c_r);
+#ifdef CAL_X_C0  // (ablation: every panel reads the same coefficients)
+  const unsigned c_voff = (unsigned)((im_lane ? (int)(A.c_i - A.c_r) : 0) + 8 * half) * 4u;
+#else
   const unsigned c_voff = (unsigned)((im_lane ? (int)(A.c_i - A.c_r) : 0) + my_coff + 8 * half) * 4u;
+#endif
   int c_d = 0;  // forward group of the next request
   int markC = 0;
   auto request_c = [&]() {
     const unsigned off = (unsigned)c_d * 128u;  // 32 vectors x 4 B
-    ring_issue(cr_lds, cbase, c_voff, off);
-    ring_issue(cr_lds + 1024u, cbase, c_voff, off + 16u);
-    ring_issue(cr_lds + 2048u, cbase, c_voff, off + 64u);
-    ring_issue(cr_lds + 3072u, cbase, c_voff, off + 80u);
+    C_ISSUE(cr_lds, cbase, c_voff, off);
+    C_ISSUE(cr_lds + 1024u, cbase, c_voff, off + 16u);
+    C_ISSUE(cr_lds + 2048u, cbase, c_voff, off + 64u);
+    C_ISSUE(cr_lds + 3072u, cbase, c_voff, off + 80u);
     issued += 4;
     markC = issued;
     c_d = c_d + 1 == ngd ? 0 : c_d + 1;
@@ -171,17 +225,22 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   // ---- samples of one channel block (as dense_kernels.hpp): request k fetches array k / 2, register groups 2 (k & 1) + (lane >> 5)
   const unsigned row = (unsigned)(my_bl >= 0 ? my_bl : A.nbls);
   const unsigned smp_lds = (unsigned)reinterpret_cast<unsigned long long>(s_smp + wave * kSmpBytes);
-  const unsigned smp_voff = (row * (unsigned)A.fpad + 4u * ((unsigned)(lane >> 4) & 1u)) * 4u + (unsigned)(lane >> 5) * 32u;
+#ifdef CAL_X_S0  // (ablation: every panel reads the samples of baselines 0..15)
+  const unsigned srow = (unsigned)slot;
+#else
+  const unsigned srow = row;
+#endif
+  const unsigned smp_voff = (srow * (unsigned)A.fpad + 4u * ((unsigned)(lane >> 4) & 1u)) * 4u + (unsigned)(lane >> 5) * 32u;
   const unsigned char* smp_rd = s_smp + wave * kSmpBytes + (slot + 16 * half) * 16 + (im_lane ? 8 : 0);
   int markS = 0;
   auto smp_issue = [&](int cb) {
     const unsigned o = (unsigned)cb * (kCB * 4u);
-    ring_issue(smp_lds + 0u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o);
-    ring_issue(smp_lds + 1u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o + 64u);
-    ring_issue(smp_lds + 2u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o);
-    ring_issue(smp_lds + 3u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o + 64u);
-    ring_issue(smp_lds + 4u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o);
-    ring_issue(smp_lds + 5u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o + 64u);
+    SMP_ISSUE(smp_lds + 0u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o);
+    SMP_ISSUE(smp_lds + 1u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o + 64u);
+    SMP_ISSUE(smp_lds + 2u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o);
+    SMP_ISSUE(smp_lds + 3u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o + 64u);
+    SMP_ISSUE(smp_lds + 4u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o);
+    SMP_ISSUE(smp_lds + 5u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o + 64u);
     issued += 6;
     markS = issued;
   };
@@ -199,9 +258,11 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   // have left the previous group), request the group kSpRing - 1 ahead into the slots just freed
   int cur_slot = 0;
   auto group_begin = [&]() -> int {  // -> f32x4 index (without the lane) of the group's first plane
+    SPL_T(ts0);
     wait_vm_dyn(issued - markA[0]);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    SPL_ADD(cyc_sync, ts0);
 #pragma unroll
     for (int j = 0; j + 1 < kSpRing - 1; ++j) markA[j] = markA[j + 1];
     request_group();
@@ -227,29 +288,56 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   const unsigned og0 = ((unsigned)my_ant.x * (unsigned)A.fpad + chan0) * 8u;  // gains
   const unsigned og1 = ((unsigned)my_ant.y * (unsigned)A.fpad + chan0) * 8u;
 
+  // ---- the two antennas' gains of this lane's eight channels of a channel block (they come from L2).  They are requested one GROUP before the
+  // element stage that uses them -- in the last forward group for cb0, in the last adjoint group of cb0 for cb1 -- as ordinary loads the compiler
+  // tracks: its wait in front of their first use counts only its own loads, i.e. it also waits for every LDS-DMA request issued after them;
+  // a group later those have landed anyway.  (Requested inside the element stage the round trip was exposed: 2 500 of its 5 400 ticks.)
+  struct GainRegs { f32x4 a[4], b[4]; };
+  auto gains_request = [&](GainRegs& R, int cb) {
+    const unsigned cb8 = (unsigned)cb * (kCB * 8u);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      R.a[g] = *reinterpret_cast<const f32x4*>(p_g + (og0 + cb8 + 64u * g));
+      R.b[g] = *reinterpret_cast<const f32x4*>(p_g + (og1 + cb8 + 64u * g));
+    }
+  };
+
   // ---- E: element stage of one channel block on its forward accumulator (calibration.py:1593-1609 and their adjoints).  Lane (col, half) holds
   // v of column col = (slot, re | im) at 16 channels: register 4 g + r -> channel 8 g + 4 half + r.  The re and im lane of a slot sit 16 lanes
   // apart and share the work: v_permlane16_swap(acc[4 g + i], acc[4 g + i + 2]) hands the re lane (re, im) of channel i and the im lane (re, im)
   // of channel i + 2; after the arithmetic ONE more swap of (gbar_v.re, gbar_v.im) puts gbar_v back in the layout v had (the re lane keeps the
   // real part of its channel and receives the real part of the im lane's channel; the im lane the imaginary parts), no selects.
-  auto element_stage = [&](f32x16& acc, int cb, int next_cb) {
+  auto element_stage = [&](f32x16& acc, int cb, int next_cb, const GainRegs& GR) {
     const unsigned cb8 = (unsigned)cb * (kCB * 8u);
     cf2 lt = {0.f, 0.f}, st = {0.f, 0.f};
+    SPL_T(tw0);
     wait_vm_dyn(issued - markS);
-    f32x4 ga_n = *reinterpret_cast<const f32x4*>(p_g + (og0 + cb8));
-    f32x4 gb_n = *reinterpret_cast<const f32x4*>(p_g + (og1 + cb8));
+    SPL_ADD(cyc_sw, tw0);
+    // the block's samples, all of them at once: the staging area is then free for the next block's (requested a whole adjoint phase ahead)
+    cf2 s_dr[4], s_di[4], s_w[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 ga = ga_n, gb = gb_n;
-      if (g < 3) {  // the next register group's gains (they come from L2)
-        ga_n = *reinterpret_cast<const f32x4*>(p_g + (og0 + cb8 + 64u * (g + 1)));
-        gb_n = *reinterpret_cast<const f32x4*>(p_g + (og1 + cb8 + 64u * (g + 1)));
-      }
-      // this register group's samples, read when they are needed (all four groups up front cost more registers than the kernel has)
       const int so = ((g >> 1) * 64 + 32 * (g & 1)) * 16;
-      const cf2 s_dr = *reinterpret_cast<const cf2*>(smp_rd + so);
-      const cf2 s_di = *reinterpret_cast<const cf2*>(smp_rd + 2048 + so);
-      const cf2 s_w = *reinterpret_cast<const cf2*>(smp_rd + 4096 + so);
+      s_dr[g] = *reinterpret_cast<const cf2*>(smp_rd + so);
+      s_di[g] = *reinterpret_cast<const cf2*>(smp_rd + 2048 + so);
+      s_w[g] = *reinterpret_cast<const cf2*>(smp_rd + 4096 + so);
+    }
+    if (next_cb >= 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      smp_issue(next_cb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef CAL_STAMP
+    SPL_ADD(cyc_eg, tw0);
+    SPL_T(tl0);
+#endif
+#ifdef CAL_X_NOE
+    acc[0] += s_dr[0][0] + s_di[1][1] + s_w[2][0] + GR.a[0][0] + GR.b[3][3];
+    if (false)
+#endif
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
       f32x4 qs;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -259,10 +347,9 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
         const u2 pr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, xb), false, false);
         const unsigned p0 = pr[0], p1 = pr[1];
         const cf2 v = {__builtin_bit_cast(float, p0), __builtin_bit_cast(float, p1)};
-        const cf2 d = {s_dr[i], s_di[i]};
-        const float w = s_w[i];
-        const cf2 g0 = {ga[2 * i], ga[2 * i + 1]}, g1 = {gb[2 * i], gb[2 * i + 1]};
-        const cf2 G = cmul_conj(g0, g1);  // g_i conj(g_j)  (calibration.py:1598-1601)
+        const cf2 d = {s_dr[g][i], s_di[g][i]};
+        const float w = s_w[g][i];
+        const cf2 G = cmul_conj(cf2{GR.a[g][2 * i], GR.a[g][2 * i + 1]}, cf2{GR.b[g][2 * i], GR.b[g][2 * i + 1]});  // g_i conj(g_j)  (calibration.py:1598-1601)
         const cf2 m = cmul(G, v);
         const cf2 r = d - m;
         lt += (r * r) * w;
@@ -280,107 +367,157 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
           qs[2 * i + 1] = gq.y;
         }
       }
+#ifndef CAL_X_NOQ
+#ifdef CAL_X_QNT
+      if (GRAD && primary) __builtin_nontemporal_store(qs, reinterpret_cast<f32x4*>(p_q + (obq + cb8 + 64u * g)));
+#else
       if (GRAD && primary) *reinterpret_cast<f32x4*>(p_q + (obq + cb8 + 64u * g)) = qs;
-      __builtin_amdgcn_sched_barrier(0);  // one register group at a time
+#endif
+#endif
     }
+    SPL_ADD(cyc_el, tl0);
+    SPL_T(tq0);
     if (primary) {
       loss_acc += (double)(lt.x + lt.y);
       sr_acc += (double)st.x;
       si_acc += (double)st.y;
     }
-    if (next_cb >= 0) {
-      // the staging area is free once the reads above have returned: the next block's samples go into it
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      smp_issue(next_cb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    SPL_ADD(cyc_es, tq0);
   };
-  // ---- B: adjoint of one channel block: dC[t] += A[ch, 32 t ...]^T gbar_v, a group = two tiles x two K-steps of 16 channels
-  auto adjoint = [&](const f32x16& acc) {
+  // ---- B: adjoint of one channel block: dC[t] += A[ch, 32 t ...]^T gbar_v, a group = two tiles x two K-steps of 16 channels (the two tiles'
+  // chains interleaved: a dependent MFMA waits for its predecessor).  `pre`: called in front of the MFMAs of the block's LAST group
+  auto adjoint = [&](const f32x16& acc, auto&& pre) {
+    SPL_T(tb0);
     bf16x8 g1[2], g2[2], g3[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = acc[8 * q + j];
+#ifdef CAL_X_NOGSPLIT
+      split3<true>(x, g1[q], g2[q], g3[q]);
+#else
       split3(x, g1[q], g2[q], g3[q]);
+#endif
     }
+#ifdef CAL_STAMP
+    asm volatile("" : "+v"(g1[1]), "+v"(g2[1]), "+v"(g3[1]));
+    SPL_ADD(cyc_bs, tb0);
+#endif
 #pragma unroll
     for (int e = 0; e < NTMAX / 2; ++e) {
       if (e < ntd) {  // wave-uniform
         const int at = group_begin();
+        if (e == ntd - 1) pre();
+        const bool two = 2 * e + 1 < NT;  // wave-uniform: the group's second tile exists
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          if (2 * e + tt < NT) {  // wave-uniform
-            f32x16& D = dC[2 * e + tt];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const int o = at + ((2 * tt + q) * 3) * 64;
-              const bf16x8 a1 = __builtin_bit_cast(bf16x8, ring_rd[o]), a2 = __builtin_bit_cast(bf16x8, ring_rd[o + 64]),
-                           a3 = __builtin_bit_cast(bf16x8, ring_rd[o + 128]);
-              CAL_MFMA_BF16(a3, g1[q], D);
-              CAL_MFMA_BF16(a2, g2[q], D);
-              CAL_MFMA_BF16(a1, g3[q], D);
-              CAL_MFMA_BF16(a2, g1[q], D);
-              CAL_MFMA_BF16(a1, g2[q], D);
-              CAL_MFMA_BF16(a1, g1[q], D);
-            }
+        for (int q = 0; q < 2; ++q) {
+          const int o0 = at + (q * 3) * 64, o1 = at + ((2 + q) * 3) * 64;
+          const bf16x8 a1 = __builtin_bit_cast(bf16x8, ring_rd[o0]), a2 = __builtin_bit_cast(bf16x8, ring_rd[o0 + 64]),
+                       a3 = __builtin_bit_cast(bf16x8, ring_rd[o0 + 128]);
+          if (two) {
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, ring_rd[o1]), b2 = __builtin_bit_cast(bf16x8, ring_rd[o1 + 64]),
+                         b3 = __builtin_bit_cast(bf16x8, ring_rd[o1 + 128]);
+            f32x16& D0 = dC[2 * e];
+            f32x16& D1 = dC[2 * e + 1];
+            CAL_MFMA_BF16(a3, g1[q], D0);
+            CAL_MFMA_BF16(b3, g1[q], D1);
+            CAL_MFMA_BF16(a2, g2[q], D0);
+            CAL_MFMA_BF16(b2, g2[q], D1);
+            CAL_MFMA_BF16(a1, g3[q], D0);
+            CAL_MFMA_BF16(b1, g3[q], D1);
+            CAL_MFMA_BF16(a2, g1[q], D0);
+            CAL_MFMA_BF16(b2, g1[q], D1);
+            CAL_MFMA_BF16(a1, g2[q], D0);
+            CAL_MFMA_BF16(b1, g2[q], D1);
+            CAL_MFMA_BF16(a1, g1[q], D0);
+            CAL_MFMA_BF16(b1, g1[q], D1);
+          } else {
+            f32x16& D0 = dC[2 * e];
+            CAL_MFMA_BF16(a3, g1[q], D0);
+            CAL_MFMA_BF16(a2, g2[q], D0);
+            CAL_MFMA_BF16(a1, g3[q], D0);
+            CAL_MFMA_BF16(a2, g1[q], D0);
+            CAL_MFMA_BF16(a1, g2[q], D0);
+            CAL_MFMA_BF16(a1, g1[q], D0);
           }
         }
       }
     }
   };
+  // ---- F: one forward group: two K-steps x (cb0, cb1)
+  auto forward_group = [&](f32x16& acc0, f32x16& acc1, int d, auto&& pre) {
+    const int at = group_begin();
+    // the two K-steps' coefficients: wait for the buffer, read it; once the reads have returned it is requested again for the next group
+    SPL_T(tc0);
+    wait_vm_dyn(issued - markC);
+    SPL_ADD(cyc_cw, tc0);
+    f32x4 cq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cq[j] = cr_rd[j * 64];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    request_c();
+    pre();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 0 || 2 * d + 1 < ngk) {  // wave-uniform: the second K-step of the last group may lie past the block's vectors
+        bf16x8 c1, c2, c3;
+        {
+          const float x[8] = {cq[2 * ks][0], cq[2 * ks][1], cq[2 * ks][2], cq[2 * ks][3], cq[2 * ks + 1][0], cq[2 * ks + 1][1], cq[2 * ks + 1][2], cq[2 * ks + 1][3]};
+#ifdef CAL_X_NOCSPLIT
+          split3<true>(x, c1, c2, c3);
+#else
+          split3(x, c1, c2, c3);
+#endif
+        }
+        bf16x8 a0[3], a1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a0[p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks) * 3 + p) * 64]);
+          a1[p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks + 1) * 3 + p) * 64]);
+        }
+        CAL_MFMA_BF16(a0[2], c1, acc0);
+        CAL_MFMA_BF16(a1[2], c1, acc1);
+        CAL_MFMA_BF16(a0[1], c2, acc0);
+        CAL_MFMA_BF16(a1[1], c2, acc1);
+        CAL_MFMA_BF16(a0[0], c3, acc0);
+        CAL_MFMA_BF16(a1[0], c3, acc1);
+        CAL_MFMA_BF16(a0[1], c1, acc0);
+        CAL_MFMA_BF16(a1[1], c1, acc1);
+        CAL_MFMA_BF16(a0[0], c2, acc0);
+        CAL_MFMA_BF16(a1[0], c2, acc1);
+        CAL_MFMA_BF16(a0[0], c1, acc0);
+        CAL_MFMA_BF16(a1[0], c1, acc1);
+      }
+    }
+  };
 
   for (int cp = 0; cp < ncp; ++cp) {
-    // ---- F: V(cb0), V(cb1) = A[ch, :] . C
+    SPL_T(t_f0);
     f32x16 acc0, acc1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
-    for (int d = 0; d < ngd; ++d) {
-      const int at = group_begin();
-      // the two K-steps' coefficients: wait for the buffer, read it; once the reads have returned it is requested again for the next group
-      wait_vm_dyn(issued - markC);
-      f32x4 cq[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cq[j] = cr_rd[j * 64];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      request_c();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (ks == 0 || 2 * d + 1 < ngk) {  // wave-uniform: the second K-step of the last group may lie past the block's vectors
-          bf16x8 c1, c2, c3;
-          {
-            const float x[8] = {cq[2 * ks][0], cq[2 * ks][1], cq[2 * ks][2], cq[2 * ks][3], cq[2 * ks + 1][0], cq[2 * ks + 1][1], cq[2 * ks + 1][2], cq[2 * ks + 1][3]};
-            split3(x, c1, c2, c3);
-          }
-          bf16x8 a0[3], a1[3];
-#pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            a0[p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks) * 3 + p) * 64]);
-            a1[p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks + 1) * 3 + p) * 64]);
-          }
-          CAL_MFMA_BF16(a0[2], c1, acc0);
-          CAL_MFMA_BF16(a1[2], c1, acc1);
-          CAL_MFMA_BF16(a0[1], c2, acc0);
-          CAL_MFMA_BF16(a1[1], c2, acc1);
-          CAL_MFMA_BF16(a0[0], c3, acc0);
-          CAL_MFMA_BF16(a1[0], c3, acc1);
-          CAL_MFMA_BF16(a0[1], c1, acc0);
-          CAL_MFMA_BF16(a1[1], c1, acc1);
-          CAL_MFMA_BF16(a0[0], c2, acc0);
-          CAL_MFMA_BF16(a1[0], c2, acc1);
-          CAL_MFMA_BF16(a0[0], c1, acc0);
-          CAL_MFMA_BF16(a1[0], c1, acc1);
-        }
-      }
-    }
-    element_stage(acc0, 2 * cp, 2 * cp + 1);
-    if (GRAD) adjoint(acc0);
-    element_stage(acc1, 2 * cp + 1, cp + 1 < ncp ? 2 * cp + 2 : -1);
-    if (GRAD) adjoint(acc1);
+    GainRegs GR, GR1;
+    for (int d = 0; d + 1 < ngd; ++d) forward_group(acc0, acc1, d, [] {});
+    forward_group(acc0, acc1, ngd - 1, [&] {
+      gains_request(GR, 2 * cp);
+      if (!GRAD) gains_request(GR1, 2 * cp + 1);  // (the loss-only pass has no adjoint phase to hide the second block's round trip, and registers to spare)
+    });
+    SPL_T(t1);
+    SPL_ADD(cyc_f, t_f0);
+    element_stage(acc0, 2 * cp, 2 * cp + 1, GR);
+    SPL_T(t2);
+    SPL_ADD(cyc_e, t1);
+    if (GRAD) adjoint(acc0, [&] { gains_request(GR1, 2 * cp + 1); });
+    SPL_T(t3);
+    SPL_ADD(cyc_b, t2);
+    element_stage(acc1, 2 * cp + 1, cp + 1 < ncp ? 2 * cp + 2 : -1, GR1);
+    SPL_T(t4);
+    SPL_ADD(cyc_e, t3);
+    if (GRAD) adjoint(acc1, [] {});
+    SPL_ADD(cyc_b, t4);
   }
   RING_WAIT(0);  // nothing may still be writing into this workgroup's LDS when it ends
 
@@ -394,6 +531,16 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
       A.part[pi + 2] = si;
     }
   }
+#ifdef CAL_STAMP
+  if (lane == 0 && sp < 4096) {
+    long long* o = g_split_stamps[sp][wave];
+    o[0] = cyc_f; o[1] = cyc_e; o[2] = cyc_b; o[3] = cyc_sync; o[4] = cyc_cw; o[5] = cyc_sw; o[6] = t_entry;
+    o[7] = (long long)__builtin_amdgcn_s_memtime();
+    o[8] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    o[9] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    o[10] = cyc_eg; o[11] = cyc_el; o[12] = cyc_es; o[13] = cyc_bs;  // element stage: until the gains are there, the loop, the tail; adjoint: the split
+  }
+#endif
   if (!GRAD) return;
   if (my_bl >= 0) {
     float* gc = (im_lane ? A.gc_i : A.gc_r) + my_coff + 32 * tile0;

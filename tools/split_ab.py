@@ -34,7 +34,12 @@ def main():
     ap.add_argument("--paths", default="dense,dense_f32")
     ap.add_argument("--reg", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--lib", default=None, help="an experiment build of the library (make variant) instead of the shipped one")
     args = ap.parse_args()
+    if args.lib:
+        from calamity_amd import _lib
+
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     t0 = time.time()
     if args.config:
         p, truth, start = synthetic.make_config(args.config, with_sky=True)
@@ -70,12 +75,14 @@ def main():
         if not args.no_time:
             s.set_optimizer("Adam", learning_rate=1e-3)
             s.run(3, record=False)
-            s.timing_enable(True)
             s.synchronize()
             t1 = time.perf_counter()
             s.run(args.steps, record=True, tol=0.0)
             s.synchronize()
             dt = time.perf_counter() - t1
+            s.timing_enable(True)
+            s.run(args.steps, record=True, tol=0.0)
+            s.synchronize()
             t = s.timing_get()
             rec["pass_ms"] = t["total_ms"] / max(t["launches"], 1)
             rec["step_ms"] = dt / args.steps * 1e3
