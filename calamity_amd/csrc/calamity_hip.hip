@@ -221,6 +221,7 @@ struct SolverT final : cal_solver {
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
+  int mf_split_c_bytes = 0;
   bool mf_split = false;                       // fp32: the split-bf16 kernel (split_kernels.hpp: super-panels of 4 panels) instead of fused_dense_kernel
   DevBuf mf_map;                               // [mf_grid] workgroup -> panel (-1: empty slot): XCD-affine dispatch of the dense launch
   int mf_grid = 0;
@@ -452,7 +453,8 @@ struct SolverT final : cal_solver {
     if (d->kernel_path == CAL_PATH_DENSE_F32 && !std::is_same<T, float>::value)
       return fail(CAL_ERR_UNSUPPORTED, "set_problem: CAL_PATH_DENSE_F32 is the fp32 kernel on v_mfma_f32_32x32x2_f32; this solver is fp64");
     const bool forced_dense = d->kernel_path == CAL_PATH_DENSE || d->kernel_path == CAL_PATH_DENSE_F32;
-    const bool want_split = std::is_same<T, float>::value && d->kernel_path != CAL_PATH_DENSE_F32;
+    bool want_split = std::is_same<T, float>::value && d->kernel_path != CAL_PATH_DENSE_F32;
+    for (int u = 0; u < nbasis && want_split; ++u) want_split = d->basis_nvec[u] <= kSplitMaxNvec;  // (wider blocks: the f32 kernel, up to 256 vectors)
     // dense (matrix-core) path: eligibility, then -- for CAL_PATH_AUTO -- whether the problem fills the chip
     bool dense_ok = layout == CAL_LAYOUT_SHARED && fpad % kChunk == 0;
     for (int g = 0; g < ngrps && dense_ok; ++g) dense_ok = (d->grp_bl_start[g + 1] - d->grp_bl_start[g]) == 1;
@@ -462,7 +464,7 @@ struct SolverT final : cal_solver {
     // ... and its packed operands (two MFMA-native copies of every unique block) with 32-bit byte offsets from one base
     long long dense_op_elems = 0;
     for (int u = 0; u < nbasis && dense_ok; ++u)  // kilobyte positions: forward + adjoint (the same count for both dtypes' layouts up to padding)
-      dense_op_elems += want_split ? 2 * split_stream_bytes(fpad, d->basis_nvec[u], kSplitNT) / 4  // (an upper bound: two items per block at most)
+      dense_op_elems += want_split ? split_stream_bytes(fpad, d->basis_nvec[u], (d->basis_nvec[u] + 31) / 32) / 4
                         : std::is_same<T, float>::value
                             ? (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256 + (long long)(fpad / 32) * ((d->basis_nvec[u] + 31) / 32) * 4 * 256
                             : (long long)(fpad / 16) * ((d->basis_nvec[u] + 7) / 8) * 128 + (long long)(fpad / 16) * ((d->basis_nvec[u] + 15) / 16) * 2 * 128;
@@ -654,8 +656,7 @@ struct SolverT final : cal_solver {
         long long obytes = 0;
         for (int u = 0; u < nbasis; ++u) {
           const int ntu = (d->basis_nvec[u] + 31) / 32;
-          if (ntu <= kSplitNT) halves[u] = {Half{0, ntu, 0}};
-          else halves[u] = {Half{0, (ntu + 1) / 2, 0}, Half{(ntu + 1) / 2, ntu / 2, 0}};
+          halves[u] = {Half{0, ntu, 0}};  // (kSplitNT = 8 tiles fit one item since the kernel runs one workgroup per CU)
           for (Half& h : halves[u]) {
             h.obyte = obytes;
             obytes += split_stream_bytes(fpad, d->basis_nvec[u], h.ntiles);
@@ -705,7 +706,10 @@ struct SolverT final : cal_solver {
           }
         }
         CAL_TRY(order_panels(h_panels, h_cost, kSpWaves));
-        mf_lds_grad[0] = mf_lds_loss[0] = split_lds_bytes();
+        int nvec_max = 0;
+        for (int u = 0; u < nbasis; ++u) nvec_max = std::max(nvec_max, d->basis_nvec[u]);
+        mf_split_c_bytes = split_c_wave_bytes(nvec_max);
+        mf_lds_grad[0] = mf_lds_loss[0] = split_lds_bytes(nvec_max);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
         mf_ok = true;
@@ -1555,6 +1559,7 @@ struct SolverT final : cal_solver {
   template <bool GRAD> void launch_dense(MfmaArgs m) {
     m.slot_map = mf_map.as<int>();
     if (mf_split) {
+      m.split_c_bytes = mf_split_c_bytes;
       hipLaunchKernelGGL((fused_dense_split_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
       return;
     }

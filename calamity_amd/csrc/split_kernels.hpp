@@ -34,15 +34,20 @@ constexpr int kSpWaves = 4;            // panels (waves) per super-panel
 constexpr int kPosBytes = 3072;        // one operand position: [3 planes][64 lanes][16 B]
 constexpr int kGroupBytes = 4 * kPosBytes;
 #ifndef CAL_SPLIT_RING
-#define CAL_SPLIT_RING 3
+#define CAL_SPLIT_RING 2
 #endif
 constexpr int kSpRing = CAL_SPLIT_RING;  // groups in the operand ring
-constexpr int kSpCBytes = 4096;          // per-wave coefficient buffer: two K-steps x (32 columns x 16 vectors) fp32
-constexpr int kSplitNT = 4;              // vector tiles per item
+constexpr int kSplitNT = 8;              // vector tiles per item at most (128 gradient accumulators)
+constexpr int kSplitMaxNvec = 224;       // 7 forward groups: the coefficient panels of the four waves stay in LDS (4 x 28 KB) beside ring and samples
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-inline size_t split_lds_bytes() { return (size_t)kSpRing * kGroupBytes + (size_t)kSpWaves * kSpCBytes + (size_t)kSpWaves * kSmpBytes; }
+// LDS of a workgroup: the operand ring, per wave its coefficient panel (fp32, c_wave_bytes = 4 KB per forward group of the widest block) and the
+// samples of one channel block.  ONE workgroup per CU (one wave per SIMD, 512 registers): halving the occupancy costs this kernel 13 % -- it
+// is bound by the traffic it draws from the fabric, and the LDS a single workgroup has keeps the coefficients resident (they were 1.3 GB of
+// re-reads per pass) and the registers carry all eight vector tiles of the widest blocks (they were two items, each with the whole forward).
+inline int split_c_wave_bytes(int nvec_max) { return (((nvec_max + 15) / 16 + 1) / 2) * 4096; }
+inline size_t split_lds_bytes(int nvec_max) { return (size_t)kSpRing * kGroupBytes + (size_t)kSpWaves * split_c_wave_bytes(nvec_max) + (size_t)kSpWaves * kSmpBytes; }
 // groups of one item's packed stream per channel-block pair: forward (two K-steps each), then the adjoint of cb0 and of cb1 (two tiles each)
 inline int split_groups_per_pair(int nvec, int ntiles) { return ((nvec + 15) / 16 + 1) / 2 + 2 * ((ntiles + 1) / 2); }
 inline long long split_stream_bytes(int fpad, int nvec, int ntiles) { return (long long)(fpad / 64) * split_groups_per_pair(nvec, ntiles) * kGroupBytes; }
@@ -50,12 +55,14 @@ inline long long split_stream_bytes(int fpad, int nvec, int ntiles) { return (lo
 // s_waitcnt vmcnt(n), n wave-uniform at run time: a jump into a table of (s_waitcnt vmcnt(k); s_branch end) pairs.  ONE asm statement: the
 // compiler sees no control flow (a switch at every wait made the kernel's flow graph -- and its register allocation -- unmanageable).
 __device__ __forceinline__ void wait_vm_dyn(int n) {
-  n = n < 0 ? 0 : (n > 31 ? 31 : n);  // more outstanding requests than the table holds: the wait is stricter, never weaker
-  n = __builtin_amdgcn_readfirstlane(n);  // (hipcc hands an "s" operand it computed in the vector ALU to the asm as a VGPR)
+  // (n comes from scalar arithmetic on wave-uniform counters; the clamp is done inside the asm: written in C++ hipcc evaluated it in the
+  // vector ALU and handed the asm a VGPR.)  More outstanding requests than the table holds: the wait is stricter, never weaker.
   asm volatile(
-      "s_getpc_b64 s[98:99]\n\t"        // = address of the next instruction
-      "s_lshl_b32 s97, %0, 3\n\t"       // 8 bytes per table entry
-      "s_add_u32 s97, s97, 20\n\t"      // the five 4-byte instructions from here to the table
+      "s_max_i32 s97, %0, 0\n\t"
+      "s_min_i32 s97, s97, 31\n\t"
+      "s_getpc_b64 s[98:99]\n\t"      // = address of the next instruction
+      "s_lshl_b32 s97, s97, 3\n\t"     // 8 bytes per table entry
+      "s_add_u32 s97, s97, 20\n\t"     // the five 4-byte instructions from there to the table
       "s_add_u32 s98, s98, s97\n\t"
       "s_addc_u32 s99, s99, 0\n\t"
       "s_setpc_b64 s[98:99]\n\t"
@@ -69,6 +76,22 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
       : "s"(n)
       : "memory", "s97", "s98", "s99", "scc");
   __builtin_amdgcn_sched_barrier(0);
+}
+
+// LDS-DMA requests (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KB, no register destination).  M0 carries the LDS address; it is a register
+// the compiler reserves and re-initialises in front of every use of its own, so it is set and left.  `base` must be wave-uniform (dma_base).
+__device__ __forceinline__ const void* dma_base(const void* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void dma1(unsigned lds, const void* base, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(base) : "memory");
+}
+// three consecutive kilobytes: the instruction offset moves the global and the LDS address alike
+__device__ __forceinline__ void dma3(unsigned lds, const void* base, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048" ::"s"(lds), "v"(voff), "s"(base) : "memory");
 }
 
 // x (8 fp32) -> three bf16 planes, round to nearest even at every level (v_cvt_pk_bf16_f32)
@@ -93,32 +116,9 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& p1, bf16x8& 
   }
 }
 
-// ring_issue (dense_kernels.hpp) with the non-temporal hint: data read once per pass (samples) must not displace the operand stream in L2
-__device__ __forceinline__ void ring_issue_nt(unsigned lds_slot, const f32x4_t* sbase, unsigned lane_bytes, unsigned item_bytes) {
-  const unsigned vo = lane_bytes + item_bytes;
-  sbase = uniform_ptr(sbase);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "s"(lds_slot), "v"(vo), "s"(sbase)
-               : "memory");
-}
-#ifdef CAL_X_SMPNT
-#define SMP_ISSUE ring_issue_nt
-#else
-#define SMP_ISSUE ring_issue
-#endif
-#ifdef CAL_X_CNT
-#define C_ISSUE ring_issue_nt
-#else
-#define C_ISSUE ring_issue
-#endif
-
 #define CAL_MFMA_BF16(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
 
-typedef float cf2 __attribute__((ext_vector_type(2)));  // (re, im): complex arithmetic as packed fp32 (v_pk_mul / v_pk_fma with op_sel)
-__device__ __forceinline__ cf2 cmul(cf2 a, cf2 b) { return a.xx * b + cf2{-a.y, a.y} * b.yx; }       // a b
-__device__ __forceinline__ cf2 cmul_conj(cf2 a, cf2 b) { return b.xx * a + cf2{b.y, -b.y} * a.yx; }  // a conj(b)
+typedef float cf2 __attribute__((ext_vector_type(2)));  // a pair of fp32: the element stage computes on the lane's two channels at once (v_pk_*)
 
 #ifdef CAL_STAMP
 // diagnostic build only: [item][wave][F, E, B, group waits + barriers, coefficient waits, sample waits, entry time, exit time, HW_ID, XCC_ID] in s_memtime ticks
@@ -165,14 +165,19 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   if (stopped) return;  // (the four panels of a super-panel belong to one slice: workgroup-uniform)
 
   unsigned char* s_ring = smem_raw;                                 // [kSpRing groups][4 positions][3 KB]
-  unsigned char* s_cr = smem_raw + kSpRing * kGroupBytes;           // [4 waves][4 KB]
-  unsigned char* s_smp = s_cr + kSpWaves * kSpCBytes;               // [4 waves][6 KB]
-  const f32x4* ops = reinterpret_cast<const f32x4*>(A.ops);
+  unsigned char* s_cr = smem_raw + kSpRing * kGroupBytes;           // [4 waves][c_wave_bytes]: the wave's coefficient panel, 4 KB per forward group
+  unsigned char* s_smp = s_cr + kSpWaves * A.split_c_bytes;         // [4 waves][6 KB]
+  // wave-uniform bases of everything the LDS-DMA requests read ("s" operands of the asm)
+  const void* ops_u = dma_base(A.ops);
+  const void* c_u = dma_base(A.c_r);
+  const void* dr_u = dma_base(A.data_r);
+  const void* di_u = dma_base(A.data_i);
+  const void* w_u = dma_base(A.wgts);
   const unsigned voff = (unsigned)lane * 16u;
   const unsigned ring_lds = (unsigned)reinterpret_cast<unsigned long long>(s_ring);
   const f32x4* ring_rd = reinterpret_cast<const f32x4*>(s_ring) + lane;
-  const unsigned cr_lds = (unsigned)reinterpret_cast<unsigned long long>(s_cr + wave * kSpCBytes);
-  const f32x4* cr_rd = reinterpret_cast<const f32x4*>(s_cr + wave * kSpCBytes) + lane;
+  const unsigned cr_lds = (unsigned)reinterpret_cast<unsigned long long>(s_cr + wave * A.split_c_bytes);
+  const f32x4* cr_rd = reinterpret_cast<const f32x4*>(s_cr + wave * A.split_c_bytes) + lane;
 
   int issued = 0;  // vector-memory requests this wave has issued through asm
 
@@ -191,9 +196,7 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     const unsigned off = base + (unsigned)(rq_cp * GP + rq_d) * (unsigned)kGroupBytes;
 #endif
     const unsigned lds = ring_lds + (unsigned)(rq_slot * 4 + wave) * (unsigned)kPosBytes;
-    ring_issue(lds, ops, voff, off);
-    ring_issue(lds + 1024u, ops, voff, off + 1024u);
-    ring_issue(lds + 2048u, ops, voff, off + 2048u);
+    dma3(lds, ops_u, voff + off);
     issued += 3;
     if (rq_cp < ncp - 1 || rq_d < g_used - 1) {
       ++rq_d;
@@ -204,23 +207,24 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   int markA[kSpRing - 1];  // issue counts of the group requests in flight, oldest first
   // ---- the coefficient operand of a forward group (two K-steps): 4 KB, request i = 0..3 brings K-step i >> 1, vectors 4 (i & 1) .. + 3 of
   // lane L's eight: c[col L & 31][16 kk + 8 (L >> 5) + 4 (i & 1) ..]
-  const f32x4* cbase = reinterpret_cast<const f32x4*>(A.c_r);
 #ifdef CAL_X_C0  // (ablation: every panel reads the same coefficients)
   const unsigned c_voff = (unsigned)((im_lane ? (int)(A.c_i - A.c_r) : 0) + 8 * half) * 4u;
 #else
   const unsigned c_voff = (unsigned)((im_lane ? (int)(A.c_i - A.c_r) : 0) + my_coff + 8 * half) * 4u;
 #endif
-  int c_d = 0;  // forward group of the next request
+  // (loaded once per item, in front of the sweep: request i = 0..3 of forward group d at d x 4 KB + i KB)
   int markC = 0;
-  auto request_c = [&]() {
-    const unsigned off = (unsigned)c_d * 128u;  // 32 vectors x 4 B
-    C_ISSUE(cr_lds, cbase, c_voff, off);
-    C_ISSUE(cr_lds + 1024u, cbase, c_voff, off + 16u);
-    C_ISSUE(cr_lds + 2048u, cbase, c_voff, off + 64u);
-    C_ISSUE(cr_lds + 3072u, cbase, c_voff, off + 80u);
-    issued += 4;
+  auto request_c_panel = [&]() {
+    for (int d = 0; d < ngd; ++d) {
+      const unsigned vo = c_voff + (unsigned)d * 128u;  // 32 vectors x 4 B
+      const unsigned lds = cr_lds + (unsigned)d * 4096u;
+      dma1(lds, c_u, vo);
+      dma1(lds + 1024u, c_u, vo + 16u);
+      dma1(lds + 2048u, c_u, vo + 64u);
+      dma1(lds + 3072u, c_u, vo + 80u);
+      issued += 4;
+    }
     markC = issued;
-    c_d = c_d + 1 == ngd ? 0 : c_d + 1;
   };
   // ---- samples of one channel block (as dense_kernels.hpp): request k fetches array k / 2, register groups 2 (k & 1) + (lane >> 5)
   const unsigned row = (unsigned)(my_bl >= 0 ? my_bl : A.nbls);
@@ -235,12 +239,13 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   int markS = 0;
   auto smp_issue = [&](int cb) {
     const unsigned o = (unsigned)cb * (kCB * 4u);
-    SMP_ISSUE(smp_lds + 0u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o);
-    SMP_ISSUE(smp_lds + 1u * 1024u, reinterpret_cast<const f32x4*>(A.data_r), smp_voff, o + 64u);
-    SMP_ISSUE(smp_lds + 2u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o);
-    SMP_ISSUE(smp_lds + 3u * 1024u, reinterpret_cast<const f32x4*>(A.data_i), smp_voff, o + 64u);
-    SMP_ISSUE(smp_lds + 4u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o);
-    SMP_ISSUE(smp_lds + 5u * 1024u, reinterpret_cast<const f32x4*>(A.wgts), smp_voff, o + 64u);
+    const unsigned vo = smp_voff + o;
+    dma1(smp_lds + 0u * 1024u, dr_u, vo);
+    dma1(smp_lds + 1u * 1024u, dr_u, vo + 64u);
+    dma1(smp_lds + 2u * 1024u, di_u, vo);
+    dma1(smp_lds + 3u * 1024u, di_u, vo + 64u);
+    dma1(smp_lds + 4u * 1024u, w_u, vo);
+    dma1(smp_lds + 5u * 1024u, w_u, vo + 64u);
     issued += 6;
     markS = issued;
   };
@@ -252,7 +257,7 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     request_group();
     markA[j] = issued;
   }
-  request_c();
+  request_c_panel();
 
   // one step of the code = one group: wait for the wave's own request of it, meet the other waves (their requests have landed too, and they
   // have left the previous group), request the group kSpRing - 1 ahead into the slots just freed
@@ -309,7 +314,7 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   // real part of its channel and receives the real part of the im lane's channel; the im lane the imaginary parts), no selects.
   auto element_stage = [&](f32x16& acc, int cb, int next_cb, const GainRegs& GR) {
     const unsigned cb8 = (unsigned)cb * (kCB * 8u);
-    cf2 lt = {0.f, 0.f}, st = {0.f, 0.f};
+    cf2 lt = {0.f, 0.f}, st_r = {0.f, 0.f}, st_i = {0.f, 0.f};
     SPL_T(tw0);
     wait_vm_dyn(issued - markS);
     SPL_ADD(cyc_sw, tw0);
@@ -332,55 +337,56 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     SPL_ADD(cyc_eg, tw0);
     SPL_T(tl0);
 #endif
-#ifdef CAL_X_NOE
-    acc[0] += s_dr[0][0] + s_di[1][1] + s_w[2][0] + GR.a[0][0] + GR.b[3][3];
-    if (false)
-#endif
+    // Per register group the lane's two channels a, b are computed side by side: every quantity is a pair (x_a, x_b) in two adjacent registers
+    // and every operation one packed instruction, no shuffles: after the two swaps acc[4 g], acc[4 g + 1] = (v_re a, v_re b) and
+    // acc[4 g + 2], acc[4 g + 3] = (v_im a, v_im b) ARE such pairs, the samples arrive as (d a, d b), and gbar_v is written back the same way.
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 qs;
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      cf2 vr, vi;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
         // (bit_cast applied to a vector ELEMENT expression reads element 0 with this hipcc: go through scalars)
         const float xa = acc[4 * g + i], xb = acc[4 * g + i + 2];
         const u2 pr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, xb), false, false);
         const unsigned p0 = pr[0], p1 = pr[1];
-        const cf2 v = {__builtin_bit_cast(float, p0), __builtin_bit_cast(float, p1)};
-        const cf2 d = {s_dr[g][i], s_di[g][i]};
-        const float w = s_w[g][i];
-        const cf2 G = cmul_conj(cf2{GR.a[g][2 * i], GR.a[g][2 * i + 1]}, cf2{GR.b[g][2 * i], GR.b[g][2 * i + 1]});  // g_i conj(g_j)  (calibration.py:1598-1601)
-        const cf2 m = cmul(G, v);
-        const cf2 r = d - m;
-        lt += (r * r) * w;
-        st += m * w;  // S = sum w m of the "sum" regulariser (calibration.py:1648-1649)
-        if (GRAD) {
-          const cf2 e = (r * -2.f + alpha) * w;
-          const cf2 gv = cmul_conj(e, G);  // gbar_v = conj(G) e
-          const cf2 gq = cmul_conj(e, v);  // gbar_G = conj(v) e
-          const float gvx = gv.x, gvy = gv.y;
-          const u2 qr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, gvx), __builtin_bit_cast(unsigned, gvy), false, false);
+        vr[i] = __builtin_bit_cast(float, p0);
+        vi[i] = __builtin_bit_cast(float, p1);
+      }
+      // G = g_i conj(g_j)  (calibration.py:1598-1601): the gains arrive as (re, im) per channel
+      const cf2 g0r = {GR.a[g][0], GR.a[g][2]}, g0i = {GR.a[g][1], GR.a[g][3]}, g1r = {GR.b[g][0], GR.b[g][2]}, g1i = {GR.b[g][1], GR.b[g][3]};
+      const cf2 Gr = g0r * g1r + g0i * g1i, Gi = g0i * g1r - g0r * g1i;
+      const cf2 mr = Gr * vr - Gi * vi, mi = Gi * vr + Gr * vi;  // model = G v  (:1602-1604)
+      const cf2 rr = s_dr[g] - mr, ri = s_di[g] - mi;
+      const cf2 w = s_w[g];
+      lt += (rr * rr + ri * ri) * w;  // (:1609)
+      st_r += mr * w;                 // S = sum w m of the "sum" regulariser (calibration.py:1648-1649)
+      st_i += mi * w;
+      if (GRAD) {
+        const cf2 er = (rr * -2.f + alpha.x) * w, ei = (ri * -2.f + alpha.y) * w;  // e = -2 w r + alpha w
+        const cf2 gvr = Gr * er + Gi * ei, gvi = Gr * ei - Gi * er;                // gbar_v = conj(G) e
+        const cf2 gqr = vr * er + vi * ei, gqi = vr * ei - vi * er;                // gbar_G = conj(v) e
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float fx = gvr[i], fy = gvi[i];
+          const u2 qr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, fx), __builtin_bit_cast(unsigned, fy), false, false);
           const unsigned q0b = qr[0], q1b = qr[1];
           acc[4 * g + i] = __builtin_bit_cast(float, q0b);
           acc[4 * g + i + 2] = __builtin_bit_cast(float, q1b);
-          qs[2 * i] = gq.x;
-          qs[2 * i + 1] = gq.y;
         }
+#if defined(CAL_X_QSMALL)  // (ablation: the stores go to 256 KB that stay in L2)
+        if (primary) *reinterpret_cast<f32x4*>(p_q + ((obq + cb8 + 64u * g) & 0x3FFF0u)) = f32x4{gqr[0], gqi[0], gqr[1], gqi[1]};
+#elif !defined(CAL_X_NOQ)
+        if (primary) *reinterpret_cast<f32x4*>(p_q + (obq + cb8 + 64u * g)) = f32x4{gqr[0], gqi[0], gqr[1], gqi[1]};
+#endif
       }
-#ifndef CAL_X_NOQ
-#ifdef CAL_X_QNT
-      if (GRAD && primary) __builtin_nontemporal_store(qs, reinterpret_cast<f32x4*>(p_q + (obq + cb8 + 64u * g)));
-#else
-      if (GRAD && primary) *reinterpret_cast<f32x4*>(p_q + (obq + cb8 + 64u * g)) = qs;
-#endif
-#endif
     }
     SPL_ADD(cyc_el, tl0);
     SPL_T(tq0);
     if (primary) {
       loss_acc += (double)(lt.x + lt.y);
-      sr_acc += (double)st.x;
-      si_acc += (double)st.y;
+      sr_acc += (double)(st_r.x + st_r.y);
+      si_acc += (double)(st_i.x + st_i.y);
     }
     SPL_ADD(cyc_es, tq0);
   };
@@ -448,16 +454,10 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   // ---- F: one forward group: two K-steps x (cb0, cb1)
   auto forward_group = [&](f32x16& acc0, f32x16& acc1, int d, auto&& pre) {
     const int at = group_begin();
-    // the two K-steps' coefficients: wait for the buffer, read it; once the reads have returned it is requested again for the next group
-    SPL_T(tc0);
-    wait_vm_dyn(issued - markC);
-    SPL_ADD(cyc_cw, tc0);
+    // the two K-steps' coefficients, from the wave's resident panel
     f32x4 cq[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cq[j] = cr_rd[j * 64];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    request_c();
+    for (int j = 0; j < 4; ++j) cq[j] = cr_rd[d * 256 + j * 64];
     pre();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -494,6 +494,11 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     }
   };
 
+  {
+    SPL_T(tc0);
+    wait_vm_dyn(issued - markC);  // the coefficient panel has landed
+    SPL_ADD(cyc_cw, tc0);
+  }
   for (int cp = 0; cp < ncp; ++cp) {
     SPL_T(t_f0);
     f32x16 acc0, acc1;
@@ -551,9 +556,14 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int n0 = 32 * t + 8 * i + 4 * half;  // registers 4 i .. 4 i + 3 = vectors n0 .. n0 + 3 of the item
+          if (n0 + 3 < nleft) {
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // (a group's coefficients start at any multiple of 4 bytes)
+            *reinterpret_cast<f32x4u*>(gc + n0) = f32x4u{dC[t][4 * i], dC[t][4 * i + 1], dC[t][4 * i + 2], dC[t][4 * i + 3]};
+          } else {
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            if (n0 + jj < nleft) gc[n0 + jj] = dC[t][4 * i + jj];
+            for (int jj = 0; jj < 3; ++jj)
+              if (n0 + jj < nleft) gc[n0 + jj] = dC[t][4 * i + jj];
+          }
         }
       }
     }
@@ -562,7 +572,7 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
 
 // One launch for all items; XCD-affine dispatch through slot_map as fused_dense_kernel.
 template <bool GRAD>
-__global__ __launch_bounds__(kDenseThreads, 2) void fused_dense_split_kernel(const MfmaArgs A) {
+__global__ __launch_bounds__(kDenseThreads, 1) void fused_dense_split_kernel(const MfmaArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int sp = A.slot_map[blockIdx.x];
   if (sp < 0) return;
