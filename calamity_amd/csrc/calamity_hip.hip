@@ -221,7 +221,6 @@ struct SolverT final : cal_solver {
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
-  int mf_split_c_bytes = 0;
   bool mf_split = false;                       // fp32: the split-bf16 kernel (split_kernels.hpp: super-panels of 4 panels) instead of fused_dense_kernel
   DevBuf mf_map;                               // [mf_grid] workgroup -> panel (-1: empty slot): XCD-affine dispatch of the dense launch
   int mf_grid = 0;
@@ -706,10 +705,7 @@ struct SolverT final : cal_solver {
           }
         }
         CAL_TRY(order_panels(h_panels, h_cost, kSpWaves));
-        int nvec_max = 0;
-        for (int u = 0; u < nbasis; ++u) nvec_max = std::max(nvec_max, d->basis_nvec[u]);
-        mf_split_c_bytes = split_c_wave_bytes(nvec_max);
-        mf_lds_grad[0] = mf_lds_loss[0] = split_lds_bytes(nvec_max);
+        mf_lds_grad[0] = mf_lds_loss[0] = split_lds_bytes();
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
         mf_ok = true;
@@ -1559,7 +1555,6 @@ struct SolverT final : cal_solver {
   template <bool GRAD> void launch_dense(MfmaArgs m) {
     m.slot_map = mf_map.as<int>();
     if (mf_split) {
-      m.split_c_bytes = mf_split_c_bytes;
       hipLaunchKernelGGL((fused_dense_split_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
       return;
     }

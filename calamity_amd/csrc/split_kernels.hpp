@@ -26,6 +26,8 @@
 // s_waitcnt vmcnt(issued - mark) -- a jump into a table of s_waitcnt instructions (the instruction takes an immediate).  Operations the compiler
 // issues itself (gain loads, gbar_G stores) are not in the count: they only make a wait stricter -- towards OLDER operations -- never weaker.
 #pragma once
+#include <type_traits>
+
 #include "dense_kernels.hpp"
 
 namespace calk {
@@ -33,10 +35,8 @@ namespace calk {
 constexpr int kSpWaves = 4;            // panels (waves) per super-panel
 constexpr int kPosBytes = 3072;        // one operand position: [3 planes][64 lanes][16 B]
 constexpr int kGroupBytes = 4 * kPosBytes;
-#ifndef CAL_SPLIT_RING
-#define CAL_SPLIT_RING 2
-#endif
-constexpr int kSpRing = CAL_SPLIT_RING;  // groups in the operand ring
+constexpr int kSpRingMax = 2;             // groups in the operand ring (measured at HERA-350, one workgroup per CU: 2 groups 0.728 ms, 3 groups 0.752, up to 6 as the LDS allows 0.756)
+constexpr int kSplitLds = 160 * 1024;     // the workgroup's LDS: all of the CU's
 constexpr int kSplitNT = 8;              // vector tiles per item at most (128 gradient accumulators)
 constexpr int kSplitMaxNvec = 224;       // 7 forward groups: the coefficient panels of the four waves stay in LDS (4 x 28 KB) beside ring and samples
 
@@ -46,8 +46,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // samples of one channel block.  ONE workgroup per CU (one wave per SIMD, 512 registers): halving the occupancy costs this kernel 13 % -- it
 // is bound by the traffic it draws from the fabric, and the LDS a single workgroup has keeps the coefficients resident (they were 1.3 GB of
 // re-reads per pass) and the registers carry all eight vector tiles of the widest blocks (they were two items, each with the whole forward).
-inline int split_c_wave_bytes(int nvec_max) { return (((nvec_max + 15) / 16 + 1) / 2) * 4096; }
-inline size_t split_lds_bytes(int nvec_max) { return (size_t)kSpRing * kGroupBytes + (size_t)kSpWaves * split_c_wave_bytes(nvec_max) + (size_t)kSpWaves * kSmpBytes; }
+inline int split_c_wave_bytes(int nvec) { return (((nvec + 15) / 16 + 1) / 2) * 4096; }
+inline size_t split_lds_bytes() { return kSplitLds; }
 // groups of one item's packed stream per channel-block pair: forward (two K-steps each), then the adjoint of cb0 and of cb1 (two tiles each)
 inline int split_groups_per_pair(int nvec, int ntiles) { return ((nvec + 15) / 16 + 1) / 2 + 2 * ((ntiles + 1) / 2); }
 inline long long split_stream_bytes(int fpad, int nvec, int ntiles) { return (long long)(fpad / 64) * split_groups_per_pair(nvec, ntiles) * kGroupBytes; }
@@ -154,7 +154,6 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   const int nvec = __builtin_amdgcn_readfirstlane(P.nvec);
   const int NT = __builtin_amdgcn_readfirstlane(P.nvp32 / 32);  // vector tiles of THIS item (<= kSplitNT), the first one being tile0 of the block
   const int tile0 = __builtin_amdgcn_readfirstlane(P.tile0);
-  const bool primary = tile0 == 0;   // the item that owns the loss and gbar_G of its baselines
   const int ngk = (nvec + 15) / 16;  // forward K-steps of 16 vectors
   const int ngd = (ngk + 1) / 2;     // forward groups
   const int ntd = (NT + 1) / 2;      // adjoint groups per channel block
@@ -164,9 +163,16 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   const int stopped = __builtin_amdgcn_readfirstlane(sst->done | sst->done_after);
   if (stopped) return;  // (the four panels of a super-panel belong to one slice: workgroup-uniform)
 
-  unsigned char* s_ring = smem_raw;                                 // [kSpRing groups][4 positions][3 KB]
-  unsigned char* s_cr = smem_raw + kSpRing * kGroupBytes;           // [4 waves][c_wave_bytes]: the wave's coefficient panel, 4 KB per forward group
-  unsigned char* s_smp = s_cr + kSpWaves * A.split_c_bytes;         // [4 waves][6 KB]
+  // LDS of the item: [4 waves][6 KB] samples | [4 waves][4 KB x ngd] coefficient panels | the operand ring: the rest, nring groups of 12 KB
+  const int c_wave_bytes = ngd * 4096;
+  unsigned char* s_smp = smem_raw;
+  unsigned char* s_cr = smem_raw + kSpWaves * kSmpBytes;
+  unsigned char* s_ring = s_cr + kSpWaves * c_wave_bytes;
+  int nring = (kSplitLds - kSpWaves * kSmpBytes - kSpWaves * c_wave_bytes) / kGroupBytes;
+  nring = nring > kSpRingMax ? kSpRingMax : nring;  // >= 2 for every block the host admits (kSplitMaxNvec)
+#ifdef CAL_X_RINGCAP
+  nring = nring > CAL_X_RINGCAP ? CAL_X_RINGCAP : nring;
+#endif
   // wave-uniform bases of everything the LDS-DMA requests read ("s" operands of the asm)
   const void* ops_u = dma_base(A.ops);
   const void* c_u = dma_base(A.c_r);
@@ -176,8 +182,8 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   const unsigned voff = (unsigned)lane * 16u;
   const unsigned ring_lds = (unsigned)reinterpret_cast<unsigned long long>(s_ring);
   const f32x4* ring_rd = reinterpret_cast<const f32x4*>(s_ring) + lane;
-  const unsigned cr_lds = (unsigned)reinterpret_cast<unsigned long long>(s_cr + wave * A.split_c_bytes);
-  const f32x4* cr_rd = reinterpret_cast<const f32x4*>(s_cr + wave * A.split_c_bytes) + lane;
+  const unsigned cr_lds = (unsigned)reinterpret_cast<unsigned long long>(s_cr + wave * c_wave_bytes);
+  const f32x4* cr_rd = reinterpret_cast<const f32x4*>(s_cr + wave * c_wave_bytes) + lane;
 
   int issued = 0;  // vector-memory requests this wave has issued through asm
 
@@ -202,9 +208,9 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
       ++rq_d;
       if (rq_d == g_used) { rq_d = 0; ++rq_cp; }
     }
-    rq_slot = rq_slot + 1 == kSpRing ? 0 : rq_slot + 1;
+    rq_slot = rq_slot + 1 == nring ? 0 : rq_slot + 1;
   };
-  int markA[kSpRing - 1];  // issue counts of the group requests in flight, oldest first
+  int markA[kSpRingMax - 1];  // issue counts of the group requests in flight (nring - 1 of them), oldest first
   // ---- the coefficient operand of a forward group (two K-steps): 4 KB, request i = 0..3 brings K-step i >> 1, vectors 4 (i & 1) .. + 3 of
   // lane L's eight: c[col L & 31][16 kk + 8 (L >> 5) + 4 (i & 1) ..]
 #ifdef CAL_X_C0  // (ablation: every panel reads the same coefficients)
@@ -253,14 +259,17 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   RING_WAIT(0);  // the record loads above are the compiler's: nothing of them is in flight when the counting starts
   smp_issue(0);
 #pragma unroll
-  for (int j = 0; j < kSpRing - 1; ++j) {
-    request_group();
-    markA[j] = issued;
+  for (int j = 0; j < kSpRingMax - 1; ++j) {
+    markA[j] = 0;
+    if (j < nring - 1) {
+      request_group();
+      markA[j] = issued;
+    }
   }
   request_c_panel();
 
   // one step of the code = one group: wait for the wave's own request of it, meet the other waves (their requests have landed too, and they
-  // have left the previous group), request the group kSpRing - 1 ahead into the slots just freed
+  // have left the previous group), request the group nring - 1 ahead into the slots just freed
   int cur_slot = 0;
   auto group_begin = [&]() -> int {  // -> f32x4 index (without the lane) of the group's first plane
     SPL_T(ts0);
@@ -269,12 +278,14 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     __builtin_amdgcn_sched_barrier(0);
     SPL_ADD(cyc_sync, ts0);
 #pragma unroll
-    for (int j = 0; j + 1 < kSpRing - 1; ++j) markA[j] = markA[j + 1];
+    for (int j = 0; j + 1 < kSpRingMax - 1; ++j) markA[j] = markA[j + 1];
     request_group();
-    markA[kSpRing - 2] = issued;
+#pragma unroll
+    for (int j = 0; j < kSpRingMax - 1; ++j)
+      if (j == nring - 2) markA[j] = issued;
     __builtin_amdgcn_sched_barrier(0);
     const int at = cur_slot * (kGroupBytes / 16);
-    cur_slot = cur_slot + 1 == kSpRing ? 0 : cur_slot + 1;
+    cur_slot = cur_slot + 1 == nring ? 0 : cur_slot + 1;
     return at;
   };
 
@@ -309,147 +320,161 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
 
   // ---- E: element stage of one channel block on its forward accumulator (calibration.py:1593-1609 and their adjoints).  Lane (col, half) holds
   // v of column col = (slot, re | im) at 16 channels: register 4 g + r -> channel 8 g + 4 half + r.  The re and im lane of a slot sit 16 lanes
-  // apart and share the work: v_permlane16_swap(acc[4 g + i], acc[4 g + i + 2]) hands the re lane (re, im) of channel i and the im lane (re, im)
-  // of channel i + 2; after the arithmetic ONE more swap of (gbar_v.re, gbar_v.im) puts gbar_v back in the layout v had (the re lane keeps the
+  // apart and share the work: v_permlane16_swap(v[4 g + i], v[4 g + i + 2]) hands the re lane (re, im) of channel i and the im lane (re, im)
+  // of channel i + 2; after the arithmetic ONE more swap of (gbar_v.re, gbar_v.im) puts gbar_v into the layout v had (the re lane keeps the
   // real part of its channel and receives the real part of the im lane's channel; the im lane the imaginary parts), no selects.
-  auto element_stage = [&](f32x16& acc, int cb, int next_cb, const GainRegs& GR) {
-    const unsigned cb8 = (unsigned)cb * (kCB * 8u);
-    cf2 lt = {0.f, 0.f}, st_r = {0.f, 0.f}, st_i = {0.f, 0.f};
+  // In three parts, so that the stage of a pair's SECOND block can run between the MFMAs of the first block's adjoint (a wave alone on its
+  // SIMD has nobody else to fill the issue slots a chain of dependent MFMAs leaves free):
+  //   e_begin  waits for the block's samples, reads them into registers, requests the next block's into the staging area
+  //   e_chunk  one register group: arithmetic only (and one gbar_G store) -- nothing the compiler may not move between MFMAs
+  //   e_end    the loss partials
+  struct EState { cf2 s_dr[4], s_di[4], s_w[4], lt, st_r, st_i; };
+  auto e_begin = [&](EState& S, int next_cb) {
+    S.lt = cf2{0.f, 0.f}; S.st_r = cf2{0.f, 0.f}; S.st_i = cf2{0.f, 0.f};
     SPL_T(tw0);
     wait_vm_dyn(issued - markS);
     SPL_ADD(cyc_sw, tw0);
-    // the block's samples, all of them at once: the staging area is then free for the next block's (requested a whole adjoint phase ahead)
-    cf2 s_dr[4], s_di[4], s_w[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int so = ((g >> 1) * 64 + 32 * (g & 1)) * 16;
-      s_dr[g] = *reinterpret_cast<const cf2*>(smp_rd + so);
-      s_di[g] = *reinterpret_cast<const cf2*>(smp_rd + 2048 + so);
-      s_w[g] = *reinterpret_cast<const cf2*>(smp_rd + 4096 + so);
+      S.s_dr[g] = *reinterpret_cast<const cf2*>(smp_rd + so);
+      S.s_di[g] = *reinterpret_cast<const cf2*>(smp_rd + 2048 + so);
+      S.s_w[g] = *reinterpret_cast<const cf2*>(smp_rd + 4096 + so);
     }
     if (next_cb >= 0) {
+      // the staging area is free once the reads above have returned: the next block's samples go into it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       smp_issue(next_cb);
       __builtin_amdgcn_sched_barrier(0);
     }
-#ifdef CAL_STAMP
     SPL_ADD(cyc_eg, tw0);
-    SPL_T(tl0);
-#endif
-    // Per register group the lane's two channels a, b are computed side by side: every quantity is a pair (x_a, x_b) in two adjacent registers
-    // and every operation one packed instruction, no shuffles: after the two swaps acc[4 g], acc[4 g + 1] = (v_re a, v_re b) and
-    // acc[4 g + 2], acc[4 g + 3] = (v_im a, v_im b) ARE such pairs, the samples arrive as (d a, d b), and gbar_v is written back the same way.
+  };
+  // Per register group the lane's two channels a, b are computed side by side: every quantity is a pair (x_a, x_b) in two adjacent registers
+  // and every operation one packed instruction, no shuffles: after the two swaps (v[4 g], v[4 g + 1]) = (v_re a, v_re b) and
+  // (v[4 g + 2], v[4 g + 3]) = (v_im a, v_im b) ARE such pairs, the samples arrive as (d a, d b), and gbar_v leaves the same way.
+  auto e_chunk = [&](EState& S, const f32x16& v, f32x16& gout, const GainRegs& GR, int cb, int g) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned cb8 = (unsigned)cb * (kCB * 8u);
+    cf2 vr, vi;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      typedef unsigned u2 __attribute__((ext_vector_type(2)));
-      cf2 vr, vi;
+    for (int i = 0; i < 2; ++i) {
+      // (bit_cast applied to a vector ELEMENT expression reads element 0 with this hipcc: go through scalars)
+      const float xa = v[4 * g + i], xb = v[4 * g + i + 2];
+      const u2 pr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, xb), false, false);
+      const unsigned p0 = pr[0], p1 = pr[1];
+      vr[i] = __builtin_bit_cast(float, p0);
+      vi[i] = __builtin_bit_cast(float, p1);
+    }
+    // G = g_i conj(g_j)  (calibration.py:1598-1601): the gains arrive as (re, im) per channel
+    const cf2 g0r = {GR.a[g][0], GR.a[g][2]}, g0i = {GR.a[g][1], GR.a[g][3]}, g1r = {GR.b[g][0], GR.b[g][2]}, g1i = {GR.b[g][1], GR.b[g][3]};
+    const cf2 Gr = g0r * g1r + g0i * g1i, Gi = g0i * g1r - g0r * g1i;
+    const cf2 mr = Gr * vr - Gi * vi, mi = Gi * vr + Gr * vi;  // model = G v  (:1602-1604)
+    const cf2 rr = S.s_dr[g] - mr, ri = S.s_di[g] - mi;
+    const cf2 w = S.s_w[g];
+    S.lt += (rr * rr + ri * ri) * w;  // (:1609)
+    S.st_r += mr * w;                 // S = sum w m of the "sum" regulariser (calibration.py:1648-1649)
+    S.st_i += mi * w;
+    if (GRAD) {
+      const cf2 er = (rr * -2.f + alpha.x) * w, ei = (ri * -2.f + alpha.y) * w;  // e = -2 w r + alpha w
+      const cf2 gvr = Gr * er + Gi * ei, gvi = Gr * ei - Gi * er;                // gbar_v = conj(G) e
+      const cf2 gqr = vr * er + vi * ei, gqi = vr * ei - vi * er;                // gbar_G = conj(v) e
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        // (bit_cast applied to a vector ELEMENT expression reads element 0 with this hipcc: go through scalars)
-        const float xa = acc[4 * g + i], xb = acc[4 * g + i + 2];
-        const u2 pr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, xb), false, false);
-        const unsigned p0 = pr[0], p1 = pr[1];
-        vr[i] = __builtin_bit_cast(float, p0);
-        vi[i] = __builtin_bit_cast(float, p1);
+        const float fx = gvr[i], fy = gvi[i];
+        const u2 qr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, fx), __builtin_bit_cast(unsigned, fy), false, false);
+        const unsigned q0b = qr[0], q1b = qr[1];
+        gout[4 * g + i] = __builtin_bit_cast(float, q0b);
+        gout[4 * g + i + 2] = __builtin_bit_cast(float, q1b);
       }
-      // G = g_i conj(g_j)  (calibration.py:1598-1601): the gains arrive as (re, im) per channel
-      const cf2 g0r = {GR.a[g][0], GR.a[g][2]}, g0i = {GR.a[g][1], GR.a[g][3]}, g1r = {GR.b[g][0], GR.b[g][2]}, g1i = {GR.b[g][1], GR.b[g][3]};
-      const cf2 Gr = g0r * g1r + g0i * g1i, Gi = g0i * g1r - g0r * g1i;
-      const cf2 mr = Gr * vr - Gi * vi, mi = Gi * vr + Gr * vi;  // model = G v  (:1602-1604)
-      const cf2 rr = s_dr[g] - mr, ri = s_di[g] - mi;
-      const cf2 w = s_w[g];
-      lt += (rr * rr + ri * ri) * w;  // (:1609)
-      st_r += mr * w;                 // S = sum w m of the "sum" regulariser (calibration.py:1648-1649)
-      st_i += mi * w;
-      if (GRAD) {
-        const cf2 er = (rr * -2.f + alpha.x) * w, ei = (ri * -2.f + alpha.y) * w;  // e = -2 w r + alpha w
-        const cf2 gvr = Gr * er + Gi * ei, gvi = Gr * ei - Gi * er;                // gbar_v = conj(G) e
-        const cf2 gqr = vr * er + vi * ei, gqi = vr * ei - vi * er;                // gbar_G = conj(v) e
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const float fx = gvr[i], fy = gvi[i];
-          const u2 qr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, fx), __builtin_bit_cast(unsigned, fy), false, false);
-          const unsigned q0b = qr[0], q1b = qr[1];
-          acc[4 * g + i] = __builtin_bit_cast(float, q0b);
-          acc[4 * g + i + 2] = __builtin_bit_cast(float, q1b);
-        }
 #if defined(CAL_X_QSMALL)  // (ablation: the stores go to 256 KB that stay in L2)
-        if (primary) *reinterpret_cast<f32x4*>(p_q + ((obq + cb8 + 64u * g) & 0x3FFF0u)) = f32x4{gqr[0], gqi[0], gqr[1], gqi[1]};
+      *reinterpret_cast<f32x4*>(p_q + ((obq + cb8 + 64u * g) & 0x3FFF0u)) = f32x4{gqr[0], gqi[0], gqr[1], gqi[1]};
 #elif !defined(CAL_X_NOQ)
-        if (primary) *reinterpret_cast<f32x4*>(p_q + (obq + cb8 + 64u * g)) = f32x4{gqr[0], gqi[0], gqr[1], gqi[1]};
+      *reinterpret_cast<f32x4*>(p_q + (obq + cb8 + 64u * g)) = f32x4{gqr[0], gqi[0], gqr[1], gqi[1]};
 #endif
-      }
     }
-    SPL_ADD(cyc_el, tl0);
-    SPL_T(tq0);
-    if (primary) {
-      loss_acc += (double)(lt.x + lt.y);
-      sr_acc += (double)(st_r.x + st_r.y);
-      si_acc += (double)(st_i.x + st_i.y);
-    }
-    SPL_ADD(cyc_es, tq0);
   };
-  // ---- B: adjoint of one channel block: dC[t] += A[ch, 32 t ...]^T gbar_v, a group = two tiles x two K-steps of 16 channels (the two tiles'
-  // chains interleaved: a dependent MFMA waits for its predecessor).  `pre`: called in front of the MFMAs of the block's LAST group
-  auto adjoint = [&](const f32x16& acc, auto&& pre) {
-    SPL_T(tb0);
-    bf16x8 g1[2], g2[2], g3[2];
+  auto e_end = [&](const EState& S) {
+    loss_acc += (double)(S.lt.x + S.lt.y);
+    sr_acc += (double)(S.st_r.x + S.st_r.y);
+    si_acc += (double)(S.st_i.x + S.st_i.y);
+  };
+  // gbar_v (16 fp32 per lane: two K-steps of 16 channels) -> three bf16 planes: the B operand of the adjoint
+  struct Planes { bf16x8 p1[2], p2[2], p3[2]; };
+  auto split_gbar = [&](const f32x16& gv, Planes& P) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float x[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = acc[8 * q + j];
+      for (int j = 0; j < 8; ++j) x[j] = gv[8 * q + j];
 #ifdef CAL_X_NOGSPLIT
-      split3<true>(x, g1[q], g2[q], g3[q]);
+      split3<true>(x, P.p1[q], P.p2[q], P.p3[q]);
 #else
-      split3(x, g1[q], g2[q], g3[q]);
+      split3(x, P.p1[q], P.p2[q], P.p3[q]);
 #endif
     }
-#ifdef CAL_STAMP
-    asm volatile("" : "+v"(g1[1]), "+v"(g2[1]), "+v"(g3[1]));
-    SPL_ADD(cyc_bs, tb0);
-#endif
+  };
+  // ---- B: one adjoint group: dC[2 e], dC[2 e + 1] += A[ch, tile]^T gbar_v over two K-steps of 16 channels, the two tiles' chains interleaved
+  // (a dependent MFMA waits for its predecessor).  `between(k)`, k = 0..3: called between the four batches of MFMAs -- vector work placed there
+  // issues in the slots the MFMA chains leave free
+  auto adjoint_group = [&](const Planes& P, int e, auto two_tag, auto&& between) {
+    constexpr bool two = decltype(two_tag)::value;
+    const int at = group_begin();
+    f32x16& D0 = dC[2 * e];
+    f32x16& D1 = dC[two ? 2 * e + 1 : 2 * e];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o0 = at + (q * 3) * 64, o1 = at + ((2 + q) * 3) * 64;
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, ring_rd[o0]), a2 = __builtin_bit_cast(bf16x8, ring_rd[o0 + 64]),
+                   a3 = __builtin_bit_cast(bf16x8, ring_rd[o0 + 128]);
+      if (two) {
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, ring_rd[o1]), b2 = __builtin_bit_cast(bf16x8, ring_rd[o1 + 64]),
+                     b3 = __builtin_bit_cast(bf16x8, ring_rd[o1 + 128]);
+        CAL_MFMA_BF16(a3, P.p1[q], D0);
+        CAL_MFMA_BF16(b3, P.p1[q], D1);
+        CAL_MFMA_BF16(a2, P.p2[q], D0);
+        CAL_MFMA_BF16(b2, P.p2[q], D1);
+        CAL_MFMA_BF16(a1, P.p3[q], D0);
+        CAL_MFMA_BF16(b1, P.p3[q], D1);
+        between(2 * q);
+        CAL_MFMA_BF16(a2, P.p1[q], D0);
+        CAL_MFMA_BF16(b2, P.p1[q], D1);
+        CAL_MFMA_BF16(a1, P.p2[q], D0);
+        CAL_MFMA_BF16(b1, P.p2[q], D1);
+        CAL_MFMA_BF16(a1, P.p1[q], D0);
+        CAL_MFMA_BF16(b1, P.p1[q], D1);
+        between(2 * q + 1);
+      } else {
+        CAL_MFMA_BF16(a3, P.p1[q], D0);
+        CAL_MFMA_BF16(a2, P.p2[q], D0);
+        CAL_MFMA_BF16(a1, P.p3[q], D0);
+        between(2 * q);
+        CAL_MFMA_BF16(a2, P.p1[q], D0);
+        CAL_MFMA_BF16(a1, P.p2[q], D0);
+        CAL_MFMA_BF16(a1, P.p1[q], D0);
+        between(2 * q + 1);
+      }
+    }
+  };
+  // the adjoint of one channel block; `first()` runs in front of the MFMAs of the block's LAST group, `between(k)` between its batches
+  auto adjoint = [&](const Planes& P, auto&& first, auto&& between) {
+    SPL_T(tb0);
+    auto none = [](int) {};
 #pragma unroll
     for (int e = 0; e < NTMAX / 2; ++e) {
       if (e < ntd) {  // wave-uniform
-        const int at = group_begin();
-        if (e == ntd - 1) pre();
+        const bool last = e == ntd - 1;
         const bool two = 2 * e + 1 < NT;  // wave-uniform: the group's second tile exists
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int o0 = at + (q * 3) * 64, o1 = at + ((2 + q) * 3) * 64;
-          const bf16x8 a1 = __builtin_bit_cast(bf16x8, ring_rd[o0]), a2 = __builtin_bit_cast(bf16x8, ring_rd[o0 + 64]),
-                       a3 = __builtin_bit_cast(bf16x8, ring_rd[o0 + 128]);
-          if (two) {
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, ring_rd[o1]), b2 = __builtin_bit_cast(bf16x8, ring_rd[o1 + 64]),
-                         b3 = __builtin_bit_cast(bf16x8, ring_rd[o1 + 128]);
-            f32x16& D0 = dC[2 * e];
-            f32x16& D1 = dC[2 * e + 1];
-            CAL_MFMA_BF16(a3, g1[q], D0);
-            CAL_MFMA_BF16(b3, g1[q], D1);
-            CAL_MFMA_BF16(a2, g2[q], D0);
-            CAL_MFMA_BF16(b2, g2[q], D1);
-            CAL_MFMA_BF16(a1, g3[q], D0);
-            CAL_MFMA_BF16(b1, g3[q], D1);
-            CAL_MFMA_BF16(a2, g1[q], D0);
-            CAL_MFMA_BF16(b2, g1[q], D1);
-            CAL_MFMA_BF16(a1, g2[q], D0);
-            CAL_MFMA_BF16(b1, g2[q], D1);
-            CAL_MFMA_BF16(a1, g1[q], D0);
-            CAL_MFMA_BF16(b1, g1[q], D1);
-          } else {
-            f32x16& D0 = dC[2 * e];
-            CAL_MFMA_BF16(a3, g1[q], D0);
-            CAL_MFMA_BF16(a2, g2[q], D0);
-            CAL_MFMA_BF16(a1, g3[q], D0);
-            CAL_MFMA_BF16(a2, g1[q], D0);
-            CAL_MFMA_BF16(a1, g2[q], D0);
-            CAL_MFMA_BF16(a1, g1[q], D0);
-          }
+        if (!last) {  // (every group but a block's last carries two tiles)
+          adjoint_group(P, e, std::true_type{}, none);
+        } else {
+          first();
+          if (two) adjoint_group(P, e, std::true_type{}, between);
+          else adjoint_group(P, e, std::false_type{}, between);
         }
       }
     }
+    SPL_ADD(cyc_bs, tb0);
   };
   // ---- F: one forward group: two K-steps x (cb0, cb1)
   auto forward_group = [&](f32x16& acc0, f32x16& acc1, int d, auto&& pre) {
@@ -504,25 +529,40 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     f32x16 acc0, acc1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
-    GainRegs GR, GR1;
+    GainRegs GR0, GR1;
     for (int d = 0; d + 1 < ngd; ++d) forward_group(acc0, acc1, d, [] {});
-    forward_group(acc0, acc1, ngd - 1, [&] {
-      gains_request(GR, 2 * cp);
-      if (!GRAD) gains_request(GR1, 2 * cp + 1);  // (the loss-only pass has no adjoint phase to hide the second block's round trip, and registers to spare)
+    forward_group(acc0, acc1, ngd - 1, [&] {  // (the gains of both blocks: 64 of the wave's 512 registers)
+      gains_request(GR0, 2 * cp);
+      gains_request(GR1, 2 * cp + 1);
     });
     SPL_T(t1);
     SPL_ADD(cyc_f, t_f0);
-    element_stage(acc0, 2 * cp, 2 * cp + 1, GR);
+    const int next_pair_cb = cp + 1 < ncp ? 2 * cp + 2 : -1;
+    f32x16 gv0, gv1;
+    EState S0, S1;
+    e_begin(S0, 2 * cp + 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_chunk(S0, acc0, gv0, GR0, 2 * cp, g);
+    e_end(S0);
     SPL_T(t2);
     SPL_ADD(cyc_e, t1);
-    if (GRAD) adjoint(acc0, [&] { gains_request(GR1, 2 * cp + 1); });
-    SPL_T(t3);
-    SPL_ADD(cyc_b, t2);
-    element_stage(acc1, 2 * cp + 1, cp + 1 < ncp ? 2 * cp + 2 : -1, GR1);
-    SPL_T(t4);
-    SPL_ADD(cyc_e, t3);
-    if (GRAD) adjoint(acc1, [] {});
-    SPL_ADD(cyc_b, t4);
+    if (GRAD) {
+      Planes P0, P1;
+      split_gbar(gv0, P0);
+      // the adjoint of cb0, with the element stage of cb1 between the MFMAs of its last group
+      adjoint(P0, [&] { e_begin(S1, next_pair_cb); }, [&](int k) { e_chunk(S1, acc1, gv1, GR1, 2 * cp + 1, k); });
+      e_end(S1);
+      SPL_T(t3);
+      SPL_ADD(cyc_b, t2);
+      split_gbar(gv1, P1);
+      adjoint(P1, [] {}, [](int) {});
+      SPL_ADD(cyc_b, t3);
+    } else {
+      e_begin(S1, next_pair_cb);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_chunk(S1, acc1, gv1, GR1, 2 * cp + 1, g);
+      e_end(S1);
+    }
   }
   RING_WAIT(0);  // nothing may still be writing into this workgroup's LDS when it ends
 
