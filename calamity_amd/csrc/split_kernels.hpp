@@ -116,7 +116,11 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& p1, bf16x8& 
   }
 }
 
+#ifdef CAL_X_NOMFMA  // (ablation: everything but the matrix instructions)
+#define CAL_MFMA_BF16(A_, B_, C_) asm volatile("" : "+v"(C_) : "v"(A_), "v"(B_))
+#else
 #define CAL_MFMA_BF16(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
+#endif
 
 typedef float cf2 __attribute__((ext_vector_type(2)));  // a pair of fp32: the element stage computes on the lane's two channels at once (v_pk_*)
 
@@ -202,7 +206,9 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     const unsigned off = base + (unsigned)(rq_cp * GP + rq_d) * (unsigned)kGroupBytes;
 #endif
     const unsigned lds = ring_lds + (unsigned)(rq_slot * 4 + wave) * (unsigned)kPosBytes;
+#ifndef CAL_X_NOAREQ  // (ablation: no operand requests)
     dma3(lds, ops_u, voff + off);
+#endif
     issued += 3;
     if (rq_cp < ncp - 1 || rq_d < g_used - 1) {
       ++rq_d;
@@ -274,7 +280,9 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   auto group_begin = [&]() -> int {  // -> f32x4 index (without the lane) of the group's first plane
     SPL_T(ts0);
     wait_vm_dyn(issued - markA[0]);
+#ifndef CAL_X_NOBAR  // (ablation: the waves do not meet)
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
     SPL_ADD(cyc_sync, ts0);
 #pragma unroll
@@ -310,7 +318,12 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   // a group later those have landed anyway.  (Requested inside the element stage the round trip was exposed: 2 500 of its 5 400 ticks.)
   struct GainRegs { f32x4 a[4], b[4]; };
   auto gains_request = [&](GainRegs& R, int cb) {
+#ifdef CAL_X_NOGAIN  // (ablation: the same gains for every block)
+    const unsigned cb8 = 0;
+    if (cb > 1) return;
+#else
     const unsigned cb8 = (unsigned)cb * (kCB * 8u);
+#endif
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       R.a[g] = *reinterpret_cast<const f32x4*>(p_g + (og0 + cb8 + 64u * g));
@@ -328,6 +341,19 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   //   e_begin  waits for the block's samples, reads them into registers, requests the next block's into the staging area
   //   e_chunk  one register group: arithmetic only (and one gbar_G store) -- nothing the compiler may not move between MFMAs
   //   e_end    the loss partials
+  // G = g_i conj(g_j) (calibration.py:1598-1601) of the lane's eight channels, as pairs per register group.  Formed from BOTH blocks' gains at the
+  // start of the first block's stage, in front of its sample request: the compiler waits for a load it tracks with s_waitcnt vmcnt(its own
+  // younger loads) -- a count that knows nothing of the LDS-DMA requests, so a gain consumed AFTER a request went out waits for that request
+  // too (the samples come from HBM: two exposed round trips per pair of channel blocks, 40 % of the wave's time, before this was moved).
+  struct GProd { cf2 r[4], i[4]; };
+  auto gains_product = [&](const GainRegs& GR, GProd& G) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const cf2 g0r = {GR.a[g][0], GR.a[g][2]}, g0i = {GR.a[g][1], GR.a[g][3]}, g1r = {GR.b[g][0], GR.b[g][2]}, g1i = {GR.b[g][1], GR.b[g][3]};
+      G.r[g] = g0r * g1r + g0i * g1i;
+      G.i[g] = g0i * g1r - g0r * g1i;
+    }
+  };
   struct EState { cf2 s_dr[4], s_di[4], s_w[4], lt, st_r, st_i; };
   auto e_begin = [&](EState& S, int next_cb) {
     S.lt = cf2{0.f, 0.f}; S.st_r = cf2{0.f, 0.f}; S.st_i = cf2{0.f, 0.f};
@@ -353,8 +379,12 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   // Per register group the lane's two channels a, b are computed side by side: every quantity is a pair (x_a, x_b) in two adjacent registers
   // and every operation one packed instruction, no shuffles: after the two swaps (v[4 g], v[4 g + 1]) = (v_re a, v_re b) and
   // (v[4 g + 2], v[4 g + 3]) = (v_im a, v_im b) ARE such pairs, the samples arrive as (d a, d b), and gbar_v leaves the same way.
-  auto e_chunk = [&](EState& S, const f32x16& v, f32x16& gout, const GainRegs& GR, int cb, int g) {
+  auto e_chunk = [&](EState& S, const f32x16& v, f32x16& gout, const GProd& GP_, int cb, int g) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
+#ifdef CAL_X_NOE  // (ablation: no element arithmetic, no gbar_G stores)
+    gout[4 * g] = v[4 * g] + S.s_dr[g].x; gout[4 * g + 1] = v[4 * g + 1] + GP_.r[g].x; gout[4 * g + 2] = v[4 * g + 2]; gout[4 * g + 3] = v[4 * g + 3];
+    return;
+#endif
     const unsigned cb8 = (unsigned)cb * (kCB * 8u);
     cf2 vr, vi;
 #pragma unroll
@@ -366,9 +396,7 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
       vr[i] = __builtin_bit_cast(float, p0);
       vi[i] = __builtin_bit_cast(float, p1);
     }
-    // G = g_i conj(g_j)  (calibration.py:1598-1601): the gains arrive as (re, im) per channel
-    const cf2 g0r = {GR.a[g][0], GR.a[g][2]}, g0i = {GR.a[g][1], GR.a[g][3]}, g1r = {GR.b[g][0], GR.b[g][2]}, g1i = {GR.b[g][1], GR.b[g][3]};
-    const cf2 Gr = g0r * g1r + g0i * g1i, Gi = g0i * g1r - g0r * g1i;
+    const cf2 Gr = GP_.r[g], Gi = GP_.i[g];
     const cf2 mr = Gr * vr - Gi * vi, mi = Gi * vr + Gr * vi;  // model = G v  (:1602-1604)
     const cf2 rr = S.s_dr[g] - mr, ri = S.s_di[g] - mi;
     const cf2 w = S.s_w[g];
@@ -422,36 +450,53 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     const int at = group_begin();
     f32x16& D0 = dC[2 * e];
     f32x16& D1 = dC[two ? 2 * e + 1 : 2 * e];
+    // every operand of the group is requested from LDS before the first MFMA: one read latency per group, not one per batch (the wave is
+    // alone on its SIMD: nobody else covers an LDS round trip)
+    bf16x8 a[2][3], b[2][3];
+#ifdef CAL_X_NOLDS  // (ablation: no operand reads)
+    const int at_ = 0;
+    (void)at;
+#else
+    const int at_ = at;
+#endif
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#ifdef CAL_X_NOLDS
+        a[q][pl] = __builtin_bit_cast(bf16x8, f32x4{(float)at_, 1.f, 2.f, (float)pl});
+        if (two) b[q][pl] = a[q][pl];
+#else
+        a[q][pl] = __builtin_bit_cast(bf16x8, ring_rd[at_ + (q * 3 + pl) * 64]);
+        if (two) b[q][pl] = __builtin_bit_cast(bf16x8, ring_rd[at_ + ((2 + q) * 3 + pl) * 64]);
+#endif
+      }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int o0 = at + (q * 3) * 64, o1 = at + ((2 + q) * 3) * 64;
-      const bf16x8 a1 = __builtin_bit_cast(bf16x8, ring_rd[o0]), a2 = __builtin_bit_cast(bf16x8, ring_rd[o0 + 64]),
-                   a3 = __builtin_bit_cast(bf16x8, ring_rd[o0 + 128]);
       if (two) {
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, ring_rd[o1]), b2 = __builtin_bit_cast(bf16x8, ring_rd[o1 + 64]),
-                     b3 = __builtin_bit_cast(bf16x8, ring_rd[o1 + 128]);
-        CAL_MFMA_BF16(a3, P.p1[q], D0);
-        CAL_MFMA_BF16(b3, P.p1[q], D1);
-        CAL_MFMA_BF16(a2, P.p2[q], D0);
-        CAL_MFMA_BF16(b2, P.p2[q], D1);
-        CAL_MFMA_BF16(a1, P.p3[q], D0);
-        CAL_MFMA_BF16(b1, P.p3[q], D1);
+        CAL_MFMA_BF16(a[q][2], P.p1[q], D0);
+        CAL_MFMA_BF16(b[q][2], P.p1[q], D1);
+        CAL_MFMA_BF16(a[q][1], P.p2[q], D0);
+        CAL_MFMA_BF16(b[q][1], P.p2[q], D1);
+        CAL_MFMA_BF16(a[q][0], P.p3[q], D0);
+        CAL_MFMA_BF16(b[q][0], P.p3[q], D1);
         between(2 * q);
-        CAL_MFMA_BF16(a2, P.p1[q], D0);
-        CAL_MFMA_BF16(b2, P.p1[q], D1);
-        CAL_MFMA_BF16(a1, P.p2[q], D0);
-        CAL_MFMA_BF16(b1, P.p2[q], D1);
-        CAL_MFMA_BF16(a1, P.p1[q], D0);
-        CAL_MFMA_BF16(b1, P.p1[q], D1);
+        CAL_MFMA_BF16(a[q][1], P.p1[q], D0);
+        CAL_MFMA_BF16(b[q][1], P.p1[q], D1);
+        CAL_MFMA_BF16(a[q][0], P.p2[q], D0);
+        CAL_MFMA_BF16(b[q][0], P.p2[q], D1);
+        CAL_MFMA_BF16(a[q][0], P.p1[q], D0);
+        CAL_MFMA_BF16(b[q][0], P.p1[q], D1);
         between(2 * q + 1);
       } else {
-        CAL_MFMA_BF16(a3, P.p1[q], D0);
-        CAL_MFMA_BF16(a2, P.p2[q], D0);
-        CAL_MFMA_BF16(a1, P.p3[q], D0);
+        CAL_MFMA_BF16(a[q][2], P.p1[q], D0);
+        CAL_MFMA_BF16(a[q][1], P.p2[q], D0);
+        CAL_MFMA_BF16(a[q][0], P.p3[q], D0);
         between(2 * q);
-        CAL_MFMA_BF16(a2, P.p1[q], D0);
-        CAL_MFMA_BF16(a1, P.p2[q], D0);
-        CAL_MFMA_BF16(a1, P.p1[q], D0);
+        CAL_MFMA_BF16(a[q][1], P.p1[q], D0);
+        CAL_MFMA_BF16(a[q][0], P.p2[q], D0);
+        CAL_MFMA_BF16(a[q][0], P.p1[q], D0);
         between(2 * q + 1);
       }
     }
@@ -479,10 +524,23 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
   // ---- F: one forward group: two K-steps x (cb0, cb1)
   auto forward_group = [&](f32x16& acc0, f32x16& acc1, int d, auto&& pre) {
     const int at = group_begin();
-    // the two K-steps' coefficients, from the wave's resident panel
+    // the two K-steps' coefficients (from the wave's resident panel) and every operand of the group, requested from LDS before the first MFMA
     f32x4 cq[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cq[j] = cr_rd[d * 256 + j * 64];
+    bf16x8 a0[2][3], a1[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#ifdef CAL_X_NOLDS
+        a0[ks][p] = __builtin_bit_cast(bf16x8, f32x4{(float)at, 1.f, 2.f, (float)p});
+        a1[ks][p] = a0[ks][p];
+#else
+        a0[ks][p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks) * 3 + p) * 64]);
+        a1[ks][p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks + 1) * 3 + p) * 64]);
+#endif
+      }
     pre();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -497,24 +555,18 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
           split3(x, c1, c2, c3);
 #endif
         }
-        bf16x8 a0[3], a1[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          a0[p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks) * 3 + p) * 64]);
-          a1[p] = __builtin_bit_cast(bf16x8, ring_rd[at + ((2 * ks + 1) * 3 + p) * 64]);
-        }
-        CAL_MFMA_BF16(a0[2], c1, acc0);
-        CAL_MFMA_BF16(a1[2], c1, acc1);
-        CAL_MFMA_BF16(a0[1], c2, acc0);
-        CAL_MFMA_BF16(a1[1], c2, acc1);
-        CAL_MFMA_BF16(a0[0], c3, acc0);
-        CAL_MFMA_BF16(a1[0], c3, acc1);
-        CAL_MFMA_BF16(a0[1], c1, acc0);
-        CAL_MFMA_BF16(a1[1], c1, acc1);
-        CAL_MFMA_BF16(a0[0], c2, acc0);
-        CAL_MFMA_BF16(a1[0], c2, acc1);
-        CAL_MFMA_BF16(a0[0], c1, acc0);
-        CAL_MFMA_BF16(a1[0], c1, acc1);
+        CAL_MFMA_BF16(a0[ks][2], c1, acc0);
+        CAL_MFMA_BF16(a1[ks][2], c1, acc1);
+        CAL_MFMA_BF16(a0[ks][1], c2, acc0);
+        CAL_MFMA_BF16(a1[ks][1], c2, acc1);
+        CAL_MFMA_BF16(a0[ks][0], c3, acc0);
+        CAL_MFMA_BF16(a1[ks][0], c3, acc1);
+        CAL_MFMA_BF16(a0[ks][1], c1, acc0);
+        CAL_MFMA_BF16(a1[ks][1], c1, acc1);
+        CAL_MFMA_BF16(a0[ks][0], c2, acc0);
+        CAL_MFMA_BF16(a1[ks][0], c2, acc1);
+        CAL_MFMA_BF16(a0[ks][0], c1, acc0);
+        CAL_MFMA_BF16(a1[ks][0], c1, acc1);
       }
     }
   };
@@ -540,9 +592,16 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     const int next_pair_cb = cp + 1 < ncp ? 2 * cp + 2 : -1;
     f32x16 gv0, gv1;
     EState S0, S1;
+    GProd G0, G1;
+    gains_product(GR0, G0);
+    gains_product(GR1, G1);
+    // (pin the products here: everything the compiler waits for must have been waited for before the next request is issued)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(G0.r[g]), "+v"(G0.i[g]), "+v"(G1.r[g]), "+v"(G1.i[g]));
+    __builtin_amdgcn_sched_barrier(0);
     e_begin(S0, 2 * cp + 1);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) e_chunk(S0, acc0, gv0, GR0, 2 * cp, g);
+    for (int g = 0; g < 4; ++g) e_chunk(S0, acc0, gv0, G0, 2 * cp, g);
     e_end(S0);
     SPL_T(t2);
     SPL_ADD(cyc_e, t1);
@@ -550,7 +609,7 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
       Planes P0, P1;
       split_gbar(gv0, P0);
       // the adjoint of cb0, with the element stage of cb1 between the MFMAs of its last group
-      adjoint(P0, [&] { e_begin(S1, next_pair_cb); }, [&](int k) { e_chunk(S1, acc1, gv1, GR1, 2 * cp + 1, k); });
+      adjoint(P0, [&] { e_begin(S1, next_pair_cb); }, [&](int k) { e_chunk(S1, acc1, gv1, G1, 2 * cp + 1, k); });
       e_end(S1);
       SPL_T(t3);
       SPL_ADD(cyc_b, t2);
@@ -560,7 +619,7 @@ __device__ __forceinline__ void split_panel(const MfmaArgs& A, unsigned char* sm
     } else {
       e_begin(S1, next_pair_cb);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) e_chunk(S1, acc1, gv1, GR1, 2 * cp + 1, g);
+      for (int g = 0; g < 4; ++g) e_chunk(S1, acc1, gv1, G1, 2 * cp + 1, g);
       e_end(S1);
     }
   }
