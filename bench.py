@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 MFMA_F64_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate (128 FLOP/clk/CU x 256 CUs x 2.4 GHz)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16: 32768 flops per 32 cycles and SIMD)
 
 
 def parse():
@@ -97,7 +98,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("fit_kernels.hpp", "dense_kernels.hpp", "dense64_kernels.hpp", "multi_mfma_kernels.hpp", "calamity_hip.hip"):
+    for name in ("fit_kernels.hpp", "dense_kernels.hpp", "split_kernels.hpp", "dense64_kernels.hpp", "multi_mfma_kernels.hpp", "calamity_hip.hip"):
         with open(os.path.join(ROOT, "calamity_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -223,10 +224,22 @@ def dense_traffic(config, dtype):
     return pmc.get("gradient_pass", {}).get("hbm_bytes"), os.path.relpath(path, ROOT)
 
 
+def split_issued_flops(prob):
+    """bf16 flops the split-bf16 dense kernel ISSUES per gradient launch (split_kernels.hpp): six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16
+    block of the fp32 product, blocks padded to 16 vectors (forward) / 32 vectors (adjoint), panels to 16 and super-panels to 64 baselines."""
+    nv = np.asarray([b.shape[1] for b in prob.basis])
+    nbl = np.bincount(prob.grp_basis[np.repeat(np.arange(prob.ngrps), np.diff(prob.grp_bl_start))], minlength=len(nv))
+    fpad = -(-prob.nfreqs // 128) * 128
+    waves = -(-nbl // 64) * 4
+    mfma_per_wave = (fpad // 64) * (12 * -(-nv // 16) + 24 * -(-nv // 32))
+    return float(np.sum(waves * mfma_per_wave)) * 2.0 * 32 * 32 * 16
+
+
 def dense_rooflines(prob, tim, kernel_ms, dtype, config=None):
     """Both bounds of the dense (shared-layout) kernel from its measured launch duration: the matrix pipe for
     8 F sum nvec flops, and HBM for the algorithmic bytes with every DISTINCT basis block counted once."""
     f32 = dtype == np.float32
+    split = f32 and tim.get("kernel_path") == "dense"
     traffic, traffic_src = dense_traffic(config, dtype) if config else (None, None)
     peak = MFMA_F32_PEAK_TFLOPS if f32 else MFMA_F64_PEAK_TFLOPS
     flops = tim["flops_per_launch"]
@@ -234,14 +247,23 @@ def dense_rooflines(prob, tim, kernel_ms, dtype, config=None):
     uniq_bytes = float(sum(b.size for b in prob.basis)) * np.dtype(dtype).itemsize
     bytes_unique = tim["algorithmic_bytes_per_launch"] - tim["basis_bytes_per_launch"] + uniq_bytes
     gbs = bytes_unique / (kernel_ms * 1e-3) / 1e9
-    return {
-        "kernel": "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)" if f32 else "fused_dense64_kernel<GRAD> (v_mfma_f64_16x16x4_f64)",
+    out = {
+        "kernel": ("fused_dense_split_kernel<GRAD> (six v_mfma_f32_32x32x16_bf16 per fp32 product block: split-bf16 operands)" if split else
+                   "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)") if f32 else "fused_dense64_kernel<GRAD> (v_mfma_f64_16x16x4_f64)",
         "kernel_ms": kernel_ms,
+        # the USEFUL flops (8 F sum nvec: an fp32 product per (channel, vector, re | im), forward and adjoint) against the fp32 matrix peak:
+        # the yardstick every fp32 dense kernel of this repository is held to, whatever instruction it issues
         "roofline_mfma": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "flops_per_launch": flops,
                           "traffic": traffic, "traffic_source": traffic_src},
         "roofline_hbm_unique_basis": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_launch": bytes_unique},
     }
+    if split:
+        issued = split_issued_flops(prob) * (1.5 if tim["flops_per_launch"] > 8.5 * prob.nfreqs * prob.ncoeffs else 1.0)  # (regularised step: + a loss-only pass)
+        out["roofline_bf16_issued"] = {"bound": "mfma", "achieved": issued / (kernel_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": issued / (kernel_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "flops_per_launch": issued,
+                                       "note": "bf16 flops issued (6 per useful fp32 flop + padding) against the dense bf16 peak"}
+    return out
 
 
 def self_launch(args):
@@ -437,6 +459,24 @@ def main():
         shared = dense_rooflines(prob, tim2, k2, dtype, args.config if args.max_bls is None else None)
         shared.update(steps_per_s=args.steps / dt2, ms_per_step=dt2 / args.steps * 1e3, device_memory_GB=s2.memory_bytes() / 1e9)
         s2.close()
+        if dtype == np.float32 and tim2["kernel_path"] == "dense":
+            # the fp32 kernel the split-bf16 one replaced, on the same problem in the same run (kernel_path "dense_f32")
+            s2 = HipFitSolver(dtype=dtype, device=0)
+            s2.set_problem(prob, layout="shared", kernel_path="dense_f32")
+            s2.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+            s2.set_optimizer(args.optimizer, learning_rate=1e-2)
+            s2.run(max(args.warmup, 1), record=False, tol=0.0)
+            s2.timing_enable(True)
+            s2.synchronize()
+            t2 = time.perf_counter()
+            s2.run(args.steps, record=True, tol=0.0)
+            s2.synchronize()
+            dt2 = time.perf_counter() - t2
+            tim2 = s2.timing_get()
+            k2 = tim2["total_ms"] / max(tim2["launches"], 1)
+            shared["previous_f32_kernel"] = {"kernel": "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)", "kernel_ms": k2, "steps_per_s": args.steps / dt2,
+                                             "ms_per_step": dt2 / args.steps * 1e3}
+            s2.close()
 
     # what EVERY RANK of the driver's `--gpus 8` run executes per step, without the exchange: 8 time slices x that rank's 1/8 of the
     # baselines, the slices sharing basis tiles (fused_multi_mfma_kernel).  All eight shares are built and timed here, one after the

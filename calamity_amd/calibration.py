@@ -17,6 +17,7 @@ gradient-descent fitter: ``calibrate_and_model_dpss`` (:1503-1584) -> ``calibrat
 There is no CPU fallback: without the HIP library / a GPU these functions raise.
 """
 import argparse
+import collections
 import concurrent.futures
 import copy
 import datetime
@@ -45,14 +46,21 @@ def chunk_fg_comp_dict_by_nbls(fg_model_comps_dict, use_redundancy=False, grp_si
     """
     comps = dict(fg_model_comps_dict)
     if not use_redundancy:
-        for fit_grp in list(comps.keys()):
+        # The reference pops every group it splits and appends the pieces (:73-81) -- a single baseline is "split" into itself, i.e. moved
+        # to the end.  Same order here (it fixes the layout of fg_model_comps, corr_inds and the coefficient arrays): the groups that stay
+        # whole first, then the pieces in the order of their groups; without 61 075 pops and re-inserts for HERA-350's single baselines.
+        kept, moved = {}, {}
+        for fit_grp, vectors in comps.items():
             if len(fit_grp) == 1 and len(fit_grp[0]) == 1:
-                continue  # one baseline: splitting it by redundant copy gives the same key back (61 075 of these at HERA-350)
+                moved[fit_grp] = vectors  # one baseline: its only piece is itself
+                continue
             rlens = np.asarray([len(red_grp) for red_grp in fit_grp])
             if np.allclose(rlens, np.mean(rlens)) and len(rlens) < grp_size_threshold:
-                vectors = comps.pop(fit_grp)
                 for rednum in range(int(rlens[0])):
-                    comps[tuple((red_grp[rednum],) for red_grp in fit_grp)] = vectors
+                    moved[tuple((red_grp[rednum],) for red_grp in fit_grp)] = vectors
+            else:
+                kept[fit_grp] = vectors
+        comps = {**kept, **moved}
     by_nbl, maxvecs = {}, {}
     for fit_grp, vectors in comps.items():
         nbl = sum(len(red_grp) for red_grp in fit_grp)
@@ -496,9 +504,19 @@ def yield_fg_model_array(nants, nfreqs, fg_model_comps, fg_coeffs, corr_inds, dt
 _GRAPH_SOLVERS = []  # [(key, arrays kept alive, FitProblem)]: the last few chunk sets seen, so that repeated calls reuse the uploaded basis
 
 
+def _fingerprint(a):
+    """Shape, dtype and a strided checksum (at most ~4096 samples): enough to notice a component tensor that was modified in place
+    between two calls, cheap beside the upload it guards."""
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 4096)
+    return (a.shape, a.dtype.str, float(np.sum(flat[::step], dtype=np.float64)), float(flat[-1]) if flat.size else 0.0)
+
+
 def _graph_problem(fg_comps, ant0_inds, ant1_inds, nants):
-    # (the component tensors by identity -- they are kept alive below --, the small index arrays by content)
-    key = (tuple(id(c) for c in fg_comps), tuple(np.asarray(a, dtype=np.int64).tobytes() for a in ant0_inds),
+    # (the component tensors by identity AND a content fingerprint -- they are kept alive below, but a caller may write into them --,
+    # the small index arrays by content)
+    key = (tuple((id(c), _fingerprint(c)) for c in fg_comps), tuple(np.asarray(a, dtype=np.int64).tobytes() for a in ant0_inds),
            tuple(np.asarray(a, dtype=np.int64).tobytes() for a in ant1_inds), int(nants))
     for k, _, prob in _GRAPH_SOLVERS:
         if k == key:
@@ -773,8 +791,9 @@ def calibrate_and_model_tensor(
       rms scale, weight normalisation, priors, loss history, tolerance stop and use_min snapshot, exactly as in the loop
       (``batched.SliceBatchFitter``).  ``fit_history`` and every output equal those of the sequential loop (to rounding:
       the same kernels in the same order).  ``batch_slices=False`` keeps the loop.
-    * ``devices``: GPUs to fit on (list of device indices; default: every visible device when the call is large enough
-      to pay for an exchange per step, else the device selected for the process).  The caller's process drives them all.
+    * ``devices``: GPUs to fit on: a list of device indices, or "all" for every visible GPU (a set-up that fails on "all" continues on one
+      device with a RuntimeWarning).  Default ``None``: the ONE device of the process (``gpu_index`` of the file driver, else 0) -- a run
+      spreads over several GPUs only when the caller says so.
     * ``device_split``: what several devices share out.  "slices": whole batches of slices go to different devices -- no exchange
       between them, every slice is fitted exactly as on one device (bit for bit); "groups": each device takes a share of the
       fitting groups of every slice, with one exchange of the gain gradients per step.  Default: "slices" when the call has at
@@ -846,7 +865,7 @@ def calibrate_and_model_tensor(
     if layout is not None:
         prob.__dict__["_layout"] = layout
     if devices is not None:
-        prob.__dict__["_device"] = int(list(devices)[0])  # the loop fits on one device
+        prob.__dict__["_device"] = 0 if isinstance(devices, str) else int(list(devices)[0])  # the loop fits on one device
 
     def fit_slice(polnum, pol, time_index, time, carry):
         """One (polarization, time) slice: calibration.py:1167-1330.  ``carry`` holds the parameters handed from one time
@@ -1082,17 +1101,25 @@ def _auto_batch(prob, dtype, layout=None):
     return int(max(1, min(n, _lib_max_slices())))
 
 
-def _default_devices(nsamples_per_step):
-    """Devices of a batched fit when the caller names none: every visible GPU once a train step touches enough samples to
-    pay for an exchange per step (about a microsecond of kernel time per 10^4 samples against ~50 us of all-reduce), else the
-    one device selected for the process (read_calibrate_and_model_dpss: calibration.py:1741-1753)."""
+def _default_devices(nsamples_per_step=None):
+    """Devices of a batched fit when the caller names none: the ONE device selected for the process (read_calibrate_and_model_dpss:
+    calibration.py:1741-1753; device 0 otherwise).  Several devices are an explicit request -- ``devices=[0, 1, ...]`` or
+    ``devices="all"`` -- because that path sets up an RCCL communicator between threads of this process (or none, with whole batches
+    per device) that no default should stake a caller's run on before it has been exercised on multi-GPU hardware."""
+    return [_DEVICE["index"] if _DEVICE["index"] is not None else 0]
+
+
+def _resolve_devices(devices):
+    """``devices`` keyword of the batched entry points: None (the process's device), "all" (every visible GPU) or a list of indices."""
     from . import _lib
 
-    first = _DEVICE["index"] if _DEVICE["index"] is not None else 0
-    n = _lib.device_count()
-    if n > 1 and _DEVICE["index"] is None and nsamples_per_step >= 2.0e7:
-        return list(range(n))
-    return [first]
+    if devices is None:
+        return _default_devices(), True
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError(f"devices={devices!r}: None, 'all' or a list of device indices")
+        return list(range(max(1, _lib.device_count()))), True  # ("all" is a wish, not a list: set-up failure falls back to one device, aloud)
+    return [int(d) for d in devices], False
 
 
 def _batch_fitter(prob, nt, dtype, layout, devices):
@@ -1130,9 +1157,7 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
     fit_history = {polnum: {} for polnum in range(len(pols))}
     todo = [dict(polnum=polnum, pol=pol, time_index=time_index, time=time) for polnum, pol in enumerate(pols) for time_index, time in enumerate(times)]
     finish = _output_finisher(uvdata, model, resid, gains, correct_model, correct_resid)
-    chose_devices = devices is None
-    if chose_devices:
-        devices = _default_devices(float(min(len(todo), max_batch)) * prob.nbls * prob.nfreqs)
+    devices, chose_devices = _resolve_devices(devices)
     cat = lambda parts_: parts_[0] if len(parts_) == 1 else np.concatenate(parts_)  # noqa: E731
 
     # One batch goes through three stages: prep (host: the slices' rows out of the containers), fit (device), post (host: the model
@@ -1286,30 +1311,46 @@ def _fit_slices_batched(uvdata, sky_model, gains, resid, model, prob, corr_inds,
 
         fit_threads = set()
 
-        def fit_on(batch, arrs, dev):
+        def fit_on(batch, holder, dev):
             fit_threads.add(threading.get_ident())
             try:
-                return fit(batch, arrs, on=[dev])
+                if failed.is_set():  # (another batch has failed: the call is on its way out, no more maxsteps-long fits)
+                    raise RuntimeError("an earlier batch of this call failed")
+                return fit(batch, holder.pop(), on=[dev])  # the arrays (1.1-1.3 GB per HERA-350 slice) die with this frame
+            except BaseException:
+                failed.set()
+                raise
             finally:
                 permits.release()
+
+        def post_of(batch, fitted):
+            try:
+                post(batch, fitted.result())
+            except BaseException:
+                failed.set()
+                raise
 
         pools = [concurrent.futures.ThreadPoolExecutor(1) for _ in range(D + 2)]
         prep_pool, post_pool, fit_pools = pools[0], pools[1], pools[2:]
         try:
-            ahead = [prep_pool.submit(prep_when_allowed, c) for c in batches]
-            written, nfit = [], 0
-            for f in ahead:
-                arrs = f.result()
+            # The prep futures are consumed front to back and dropped as they go: a Future keeps its result alive, and a list of
+            # all of them held every batch's arrays until the call returned (60 times x 4 polarizations: ~240 GB of host memory).
+            ahead = collections.deque(prep_pool.submit(prep_when_allowed, c) for c in batches)
+            written, nfit = collections.deque(), 0
+            while ahead:
+                arrs = ahead.popleft().result()
                 batch = arrs["batch"]
                 if not batch:
                     permits.release()
                     continue
-                fitted = fit_pools[nfit % D].submit(fit_on, batch, arrs, devices[nfit % D])
+                fitted = fit_pools[nfit % D].submit(fit_on, batch, [arrs], devices[nfit % D])
                 nfit += 1
                 del arrs
-                written.append(post_pool.submit(lambda b=batch, ff=fitted: post(b, ff.result())))
-            for f in written:
-                f.result()
+                written.append(post_pool.submit(post_of, batch, fitted))
+                while written and written[0].done():  # (a failed fit or write-back surfaces here, not after every other batch has been fitted)
+                    written.popleft().result()
+            while written:
+                written.popleft().result()
         except BaseException:
             failed.set()
             for _ in range(len(batches) + D + 2):  # (nobody stays blocked behind the throttle)

@@ -1415,6 +1415,13 @@ struct SolverT final : cal_solver {
     HIP_TRY(hipSetDevice(device));
     if (!has_problem) return fail(CAL_ERR_STATE, "get_moments before set_problem");
     HIP_TRY(hipStreamSynchronize(stream));
+    if (t && nslices > 1) {
+      // every slice counts its own updates (slices stop on their own and then freeze): ONE t only describes a solver whose slices agree
+      for (int sl = 1; sl < nslices; ++sl)
+        if (h_state[sl].t != h_state[0].t)
+          return fail(CAL_ERR_STATE, "get_moments: the %d time slices of this solver have applied different numbers of updates (slice 0: %lld, slice %d: %lld); "
+                      "one iteration count cannot resume them bit for bit", nslices, (long long)h_state[0].t, sl, (long long)h_state[sl].t);
+    }
     if (gm_r) CAL_TRY(download_rows(gm_r, gains_m.as<T>(), nants, 2, 0));
     if (gm_i) CAL_TRY(download_rows(gm_i, gains_m.as<T>(), nants, 2, 1));
     if (gv_r) CAL_TRY(download_rows(gv_r, gains_v.as<T>(), nants, 2, 0));

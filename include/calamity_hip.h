@@ -42,7 +42,7 @@ enum cal_dtype { CAL_F32 = 0, CAL_F64 = 1 };                 /* dtype kwarg, cal
 enum cal_optimizer { /* OPTIMIZERS, calibration.py:17-27: the whole table */
   CAL_OPT_ADAM = 0, CAL_OPT_ADAMAX = 1, CAL_OPT_SGD = 2, CAL_OPT_RMSPROP = 3, CAL_OPT_ADAGRAD = 4, CAL_OPT_NADAM = 5, CAL_OPT_ADADELTA = 6,
   CAL_OPT_FTRL = 7, CAL_OPT_LAMB = 8 /* tensorflow_addons.optimizers.LAMB, :26.  One trust ratio per VARIABLE (cal_problem_desc::grp_var);
-                                        its norms are those of the solver's own groups: not for a fit sharded over several ranks */
+                                        with a communicator attached the per-variable norms are summed over the ranks before the ratio */
 };
 enum cal_regularization { CAL_REG_NONE = 0, CAL_REG_SUM = 1 }; /* model_regularization, calibration.py:619-661 */
 enum cal_layout {
@@ -208,7 +208,8 @@ int cal_solver_get_params(cal_solver* s, int which, void* g_r, void* g_i, void* 
  * set_params + set_moments (after set_optimizer, whose betas the bias corrections are rebuilt from) continues bit for bit.
  * The two slots per parameter, (m, v): Adam / Nadam first and second moment; Adamax (m, u); SGD (momentum accumulator, unused);
  * RMSprop (momentum accumulator, mean square); Adagrad (unused, accumulator); Adadelta (accumulated updates, accumulated gradients);
- * Ftrl (linear, accumulator); LAMB (first, second moment). */
+ * Ftrl (linear, accumulator); LAMB (first, second moment).  Several time slices (cal_problem_desc::nslices): t is the count every
+ * slice shares; get_moments fails with CAL_ERR_STATE when the slices have applied different numbers of updates (they stop on their own). */
 int cal_solver_get_moments(cal_solver* s, void* gm_r, void* gm_i, void* gv_r, void* gv_i, void* cm_r, void* cm_i,
                            void* cv_r, void* cv_i, int64_t* t);
 int cal_solver_set_moments(cal_solver* s, const void* gm_r, const void* gm_i, const void* gv_r, const void* gv_i,

@@ -82,6 +82,34 @@ def test_dense_path_vector_counts():
     for g, n in enumerate(nvecs):
         p.grp_basis[g] = first.setdefault(n, g)
     check(p, start, dtypes=(np.float32, np.float64), layouts=("shared",), kernel_path="dense")
+    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense_f32")
+
+
+def test_split_bf16_dense_kernel_vector_counts():
+    """fp32, blocks of at most 224 vectors: the split-bf16 kernel (split_kernels.hpp: super-panels of 64 baselines, forward groups of two
+    16-vector steps, adjoint groups of two 32-vector tiles) across every group count, tail and tile parity, with panels that are
+    full, ragged and empty (a block with 70 baselines = one full panel of a super-panel and one of 6), with and without the
+    regulariser; and that the path asked for is the path that ran."""
+    from calamity_amd.solver import HipFitSolver
+
+    nvecs = [1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 48, 64, 65, 96, 100, 128, 129, 160, 161, 192, 193, 223, 224]
+    reps = [1, 3, 70, 2, 17, 1, 16, 5, 64, 65, 2, 1, 33, 4, 20, 1, 18, 2, 1, 3, 1, 2, 1]
+    allv = [n for n, r in zip(nvecs, reps) for _ in range(r)]
+    p, start = random_problem(allv, [1] * len(allv), nants=40, nfreqs=1024, seed=5)
+    first = {}
+    for g, n in enumerate(allv):
+        p.grp_basis[g] = first.setdefault(n, g)
+    s = HipFitSolver(dtype=np.float32)
+    s.set_problem(p, layout="shared", kernel_path="dense")
+    assert s.timing_get()["kernel_path"] == "dense"
+    s.close()
+    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense")
+    # a channel count that is not a multiple of the kernel's 64-channel pairs (zero-weight padding up to 128 k)
+    p, start = random_problem([5, 40, 100] * 6, [1] * 18, nants=8, nfreqs=200, seed=6)
+    first = {}
+    for g, n in enumerate([5, 40, 100] * 6):
+        p.grp_basis[g] = first.setdefault(n, g)
+    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense")
 
 
 def test_many_channels_few_groups_split_items():

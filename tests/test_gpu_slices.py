@@ -122,13 +122,14 @@ def test_slices_launch_forms(launch):
     _compare(parts, np.float32, "stream", "general", False, run_kw, 2e-3, launch=launch, learning_rate=1e-2)
 
 
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dtype,path", [(np.float32, "dense"), (np.float32, "dense_f32"), (np.float64, "dense")])
 @pytest.mark.parametrize("reg", [False, True])
-def test_slices_dense_kernels(dtype, reg):
-    """The matrix-core kernels: panels never mix slices, the two-pass regulariser uses each slice's own alpha."""
+def test_slices_dense_kernels(dtype, path, reg):
+    """The matrix-core kernels (fp32: split-bf16 and the fp32 one it replaced; fp64): panels / super-panels never mix slices, the
+    two-pass regulariser uses each slice's own alpha."""
     parts = _slices(3, nants=9, nfreqs=128)
     run_kw = dict(nsteps=40, record=True, tol=1e-30, use_min=False)
-    _compare(parts, dtype, "shared", "dense", reg, run_kw, 1e-12 if dtype == np.float64 else 2e-3, learning_rate=1e-2)
+    _compare(parts, dtype, "shared", path, reg, run_kw, 1e-12 if dtype == np.float64 else 2e-3, learning_rate=1e-2)
 
 
 def test_slices_frozen_model_and_other_optimizers():
