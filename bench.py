@@ -50,12 +50,20 @@ def parse():
     ap.add_argument("--extras", action="store_true", help="also time the tutorial-notebook and the redundant-groups configurations (they launch "
                     "the same kernels at other sizes, so a rocprofv3 --stats summary of such a run no longer averages the headline launches alone)")
     ap.add_argument("--cpu-sample-bls", type=int, default=192)
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host", "gloo"],
                     help="the exchange between the ranks: RCCL over xGMI (one rank per GPU: the measurement), or the library's exchange hook over "
-                         "gloo (ranks may then SHARE a GPU: a functional rehearsal of the N-rank path on a one-GPU box, not a measurement)")
+                         "host sockets (ranks may then SHARE a GPU: a functional rehearsal of the N-rank path on a one-GPU box, not a measurement; "
+                         "'gloo' is the old name of 'host')")
+    ap.add_argument("--split", default=None, choices=["slices", "groups"],
+                    help="time the PRODUCT's own multi-device form instead of one process per GPU: ONE process drives --gpus devices through "
+                         "calamity_amd.batched.SliceBatchFitter exactly as calibrate_and_model_dpss does (calibration._fit_slices_batched) -- "
+                         "'slices': whole time slices per device, no exchange (the default of a call with at least as many batches as devices); "
+                         "'groups': every slice's fitting groups shared over the devices, one RCCL all-reduce per step between threads of this "
+                         "process.  The job is --gpus time slices either way; --split-workers-on-one-gpu lets the workers share device 0")
+    ap.add_argument("--split-workers-on-one-gpu", action="store_true", help="(with --split) all workers on device 0: a functional rehearsal on a one-GPU box")
     ap.add_argument("--dist-rehearsal", type=int, default=0, metavar="T",
                     help="with ONE rank (plain or under torch.distributed.run --nproc-per-node 1): take the multi-rank code path anyway -- "
-                         "T batched time slices, group partition, gloo rendezvous, unique id broadcast, RCCL communicator of one rank, "
+                         "T batched time slices, group partition, socket rendezvous, unique id broadcast, RCCL communicator of one rank, "
                          "grouped all-reduce every step -- so that path is exercised on a one-GPU box")
     return ap.parse_args()
 
@@ -196,20 +204,12 @@ def cpu_baseline_strong(prob, start, dtype, optimizer, reg, same_updates=0):
                        f"{np.dtype(dtype).name}) on {cores} threads; {dt * 1e3:.0f} ms per step")
 
 
-def torch_sum_int(dist, vals):
-    import torch
-
-    t = torch.tensor(vals, dtype=torch.int64)
-    dist.all_reduce(t)
-    return [int(v) for v in t]
+def ranks_sum_int(grp, vals):
+    return [int(v) for v in grp.all_reduce(np.asarray(vals, dtype=np.int64), "sum")]
 
 
-def torch_sum_float(dist, vals):
-    import torch
-
-    t = torch.tensor(np.asarray(vals, dtype=np.float64))
-    dist.all_reduce(t)
-    return t.numpy()
+def ranks_sum_float(grp, vals):
+    return np.asarray(grp.all_reduce(np.asarray(vals, dtype=np.float64), "sum"))
 
 
 def dense_traffic(config, dtype):
@@ -306,8 +306,102 @@ def self_launch(args):
     sys.stdout.flush()
 
 
+def run_split(args):
+    """--split: the product's multi-device forms, one process, a thread per device (see parse())."""
+    import threading
+
+    from calamity_amd import _lib, synthetic
+    from calamity_amd.batched import SliceBatchFitter
+
+    if int(os.environ.get("RANK", "0")) != 0:
+        return  # (under a launcher: rank 0 drives every device; the other ranks have nothing to do)
+    _lib.load()
+    N = args.gpus
+    ndev = _lib.device_count()
+    if N > ndev and not args.split_workers_on_one_gpu:
+        raise SystemExit(f"--gpus {N} --split {args.split}: this node has {ndev} GPU(s) visible (--split-workers-on-one-gpu for a functional rehearsal)")
+    devices = [0] * N if args.split_workers_on_one_gpu else list(range(N))
+    dtype = {"f32": np.float32, "f64": np.float64, None: np.float32}[args.dtype]
+    layout = args.layout or "shared"
+    cache = {}
+    cfg_seed = list(synthetic.CONFIGS).index(args.config)
+    parts = [synthetic.make_config(args.config, seed=cfg_seed + 100 * t, data_seed=100000 * (t + 1), operator_cache=cache, max_bls=args.max_bls)
+             for t in range(N)]
+    prob = parts[0][0]
+    cat = lambda key: np.concatenate([getattr(p[0], key) for p in parts])  # noqa: E731
+    t_setup = time.perf_counter()
+    if args.split == "groups":
+        fitters = [SliceBatchFitter(prob, N, dtype=dtype, layout=layout, devices=devices, communicator_of_one=(N == 1))]
+        fitters[0].set_data(cat("data_r"), cat("data_i"), cat("wgts"))
+        fitters[0].set_params(np.concatenate([p[2]["g_r"] for p in parts]), np.concatenate([p[2]["g_i"] for p in parts]),
+                              np.concatenate([p[2]["c_r"] for p in parts]), np.concatenate([p[2]["c_i"] for p in parts]))
+    else:
+        fitters = []
+        for t, d in enumerate(devices):
+            f = SliceBatchFitter(prob, 1, dtype=dtype, layout=layout, devices=[d])
+            f.set_data(parts[t][0].data_r, parts[t][0].data_i, parts[t][0].wgts)
+            f.set_params(parts[t][2]["g_r"], parts[t][2]["g_i"], parts[t][2]["c_r"], parts[t][2]["c_i"])
+            fitters.append(f)
+    for f in fitters:
+        f.set_optimizer(args.optimizer, learning_rate=1e-2)
+    t_setup = time.perf_counter() - t_setup
+
+    def each(fn):  # every fitter on a thread of its own, as _fit_slices_batched's fit threads
+        out, errs = [None] * len(fitters), []
+
+        def work(i):
+            try:
+                out[i] = fn(fitters[i])
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(fitters))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
+
+    def sync():
+        for f in fitters:
+            for sv in f.solvers:
+                sv.synchronize()
+
+    if args.warmup > 0:
+        each(lambda f: f.run_slices(args.warmup, record=False, tol=0.0))
+    sync()
+    t0 = time.perf_counter()
+    res = each(lambda f: f.run_slices(args.steps, record=True, tol=0.0))
+    sync()
+    dt = time.perf_counter() - t0
+    losses = np.sum([np.sum([r[0] for r in rr], axis=0) for rr in res], axis=0)
+    tim = fitters[0].timing_get()
+    out = {
+        "metric": "Adam steps/sec, HERA-350 1024ch DPSS; the product's multi-device split", "value": N * args.steps / dt, "unit": "slice-steps/s",
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if dtype == np.float32 else "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {prob.nants} antennas, {prob.nbls} baselines x {prob.nfreqs} channels per time slice, {N} time slices, "
+                               f"optimizer {args.optimizer} lr 1e-2", "layout": layout, "kernel_path": tim["kernel_path"],
+                   "parallelism": (f"ONE process, a thread per device, device_split='slices': whole time slices on {N} devices, no exchange"
+                                   if args.split == "slices" else
+                                   f"ONE process, a thread per device, device_split='groups': every slice's fitting groups shared over {N} devices, "
+                                   f"one RCCL all-reduce of the gain gradients + loss scalars per step")
+                                  + (" [all workers on device 0: functional rehearsal, not a measurement]" if args.split_workers_on_one_gpu else "")},
+        "extra": {"loss_first": float(losses[0]), "loss_last": float(losses[-1]), "setup_s": t_setup,
+                  # (a collective: every worker takes part)
+                  "ranks_the_exchange_spans": fitters[0]._each(lambda r, sv: sv.comm_size())[0] if args.split == "groups" else 1},
+    }
+    print(json.dumps(out))
+    for f in fitters:
+        f.close()
+
+
 def main():
     args = parse()
+    if args.split:
+        return run_split(args)
     if args.layout is None:
         args.layout = "stream" if args.config == "hera350" else "shared"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -320,13 +414,15 @@ def main():
     from calamity_amd import _lib, synthetic
     from calamity_amd.solver import HipFitSolver, comm_unique_id
 
-    # load the HIP library (and through it /opt/rocm's HIP runtime + RCCL, the ones it was built against) BEFORE torch:
-    # torch is only used for the gloo rendezvous/barrier and bundles its own, older ROCm libraries
+    # (no PyTorch anywhere in this file: the ranks meet over calamity_amd.rendezvous -- plain sockets on MASTER_ADDR:MASTER_PORT --
+    # and the data path is RCCL inside the library)
+    if args.transport == "gloo":
+        args.transport = "host"  # (the old name of the host-side stand-in for ranks that share a GPU)
     _lib.load()
     ndev = _lib.device_count()
     if world > ndev and args.transport == "rccl":  # every rank sees this and leaves at once: none waits for a peer that cannot exist
         raise SystemExit(f"--gpus {args.gpus}: this node has {ndev} GPU(s) visible; one rank per GPU is the contract "
-                         "(--transport gloo lets ranks share a GPU for a functional rehearsal)")
+                         "(--transport host lets ranks share a GPU for a functional rehearsal)")
 
     dtype = {"f32": np.float32, "f64": np.float64, None: np.float64 if args.config == "hera37" else np.float32}[args.dtype]
     dist = None
@@ -334,11 +430,9 @@ def main():
         raise SystemExit("--dist-rehearsal is a one-rank run")
     sharded = world > 1 or args.dist_rehearsal > 0  # the multi-rank code path (also taken by the one-rank rehearsal)
     if sharded:
-        import torch.distributed as dist  # rendezvous + barrier only (gloo, CPU); the data path is RCCL inside the library
+        from calamity_amd.rendezvous import SocketGroup  # the RCCL id, a barrier, the max of the wall time: sockets, no torch
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29611")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist = SocketGroup(rank=rank, world=world)
 
     t_setup = time.perf_counter()
     ntimes = world if world > 1 else max(args.dist_rehearsal, 1)
@@ -355,22 +449,16 @@ def main():
         # (one loop state per time slice, as calibrate_and_model_tensor fits them: every slice records its own loss)
         prob, start, full_nants = build_sharded_job(args.config, rank, world, ntimes, reg=args.reg == "sum", max_bls=args.max_bls, per_slice=True)
         truth = None
-        tot = torch_sum_int(dist, [prob.nbls // ntimes, prob.ncoeffs // ntimes])
+        tot = ranks_sum_int(dist, [prob.nbls // ntimes, prob.ncoeffs // ntimes])
         full_nbls, full_ncoeffs = tot
         s = HipFitSolver(dtype=dtype, device=local_rank % ndev)
         # communicator first: set_problem then agrees the kernel path and the steps per host synchronisation over the ranks
         if args.transport == "rccl":
-            uid = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            s.comm_init(uid[0], rank, world)
+            uid = dist.broadcast(comm_unique_id() if rank == 0 else None, src=0)
+            s.comm_init(uid, rank, world)
         else:
-            import torch
-
-            def gloo_all_reduce(arr, op):
-                t = torch.from_numpy(arr)  # the library's staging buffer: reduced in place
-                dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.SUM)
-
-            s.set_exchange_hook(gloo_all_reduce, rank, world)
+            # functional stand-in (ranks that share a GPU cannot form an RCCL communicator): the library's staging buffer, reduced in place
+            s.set_exchange_hook(lambda arr, op: dist.all_reduce_inplace(arr, "min" if op == "min" else "sum"), rank, world)
         s.set_problem(prob, layout=args.layout)
         s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
         solvers.append(s)
@@ -384,7 +472,7 @@ def main():
                 nb = prob.nbls // ntimes
                 pri = np.concatenate([[float(np.sum((prob.sky_r * prob.wgts)[t * nb : (t + 1) * nb])) for t in range(ntimes)],
                                       [float(np.sum((prob.sky_i * prob.wgts)[t * nb : (t + 1) * nb])) for t in range(ntimes)]])
-                pri = torch_sum_float(dist, pri)
+                pri = ranks_sum_float(dist, pri)
                 s.set_regularization("sum", pri[:ntimes], pri[ntimes:])
             else:
                 s.set_regularization("sum", float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts)))
@@ -421,11 +509,7 @@ def main():
         run_steps(min(args.steps, 200), False)
         sync()
     if dist is not None:
-        import torch
-
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = float(dist.all_reduce([dt], "max")[0])
     tim = solvers[0].timing_get()
     for s in solvers:
         s.timing_enable(False)
@@ -628,7 +712,7 @@ def main():
                             f"model_regularization {args.reg}",
                 "layout": args.layout,
                 "transport": args.transport if sharded else None,
-                "parallelism": (f"every slice's baselines sharded over {world} ranks (one process each), one {'RCCL' if args.transport == 'rccl' else 'gloo (exchange hook)'} all-reduce of the gain gradients + loss scalars per step"
+                "parallelism": (f"every slice's baselines sharded over {world} ranks (one process each), one {'RCCL' if args.transport == 'rccl' else 'host-socket (exchange hook)'} all-reduce of the gain gradients + loss scalars per step"
                                 + (" [one-rank rehearsal of the multi-rank path]" if world == 1 else "")) if sharded else "single GPU",
             },
             "roofline": roofline,
@@ -659,7 +743,7 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
 
 
 if __name__ == "__main__":

@@ -387,7 +387,7 @@ def _wake_device(devices=None):
 
     def wake():
         try:
-            for d in devices or [_DEVICE["index"] or 0]:
+            for d in (range(_lib.device_count()) if devices == "all" else devices) or [_DEVICE["index"] or 0]:
                 _lib.device_info(int(d))
                 HipFitSolver(dtype=np.float32, device=int(d)).close()  # (a stream on the device: its queues exist afterwards)
         except Exception:  # noqa: BLE001 -- reported by the solver that needs the device
@@ -1087,10 +1087,11 @@ def _auto_batch(prob, dtype, layout=None):
     per_array = float(prob.nbls) * prob.nfreqs * np.dtype(dtype).itemsize
     host_avail = 8.0e9
     try:
-        for line in open("/proc/meminfo"):
-            if line.startswith("MemAvailable:"):
-                host_avail = float(line.split()[1]) * 1024.0
-                break
+        with open("/proc/meminfo") as meminfo:
+            for line in meminfo:
+                if line.startswith("MemAvailable:"):
+                    host_avail = float(line.split()[1]) * 1024.0
+                    break
     except OSError:
         pass
     try:

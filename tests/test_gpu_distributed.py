@@ -68,8 +68,8 @@ def test_one_rank_rehearsal_under_torchrun_matches_plain_solver(layout, reg):
     assert out["n_ranks_seen"] == 1
 
 
-def test_two_self_launched_ranks_share_the_gpu_over_gloo():
-    """`bench.py --gpus 2` WITHOUT a launcher: it starts its two ranks itself (fresh processes); with `--transport gloo` they share
+def test_two_self_launched_ranks_share_the_gpu_over_host_sockets():
+    """`bench.py --gpus 2` WITHOUT a launcher: it starts its two ranks itself (fresh processes); with `--transport host` they share
     the one GPU of this box and exchange through the library's hook, so the whole N-rank path of the bench runs here: the dealt
     partition, the per-slice priors summed over ranks, one loop state per slice, the per-step exchange, the max-over-ranks timing,
     rank 0's line -- `n_ranks_seen` counted by the exchange itself.  The job (2 time slices, each slice's baselines over 2 ranks)
@@ -78,13 +78,13 @@ def test_two_self_launched_ranks_share_the_gpu_over_gloo():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "gloo"] + common, cwd=ROOT, env=env,
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host"] + common, cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + "\n" + res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     two = json.loads(lines[0])
-    assert two["n_gpus"] == 2 and two["n_ranks_seen"] == 2 and two["config"]["transport"] == "gloo"
+    assert two["n_gpus"] == 2 and two["n_ranks_seen"] == 2 and two["config"]["transport"] == "host"
     # the same job in ONE plain solver: both ranks' shares of every slice put together (slice-major), per-slice priors summed
     import bench
     from calamity_amd.problem import FitProblem
@@ -131,3 +131,22 @@ def test_two_self_launched_ranks_share_the_gpu_over_gloo():
 
     if _lib.device_count() < 2:
         assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("split,gpus", [("slices", 2), ("groups", 2), ("groups", 1)])
+def test_bench_times_the_products_own_multi_device_split(split, gpus):
+    """`bench.py --gpus N --split slices|groups`: ONE process drives N workers through batched.SliceBatchFitter as
+    calibration._fit_slices_batched does -- whole slices per device without an exchange, or every slice's groups shared with one
+    all-reduce per step.  On this one-GPU box the workers share device 0 (host exchange between them); N = 1 with 'groups' joins a
+    one-rank RCCL communicator from the worker thread.  The line names the split it timed; the steps optimise."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--split", split, "--max-bls", str(MAX_BLS), "--steps", "6", "--warmup", "2",
+           "--layout", "shared"] + (["--split-workers-on-one-gpu"] if gpus > 1 else [])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + "\n" + res.stderr[-4000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == gpus and line["unit"] == "slice-steps/s" and f"device_split='{split}'" in line["config"]["parallelism"]
+    assert line["extra"]["loss_last"] < line["extra"]["loss_first"]
+    assert line["extra"]["ranks_the_exchange_spans"] == (gpus if split == "groups" else 1)

@@ -244,3 +244,29 @@ def test_batches_on_different_devices_equal_one_device_bit_for_bit():
     _equal_outputs(one, auto, 5, 0.0, skipped=(3,))
     with pytest.raises(ValueError):
         calibration.calibrate_and_model_dpss(devices=[0, 0], device_split="times", **kw)
+
+
+def test_devices_default_is_one_device_and_all_falls_back_aloud(monkeypatch):
+    """devices=None fits on the process's ONE device however many GPUs are visible (several devices are an explicit request: a
+    default must not stake a run on a communicator set-up it was never asked for); devices="all" on a node where the set-up of
+    the visible devices fails together -- here a second device the library cannot open -- continues on one device with a
+    RuntimeWarning and returns what the one-device call returns, bit for bit."""
+    import warnings
+
+    from calamity_amd import _lib
+
+    uvd, sky = _five_times(ntimes=3, skip=None)
+    kw = dict(min_dly=2.0 / 0.3, offset=2.0 / 0.3, uvdata=uvd, gains=None, sky_model=None, maxsteps=60, tol=1e-30, optimizer="Adam",
+              learning_rate=1e-2, dtype=np.float64, model_regularization="sum")
+    one = calibration.calibrate_and_model_dpss(devices=[0], **kw)
+    monkeypatch.setattr(_lib, "device_count", lambda: 2)  # "two GPUs visible"
+    assert calibration._resolve_devices(None) == ([0], True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # the default path must not even try the second device
+        default = calibration.calibrate_and_model_dpss(**kw)
+    _equal_outputs(one, default, 3, 0.0)
+    with pytest.warns(RuntimeWarning, match="could not be set up on devices"):
+        fallback = calibration.calibrate_and_model_dpss(devices="all", device_split="groups", **kw)
+    _equal_outputs(one, fallback, 3, 0.0)
+    with pytest.raises(Exception):  # an explicit list fails as it stands
+        calibration.calibrate_and_model_dpss(devices=[0, 1], device_split="groups", **kw)

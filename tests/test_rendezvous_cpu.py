@@ -1,0 +1,55 @@
+"""calamity_amd.rendezvous: the socket group that replaces torch.distributed in bench.py's multi-rank path (the RCCL id hand-off, the
+barrier, small host reductions, the in-place all-reduce behind the exchange hook) -- three processes on 127.0.0.1."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+RANK = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from calamity_amd.rendezvous import SocketGroup
+r, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+g = SocketGroup(rank=r, world=world, addr="127.0.0.1", port=port)
+uid = g.broadcast(bytes(range(128)) if r == 0 else None, src=0)
+assert uid == bytes(range(128))
+g.barrier()
+assert [int(v) for v in g.all_reduce(np.asarray([r, 2 * r + 1], dtype=np.int64), "sum")] == [world * (world - 1) // 2, world * world]
+assert float(g.all_reduce([1.5 + r], "max")[0]) == 0.5 + world and float(g.all_reduce([1.5 + r], "min")[0]) == 1.5
+a = np.arange(5000, dtype=np.float32) * (r + 1)
+g.all_reduce_inplace(a, "sum")
+assert np.array_equal(a, np.arange(5000, dtype=np.float32) * (world * (world + 1) // 2))
+g.barrier()
+g.close()
+print("ok", r)
+"""
+
+
+def test_three_ranks_meet_over_sockets(tmp_path):
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "rank.py"
+    script.write_text(RANK.format(root=ROOT))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ok {r}" in out, err[-2000:]
+
+
+def test_a_group_of_one_needs_no_socket():
+    sys.path.insert(0, ROOT)
+    import numpy as np
+
+    from calamity_amd.rendezvous import SocketGroup
+
+    g = SocketGroup(rank=0, world=1)
+    g.barrier()
+    assert g.broadcast(b"x") == b"x" and float(g.all_reduce([2.0], "max")[0]) == 2.0
+    a = np.ones(4)
+    g.all_reduce_inplace(a)
+    assert np.array_equal(a, np.ones(4))
