@@ -5,9 +5,11 @@ the reference lives in the un-vendored third-party ``hera_filters.dspec.dpss_ope
 unpinned in setup.py:59-66); ``dpss_operator`` below restates its published algorithm with
 ``scipy.signal.windows.dpss``.  Mode-count parity with hera_filters is unpinned.
 """
+import collections
 import concurrent.futures
 import datetime
 import os
+import threading
 
 import numpy as np
 from scipy.signal import windows
@@ -161,18 +163,45 @@ def yield_dpss_model_comps_bl_grp(
     return _dpss_block(dly_ns(length, horizon=horizon, min_dly=min_dly, offset=offset), freqs, eigenval_cutoff, operator_cache)
 
 
+# DPSS blocks outlive the call that built them: a block is a function of (channel count, first / last frequency, delay half width,
+# eigenvalue cut) alone, and a pipeline calls calibrate_and_model_dpss once per file on the same array and band -- 0.5 s of
+# eigen-decompositions per HERA-350 call that only the first call needs.  Bounded (least recently used first out); the arrays are
+# read-only so that no caller can change what the next call gets.
+_BLOCKS = collections.OrderedDict()
+_BLOCKS_LOCK = threading.Lock()
+_BLOCKS_MAX_BYTES = 2 << 30
+
+
+def clear_dpss_block_cache():
+    with _BLOCKS_LOCK:
+        _BLOCKS.clear()
+
+
 def _dpss_block(delay_ns, freqs, eigenval_cutoff, operator_cache=None):
-    """The real DPSS block of one delay half width (ns), cached by delay: modeling.py:291-301."""
+    """The real DPSS block of one delay half width (ns), cached by delay: modeling.py:291-301 -- within the call through
+    ``operator_cache`` (baselines of one delay share ONE ndarray), across calls through the module's bounded cache."""
     if operator_cache is None:
         operator_cache = {}
     dly = delay_ns / 1e9
     key = ("bl_grp", dly, len(freqs), float(freqs[0]), float(freqs[-1]), eigenval_cutoff)
     if key not in operator_cache:
-        operator_cache[key] = np.ascontiguousarray(
-            dpss_operator(
-                freqs, filter_centers=[0.0], filter_half_widths=[dly], eigenval_cutoff=[eigenval_cutoff], cache=operator_cache
-            )[0].real
-        )
+        with _BLOCKS_LOCK:
+            blk = _BLOCKS.get(key)
+            if blk is not None:
+                _BLOCKS.move_to_end(key)
+        if blk is None:
+            blk = np.ascontiguousarray(
+                dpss_operator(
+                    freqs, filter_centers=[0.0], filter_half_widths=[dly], eigenval_cutoff=[eigenval_cutoff], cache=operator_cache
+                )[0].real
+            )
+            blk.setflags(write=False)
+            with _BLOCKS_LOCK:
+                _BLOCKS[key] = blk
+                total = sum(b.nbytes for b in _BLOCKS.values())
+                while total > _BLOCKS_MAX_BYTES and len(_BLOCKS) > 1:
+                    total -= _BLOCKS.popitem(last=False)[1].nbytes
+        operator_cache[key] = blk
     return operator_cache[key]
 
 

@@ -79,3 +79,22 @@ def test_dpss_operator_term_count_equals_the_dense_kernel_rule(chunk):
         want = int(np.max(np.where(eig >= ec)))
         assert nterms[0] == want, (cfg, dly, nterms[0], want)
         assert amat.shape == (nf, want) and np.allclose(amat.real.T @ amat.real, np.eye(want), atol=1e-9)
+
+
+def test_dpss_blocks_are_kept_across_calls():
+    """A block is a function of (channel count, band edges, delay half width, eigenvalue cut): a second call with a fresh
+    ``operator_cache`` gets the SAME read-only array without an eigen-decomposition (calibrate_and_model_dpss once per file of a
+    night: 0.5 s of set-up per HERA-350 call that only the first one pays); another band or cut builds its own."""
+    from calamity_amd import modeling
+
+    modeling.clear_dpss_block_cache()
+    f = 100e6 + np.arange(256) * 100e6 / 256
+    a = modeling.yield_dpss_model_comps_bl_grp(50.0, f, operator_cache={})
+    b = modeling.yield_dpss_model_comps_bl_grp(50.0, f, operator_cache={})
+    assert a is b and not a.flags.writeable
+    c = modeling.yield_dpss_model_comps_bl_grp(50.0, f, operator_cache={}, eigenval_cutoff=1e-6)
+    d = modeling.yield_dpss_model_comps_bl_grp(50.0, f + 1e6, operator_cache={})
+    assert c is not a and d is not a and c.shape[1] <= a.shape[1]
+    modeling.clear_dpss_block_cache()
+    e = modeling.yield_dpss_model_comps_bl_grp(50.0, f, operator_cache={})
+    assert e is not a and np.array_equal(e, a)

@@ -44,7 +44,7 @@ def check(p, start, dtypes=(np.float64, np.float32), layouts=("stream", "shared"
         c.set_regularization("sum" if reg else None, pr, pi)
         ref = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
         for dtype in dtypes:
-            tol_l, tol_g = (1e-10, 1e-10) if dtype == np.float64 else (2e-5, 2e-4)
+            tol_l, tol_g = (1e-10, 1e-10) if dtype == np.float64 else (1e-5, 1e-4)
             for layout in layouts:
                 s = HipFitSolver(dtype=dtype)
                 s.set_problem(p, layout=layout, kernel_path=kernel_path)
