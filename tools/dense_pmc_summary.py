@@ -44,7 +44,10 @@ def main():
         e = dict(st)
         if sq:
             # 512-flop units: a v_mfma_f32_32x32x2_f32 is 4096 flops (64 pipe cycles), a v_mfma_f64_16x16x4_f64 2048 (64 cycles)
-            n_mfma = sq["SQ_INSTS_VALU_MFMA_MOPS_F32"] / 8.0 if "SQ_INSTS_VALU_MFMA_MOPS_F32" in sq else sq["SQ_INSTS_VALU_MFMA_MOPS_F64"] / 4.0
+            if sq.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) > 0:  # the split-bf16 kernel: a v_mfma_f32_32x32x16_bf16 is 32768 flops = 64 units (32 pipe cycles)
+                n_mfma = sq["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / 64.0
+            else:
+                n_mfma = sq["SQ_INSTS_VALU_MFMA_MOPS_F32"] / 8.0 if sq.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) > 0 else sq["SQ_INSTS_VALU_MFMA_MOPS_F64"] / 4.0
             e.update(mfma_instructions=n_mfma, mfma_busy_cycles=sq["SQ_VALU_MFMA_BUSY_CYCLES"],
                      mfma_busy_cycles_per_instruction=sq["SQ_VALU_MFMA_BUSY_CYCLES"] / max(n_mfma, 1),
                      wave_wait_share=sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], wave_issue_stall_share=sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],

@@ -6,7 +6,7 @@
 set -e
 tag=${1:-dense}
 dt=${2:-f32}
-mops=SQ_INSTS_VALU_MFMA_MOPS_F32
+mops="SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16"   # (the fp32 path issues bf16 MFMAs since round 5: split_kernels.hpp)
 if [ "$dt" = f64 ]; then mops=SQ_INSTS_VALU_MFMA_MOPS_F64; fi
 cd "${GRAFT_REPO_ROOT:?}"
 export TMPDIR=/tmp
@@ -15,7 +15,7 @@ mkdir -p $out
 cmd="python3 bench.py --layout shared --dtype $dt --steps 4 --warmup 1 --no-cpu-baseline --no-shared"
 rocprofv3 --kernel-trace --stats -d $out/trace -o dense --output-format csv -- python3 bench.py --layout shared --dtype $dt --steps 20 --warmup 3 --no-cpu-baseline --no-shared > $out/trace_stdout.log 2>&1
 echo "trace done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES $mops SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $out/pmc -o sq --output-format csv -- $cmd > $out/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES $mops SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $out/pmc -o sq --output-format csv -- $cmd > $out/pmc_sq.log 2>&1
 echo "sq done"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $out/pmc -o tcc --output-format csv -- $cmd > $out/pmc_tcc.log 2>&1
 echo "tcc done"
