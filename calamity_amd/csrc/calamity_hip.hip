@@ -214,7 +214,7 @@ struct SolverT final : cal_solver {
   DevBuf gcp0, gcp1, gc0, gc1;                 // coefficient-gradient partials and (multi-item groups) their sums
   DevBuf part, state, losses, scratch, model_buf;
   DevBuf members, heads;                       // baselines that share tiles (bl_alias): member lists of the head items, head item indices
-  int nheads = 0;                              // heads[0 .. nheads_mfma): fused_multi_mfma_kernel (float32, at most kMmMaxVec vectors); the rest: fused_multi_kernel
+  int nheads = 0;                              // heads[0 .. nheads_mfma): fused_multi_mfma_kernel (at most kMmMaxVec vectors); the rest: fused_multi_kernel
   int nheads_mfma = 0;
   int mm_grid = 0;                             // workgroups of the matrix-core multi-slice launch: its head list is dealt over the 8 XCDs (-1: empty slot)
   size_t lds_multi_bytes = 0, lds_multi_mfma_bytes = 0;
@@ -940,10 +940,16 @@ struct SolverT final : cal_solver {
     std::vector<std::vector<int>> alias_sets(nbls);
     for (int b = 0; b < nbls; ++b)
       if (in_alias_set[b]) alias_sets[alias_root[b] >= 0 ? alias_root[b] : b].push_back(b);
+    // members per head item: the matrix-core kernel takes 8 in both precisions (16 MFMA columns), fused_multi_kernel
+    // MultiCfg<T>::nb_max (its gradient accumulators live in registers: 4 in fp64)
+    auto mfma_shape = [&](const Item& q) { return q.nvec <= kMmMaxVec && (1 << q.fb_log2) >= kMmStrip && fpad % 128 == 0; };
+    std::vector<int> set_cap(nbls, MultiCfg<T>::nb_max);
+    for (int q = 0; q < nitems; ++q)
+      if (!h_item_multi[q] && mfma_shape(h_items[q])) set_cap[h_items[q].bl0] = kMmMembers;
     std::vector<char> bl_covered(nbls, 0);
     for (int r = 0; r < nbls; ++r)
-      for (size_t i = 0; i < alias_sets[r].size(); i += MultiCfg<T>::nb_max) {
-        const size_t n = std::min<size_t>(MultiCfg<T>::nb_max, alias_sets[r].size() - i);
+      for (size_t i = 0; i < alias_sets[r].size(); i += set_cap[r]) {
+        const size_t n = std::min<size_t>(set_cap[r], alias_sets[r].size() - i);
         if (n >= 2)
           for (size_t k = 0; k < n; ++k) bl_covered[alias_sets[r][i + k]] = 1;
       }
@@ -1012,8 +1018,8 @@ struct SolverT final : cal_solver {
       const std::vector<std::vector<int>>& sets = alias_sets;
       std::vector<Member> h_members;
       std::vector<int> h_heads;
-      constexpr int NBM = MultiCfg<T>::nb_max;
       for (int r = 0; r < nbls; ++r) {
+        const int NBM = set_cap[r];
         for (size_t i = 0; i < sets[r].size(); i += NBM) {
           const int n = (int)std::min<size_t>(NBM, sets[r].size() - i);
           if (n < 2) continue;  // a lone baseline runs as an ordinary item
@@ -1036,11 +1042,9 @@ struct SolverT final : cal_solver {
           }
         }
       }
-      // the matrix-core form first (float32, blocks of at most kMmMaxVec vectors), each list heaviest first
+      // the matrix-core form first (blocks of at most kMmMaxVec vectors), each list heaviest first
       // (rows padded to a multiple of 128 channels -- any band of more than 64: its waves take an even number of 16-channel strips each)
-      auto on_mfma = [&](int head) {
-        return std::is_same<T, float>::value && sorted[head].nvec <= kMmMaxVec && (1 << sorted[head].fb_log2) >= kMmStrip && fpad % 128 == 0;
-      };
+      auto on_mfma = [&](int head) { return mfma_shape(sorted[head]); };
       std::stable_sort(h_heads.begin(), h_heads.end(), [&](int a, int b) {
         const bool ma = on_mfma(a), mb = on_mfma(b);
         if (ma != mb) return ma;
@@ -1049,7 +1053,7 @@ struct SolverT final : cal_solver {
       for (int head : h_heads) {
         if (on_mfma(head)) {
           ++nheads_mfma;
-          lds_multi_mfma_bytes = std::max(lds_multi_mfma_bytes, multi_mfma_lds_bytes(sorted[head].nvec));
+          lds_multi_mfma_bytes = std::max(lds_multi_mfma_bytes, multi_mfma_lds_bytes<T>(sorted[head].nvec));
         } else {
           lds_multi_bytes = std::max(lds_multi_bytes, multi_lds_for(1 << sorted[head].fb_log2));
         }
@@ -1104,10 +1108,10 @@ struct SolverT final : cal_solver {
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_LOSS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
         }
         if (nheads_mfma > 0) {
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_GRAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_LOSS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_GRAD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<MODE_LOSS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_GRAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_LOSS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_GRAD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_LOSS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
         }
       }
     }
@@ -1532,11 +1536,9 @@ struct SolverT final : cal_solver {
       // baselines that share tiles (skipped by the launch above): one workgroup per set.  With the regulariser these kernels take
       // the two-pass form (loss pass: S; gradient pass: alpha of each member's slice from the state) -- enqueue_pass orders the passes
       if (nheads > 0) {
-        if constexpr (std::is_same<T, float>::value) {
-          if (nheads_mfma > 0) {
-            if (with_reg) hipLaunchKernelGGL((fused_multi_mfma_kernel<MODE, true>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
-            else hipLaunchKernelGGL((fused_multi_mfma_kernel<MODE, false>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
-          }
+        if (nheads_mfma > 0) {
+          if (with_reg) hipLaunchKernelGGL((fused_multi_mfma_kernel<T, MODE, true>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
+          else hipLaunchKernelGGL((fused_multi_mfma_kernel<T, MODE, false>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
         }
         if (nheads > nheads_mfma) {
           FusedArgs<T> b = a;

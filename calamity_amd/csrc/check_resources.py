@@ -5,8 +5,8 @@ The dense kernels consume their LDS-DMA operand ring behind COUNTED `s_waitcnt v
 a wave is in that count, and register spills are vector-memory operations (scratch).  A spilling build would therefore not
 just be slower, it would read ring slots before they have landed.  So: no scratch, no spills, in any kernel whose name
 contains `fused_dense`; and two waves per SIMD where the kernels are written for two.
-`fused_multi_mfma_kernel` sits at 245 of the 256 registers two waves per SIMD leave it: no scratch and no spilled VGPRs there
-either (a few SGPR spills into lanes of a VGPR are tolerated: they sit outside its job loop)."""
+`fused_multi_mfma_kernel<float>` sits at 245 of the 256 registers two waves per SIMD leave it (the double instance has a
+CU to itself): no scratch and no spilled VGPRs there either (a few SGPR spills into lanes of a VGPR are tolerated: they sit outside its job loop)."""
 import re
 import sys
 
@@ -20,7 +20,7 @@ for line in sys.stdin:
     if cur is not None and "fused_multi_mfma" in cur:
         m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|VGPRs Spill|Occupancy \[waves/SIMD\]): (\d+)", line)
         if m and m.group(1).startswith("Occupancy"):
-            if int(m.group(2)) < 2:
+            if int(m.group(2)) < 2 and "IdLi" not in cur and "<double" not in cur:  # (the fp64 instance runs one workgroup per CU by design)
                 bad.append(f"{cur}: occupancy {m.group(2)} waves/SIMD (< 2)")
         elif m and int(m.group(2)) != 0:
             bad.append(f"{cur}: {m.group(1)} = {m.group(2)}")

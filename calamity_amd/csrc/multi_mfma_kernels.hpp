@@ -1,8 +1,10 @@
-// multi_mfma_kernels.hpp -- time slices of one solver that share basis tiles (cal_problem_desc::bl_alias), float32, on the
-// matrix cores: the 8 member baselines of a head item are 16 right-hand sides (re | im) of ONE tile, which makes the skinny
+// multi_mfma_kernels.hpp -- time slices of one solver that share basis tiles (cal_problem_desc::bl_alias) on the matrix
+// cores: the 8 member baselines of a head item are 16 right-hand sides (re | im) of ONE tile, which makes the skinny
 // complex GEMV of /root/reference/calamity/calibration.py:1587-1590 a real (if narrow) dense contraction --
-// v_mfma_f32_16x16x4_f32 with 16 columns -- while the tile still streams from HBM exactly once per pass (fused_multi_kernel of
-// fit_kernels.hpp does the same job in the vector ALU and is bound by its lane reductions; it keeps fp64 and the wide blocks).
+// v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 with 16 columns -- while the tile still streams from HBM exactly once per
+// pass (fused_multi_kernel of fit_kernels.hpp does the same job in the vector ALU and is bound by its lane reductions; it keeps
+// the wide blocks).  The text below describes float32; what double precision (--precision 64, calibration.py:1857) changes is
+// listed at MmT<double>.
 //
 // One 4-wave workgroup per head item.  Wave w owns the 16-channel strips j = w, w + 4, ... of the item's channels and runs, per
 // strip ("job"), with no data exchanged between waves (one barrier per job only keeps them on neighbouring strips):
@@ -35,6 +37,8 @@ namespace calk {
 
 typedef float mm_f32x4 __attribute__((ext_vector_type(4)));
 typedef float mm_f32x2 __attribute__((ext_vector_type(2)));
+typedef double mm_f64x4 __attribute__((ext_vector_type(4)));
+typedef double mm_f64x2 __attribute__((ext_vector_type(2)));
 
 #ifndef CAL_MM_NT
 #define CAL_MM_NT 0  // cache policy of the tile loads (2 = non-temporal: measured 20 % slower -- the two halves of a 128-byte line are read by neighbouring waves, and the second one should still find it in L2)
@@ -42,27 +46,67 @@ typedef float mm_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kMmStrip = 16;               // channels of a wave's job
 constexpr int kMmMaxVec = 224;             // widest block this kernel takes (wider ones: fused_multi_kernel)
 constexpr int kMmTiles = kMmMaxVec / 16;   // gradient tiles of 16 vectors = classes of the item body
-constexpr int kMmGvPitch = 20;             // words per column of the per-wave gbar_v buffer (16 channels + 4: 16-byte aligned, rows on distinct bank groups)
+constexpr int kMmMembers = 8;              // members of a head item: 16 MFMA columns (both precisions; fused_multi_kernel: MultiCfg<T>::nb_max)
 constexpr int kMmTilePadElems = 2048;      // zeroed elements the tile buffers carry behind their last tile (the read-on of the last k-steps: < 16 rows of 128 channels)
+constexpr int kMmHeader = 256 + 768 + 128; // members, loss partials, alphas
 
-inline size_t multi_mfma_lds_bytes(int nvec_max) {
+// What the precision decides.
+//   float:  v_mfma_f32_16x16x4_f32 (32 cycles); register r of the accumulator of lane (j, q) is row 4 q + r; two workgroups per CU
+//           (247 registers); a lane holds the real OR the imaginary parts of four members and trades two with the lane 32 on.
+//   double: v_mfma_f64_16x16x4_f64 (64 cycles); register r is row q + 4 r -- so lane (ch, q) of F's accumulator holds columns
+//           q, q + 4, q + 8, q + 12 = (re, re, im, im) of members q and q + 4: E needs no lane exchange at all; tile loads are
+//           8 bytes per lane (a k-step = four 128-byte row pieces), which doubles the bytes a wave keeps in flight at the same
+//           number of loads; twice the registers per value: ONE workgroup per CU (512 registers, up to 150 KB of LDS).
+//           LDS strip rows are 128 bytes: a row's 16-byte chunks are XOR-swizzled with (row >> 1) & 7, which makes the B phase's
+//           ds_read_b128 (16 lanes on 16 rows per pass) hit 16 distinct bank groups.
+template <typename T> struct MmT;
+template <> struct MmT<float> {
+  typedef mm_f32x4 v4;
+  typedef mm_f32x2 v2;
+  static constexpr int kGvPitch = 20;  // words per column of the per-wave gbar_v buffer (16 channels + 4: 16-byte aligned, rows on distinct bank groups)
+  static constexpr int kWgPerCu = 2;
+  static __device__ __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t rs, unsigned lo, unsigned so) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lo, so, CAL_MM_NT));
+  }
+  static __device__ __forceinline__ constexpr int row_of(int q, int r) { return 4 * q + r; }  // row of accumulator register r of a lane in quarter q
+};
+template <> struct MmT<double> {
+  typedef mm_f64x4 v4;
+  typedef mm_f64x2 v2;
+  static constexpr int kGvPitch = 18;  // doubles per column: 144 bytes, 16 columns on 16 distinct bank groups
+  static constexpr int kWgPerCu = 1;
+  static __device__ __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t rs, unsigned lo, unsigned so) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lo, so, CAL_MM_NT));
+  }
+  static __device__ __forceinline__ constexpr int row_of(int q, int r) { return q + 4 * r; }
+};
+
+template <typename T> inline size_t multi_mfma_lds_bytes(int nvec_max) {
   const size_t nt = (nvec_max + 15) / 16;
-  return 256 + 768 + 64 + nt * 4 * 64 * 4 + 4 * nt * 16 * 16 * 4 + 4 * 16 * kMmGvPitch * 4;  // members, loss partials, coefficient operand, four strips, four gbar_v buffers
+  return kMmHeader + (nt * 4 * 64 + 4 * nt * 16 * 16 + 4 * 16 * MmT<T>::kGvPitch) * sizeof(T);  // coefficient operand, four strips, four gbar_v buffers
 }
 
 // REG: the "sum" regulariser (calibration.py:1623-1656) in two passes, like the dense kernels: the loss pass also sums S = sum w m of
 // every member; once the slices' alpha = 2 (S - P) are known (alpha_kernel) the gradient pass applies e = -2 w r + alpha w with the
 // alpha of each member's own slice -- no second adjoint set, the tiles stream once per pass for all members.  The gradient pass
 // then leaves the loss partials of the loss pass in place.
-template <int MODE, int NT, int DEPTH, bool REG>
-__device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const Item& it, int item_idx, unsigned char* smem) {
+template <typename T, int MODE, int NT, int DEPTH, bool REG>
+__device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Item& it, int item_idx, unsigned char* smem) {
+  using X = MmT<T>;
+  typedef typename X::v4 v4;
+  typedef typename X::v2 v2;
+  constexpr bool F64 = sizeof(T) == 8;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int kGvPitch = X::kGvPitch;
   constexpr bool GRAD = MODE == MODE_GRAD;
   constexpr int NS = 4 * NT;   // forward k-steps (four vectors each), run as two interleaved accumulator chains
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15;   // index inside a row of 16 lanes: the CHANNEL of the strip (tile operand, accumulator, E), the MFMA column (coefficient operand, B)
-  const int kq = lane >> 4;    // the k of a step this lane feeds; the quad of columns 4 kq .. 4 kq + 3 it holds in the accumulator
+  const int kq = lane >> 4;    // the k of a step this lane feeds; the quarter of the accumulator's rows it holds (MmT::row_of)
   const int nvec = it.nvec;
   const int NB = it.role_n >> 2;
   const int fb_log2 = it.fb_log2;
@@ -70,65 +114,89 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
 
   Member* s_mem = reinterpret_cast<Member*>(smem);
   double* s_red = reinterpret_cast<double*>(smem + 256);  // [loss, S_r, S_i][4 waves][8 members]
-  float* s_al = reinterpret_cast<float*>(smem + 1024);               // REG, gradient pass: [8 members](alpha_r, alpha_i) of the member's slice
-  float* s_c = reinterpret_cast<float*>(smem + 1088);                 // [NS steps][64 lanes]: C[4 s + (lane >> 4)][lane & 15]
-  float* s_strips = s_c + NS * 64;                                   // [4 waves][16 NT rows][16 channels], swizzled
-  float* s_strip = s_strips + wave * NT * 256;
-  float* s_gv = s_strips + 4 * NT * 256 + wave * (16 * kMmGvPitch);   // [16 columns][16 channels] gbar_v of the current job, pitch 20 words
+  T* s_al = reinterpret_cast<T*>(smem + 1024);                        // REG, gradient pass: [8 members](alpha_r, alpha_i) of the member's slice
+  T* s_c = reinterpret_cast<T*>(smem + kMmHeader);                    // [NS steps][64 lanes]: C[4 s + (lane >> 4)][lane & 15]
+  T* s_strips = s_c + NS * 64;                                        // [4 waves][16 NT rows][16 channels], swizzled
+  T* s_strip = s_strips + wave * NT * 256;
+  T* s_gv = s_strips + 4 * NT * 256 + wave * (16 * kGvPitch);          // [16 columns][16 channels] gbar_v of the current job
 
   if (tid < NB * (int)(sizeof(Member) / 4)) reinterpret_cast<int*>(s_mem)[tid] = reinterpret_cast<const int*>(A.members + it.member0)[tid];
   __syncthreads();
   if (REG && GRAD && tid < 8) {
     const DevState* sst = A.state + (tid < NB ? s_mem[tid].slice : 0);
-    s_al[2 * tid] = tid < NB ? (float)sst->alpha_r : 0.f;
-    s_al[2 * tid + 1] = tid < NB ? (float)sst->alpha_i : 0.f;
+    s_al[2 * tid] = tid < NB ? (T)sst->alpha_r : (T)0;
+    s_al[2 * tid + 1] = tid < NB ? (T)sst->alpha_i : (T)0;
   }
   for (int n = tid; n < NS * 64; n += kThreads) {
-    const int k = n >> 4, j = n & 15, m = j & 7;
-    float v = 0.f;
+    const int k = n >> 4, j = n & 15, m = j & 7;  // column j: member j & 7, real part for j < 8
+    T v = 0;
     if (k < nvec && m < NB) v = (j < 8 ? A.c_r : A.c_i)[s_mem[m].coff + k];
     s_c[n] = v;
   }
-  // E works in the accumulator layout of F (see there): lane (ch = lane & 15, q = lane >> 4) holds, for ONE channel of the strip,
-  // the four columns 4 q .. 4 q + 3 = the real parts (q < 2) or imaginary parts (q >= 2) of members 4 (q & 1) .. + 3.  The partner
-  // 32 lanes on holds the other part of the same four members; of those four the lower lane evaluates the first two, the upper
-  // lane the last two.  Sample rows and antenna pairs of this lane's two members as 32-bit element offsets (+ its channel):
+  // E works in the accumulator layout of F (see there).  float: lane (ch = lane & 15, q = lane >> 4) holds, for ONE channel of the
+  // strip, the four columns 4 q .. 4 q + 3 = the real parts (q < 2) or imaginary parts (q >= 2) of members 4 (q & 1) .. + 3.  The
+  // partner 32 lanes on holds the other part of the same four members; of those four the lower lane evaluates the first two, the
+  // upper lane the last two.  double: the lane holds both parts of members q and q + 4 and evaluates those.
+  // Sample rows and antenna pairs of this lane's two members as 32-bit element offsets (+ its channel):
   const int half = kq >> 1;
-  const int m_a = 4 * (kq & 1) + 2 * half;  // and m_a + 1
+  const int m_first = F64 ? kq : 4 * (kq & 1) + 2 * half;  // member of i = 0
+  constexpr int m_step = F64 ? 4 : 1;                      // ... and i = 1 is m_first + m_step
   unsigned so[2], g0o[2], g1o[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const bool active = m_a + i < NB;
-    const unsigned row = active ? (unsigned)s_mem[m_a + i].bl : (unsigned)A.nbls;  // the spare all-zero row
+    const int m = m_first + i * m_step;
+    const bool active = m < NB;
+    const unsigned row = active ? (unsigned)s_mem[m].bl : (unsigned)A.nbls;  // the spare all-zero row
     so[i] = row * (unsigned)A.fpad + (unsigned)col;
-    g0o[i] = (active ? (unsigned)s_mem[m_a + i].ant0 : 0u) * (unsigned)A.fpad + (unsigned)col;
-    g1o[i] = (active ? (unsigned)s_mem[m_a + i].ant1 : 0u) * (unsigned)A.fpad + (unsigned)col;
+    g0o[i] = (active ? (unsigned)s_mem[m].ant0 : 0u) * (unsigned)A.fpad + (unsigned)col;
+    g1o[i] = (active ? (unsigned)s_mem[m].ant1 : 0u) * (unsigned)A.fpad + (unsigned)col;
   }
   __syncthreads();
 
-  const float* s_cl = s_c + lane;
+  const T* s_cl = s_c + lane;
   constexpr bool CREG = NT <= 7;  // the coefficient operand of all k-steps in registers
-  float creg[CREG ? NS : 1];
+  T creg[CREG ? NS : 1];
   if (CREG) {
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) creg[s2] = s_cl[s2 * 64];
   }
-  // LDS strip: word address of (row, ch) = row * 16 + (((ch >> 2) ^ (2 * ((row >> 3) & 1))) << 2) + (ch & 3)
-  float* s_w0 = s_strip + kq * 16 + col;                                     // store of step s with (s & 2) == 0: row 4 s + kq, channel col
-  float* s_w1 = s_strip + kq * 16 + ((((col >> 2) ^ 2) << 2) | (col & 3));   // ... with (s & 2) != 0 (rows 8..15 of a 16-row group)
-  const mm_f32x4* s_rd = reinterpret_cast<const mm_f32x4*>(s_strip + col * 16 + ((kq ^ (2 * (col >> 3))) << 2));  // + t * 256 words: row 16 t + col, channels 4 kq ..
+  // LDS strip, element address of (row, ch):
+  //   float:  row * 16 + (((ch >> 2) ^ (2 * ((row >> 3) & 1))) << 2) + (ch & 3)
+  //   double: row * 16 + (((ch >> 1) ^ ((row >> 1) & 7)) << 1) + (ch & 1)
+  // store of step s: row 4 s + kq, channel col.  float: two lane pointers, by (s & 2) (rows 8..15 of a 16-row group);
+  // double: (row >> 1) & 7 = ((2 s) & 7) | (kq >> 1): four lane pointers, by s & 3.
+  T* s_w[4];
+  if (F64) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s_w[v] = s_strip + kq * 16 + ((((col >> 1) ^ (kq >> 1) ^ (2 * v)) << 1) | (col & 1));
+  } else {
+    s_w[0] = s_w[1] = s_strip + kq * 16 + col;
+    s_w[2] = s_w[3] = s_strip + kq * 16 + ((((col >> 2) ^ 2) << 2) | (col & 3));
+  }
+  // B reads row 16 t + col, channels 4 kq .. 4 kq + 3: one ds_read_b128 (float), two (double: 16-byte chunks 2 kq and 2 kq + 1)
+  const v4* s_rd = reinterpret_cast<const v4*>(s_strip + col * 16 + ((kq ^ (2 * (col >> 3))) << 2));  // float; + t * 256 elements
+  const v2* s_rd0 = reinterpret_cast<const v2*>(s_strip + col * 16 + (((2 * kq) ^ (col >> 1)) << 1));  // double
+  const v2* s_rd1 = reinterpret_cast<const v2*>(s_strip + col * 16 + (((2 * kq + 1) ^ (col >> 1)) << 1));
+  auto strip_row = [&](int t) -> v4 {
+    if constexpr (F64) {
+      const v2 lo2 = s_rd0[t * 128], hi2 = s_rd1[t * 128];
+      return v4{lo2[0], lo2[1], hi2[0], hi2[1]};
+    } else {
+      return s_rd[t * 64];
+    }
+  };
 
-  float* s_gw = s_gv + m_a * kMmGvPitch + col;                                                  // E: column m_a (+ i, + 8 + i), channel col
-  const mm_f32x4* s_gr = reinterpret_cast<const mm_f32x4*>(s_gv + col * kMmGvPitch + 4 * kq);   // B: column col, channels 4 kq ..
+  T* s_gw = s_gv + m_first * kGvPitch + col;                                  // E: column m_first (+ i m_step, + 8), channel col
+  const T* s_gr = s_gv + col * kGvPitch + 4 * kq;                             // B: column col, channels 4 kq ..
 
   const int njobs = A.fpad >> 6;  // strips per wave: even, the host gives this kernel only rows padded to a multiple of 128 channels
   // The tile loads are buffer loads: resource = this item's tiles, per-lane offset `lo` (one VGPR for the whole kernel), the
   // k-step's offset in an SGPR -- no vector-ALU address arithmetic (with flat pointers hipcc spent a 64-bit vector add per load).
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.tiles + it.tile_first), 0, 0x7fffffff, 0x00020000);
-  const unsigned tile_bytes = (unsigned)nvec << (fb_log2 + 2);
-  const unsigned lo = ((unsigned)kq * FB + (unsigned)col) * 4u;  // byte offset of this lane's element inside a k-step
-  const unsigned step_bytes = FB * 16u;                          // four rows
-  // Software pipeline.  A wave keeps 28 to 56 tile loads (7 to 14 KB) in flight at all times: the k-step registers form a ring that
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A.tiles + it.tile_first), 0, 0x7fffffff, 0x00020000);
+  const unsigned tile_bytes = ((unsigned)nvec << fb_log2) * ES;
+  const unsigned lo = ((unsigned)kq * FB + (unsigned)col) * ES;  // byte offset of this lane's element inside a k-step
+  const unsigned step_bytes = FB * 4u * ES;                      // four rows
+  // Software pipeline.  A wave keeps 28 to 56 tile loads (7 to 14 KB; twice that in double) in flight at all times: the k-step registers form a ring that
   // is DEPTH jobs deep (4 up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads), and F re-issues each register -- for the job DEPTH ahead --
   // right behind the MFMA that consumed it, so loads are issued in the order they are consumed and the compiler's counted waits
   // never drain the queue.  The samples of job n + 1 are requested at the START of job n (two register sets, the job loop is
@@ -140,12 +208,12 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   // (Giving one wave the two halves of a 128-byte line in consecutive jobs raised the L2 hits from 15 M to 52 M per launch and
   // changed neither the fabric traffic nor the time for the better: 1.36 against 1.30 ms.)
   auto strip_of = [&](int n) -> unsigned { return (unsigned)(wave + 4 * n); };
-  float treg[DEPTH][NS];
+  T treg[DEPTH][NS];
   auto job_off = [&](int n) -> unsigned {
     const unsigned ch = strip_of(n < njobs ? n : njobs - 1) * kMmStrip;
-    return (ch >> fb_log2) * tile_bytes + (ch & (FB - 1)) * 4u;
+    return (ch >> fb_log2) * tile_bytes + (ch & (FB - 1)) * ES;
   };
-  struct Samples { float dr[2], di[2], w[2]; mm_f32x2 g0[2], g1[2]; };  // this lane's two members at its channel
+  struct Samples { T dr[2], di[2], w[2]; v2 g0[2], g1[2]; };  // this lane's two members at its channel
   auto issue_samples = [&](int n, Samples& S) {
     const unsigned ch = strip_of(n < njobs ? n : njobs - 1) * kMmStrip;
 #pragma unroll
@@ -153,14 +221,14 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
       S.dr[i] = A.data_r[so[i] + ch];
       S.di[i] = A.data_i[so[i] + ch];
       S.w[i] = A.wgts[so[i] + ch];
-      S.g0[i] = *reinterpret_cast<const mm_f32x2*>(A.gains + g0o[i] + ch);
-      S.g1[i] = *reinterpret_cast<const mm_f32x2*>(A.gains + g1o[i] + ch);
+      S.g0[i] = *reinterpret_cast<const v2*>(A.gains + g0o[i] + ch);
+      S.g1[i] = *reinterpret_cast<const v2*>(A.gains + g1o[i] + ch);
     }
   };
 
-  mm_f32x4 dC[NT];
+  v4 dC[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) dC[t] = mm_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) dC[t] = v4{0, 0, 0, 0};
   double loss_acc[2] = {0.0, 0.0};  // of this lane's two members: each member's loss goes to its OWN slot (its time slice's sum)
   double sr_acc[2] = {0.0, 0.0}, si_acc[2] = {0.0, 0.0};  // REG, loss pass: S = sum w m of the two members
 
@@ -171,24 +239,27 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
 #define MM_STAMP(ACC)
 #endif
   // one job: samples S (requested one job ago), ring set D; requests the next job's samples into Sn
-  auto job = [&](int n, float (&tr)[NS], const Samples& S, Samples& Sn) {
+  // LATE (double, more than 192 vectors: 16 registers per tile, and 512 are all there is): ONE sample set, requested again between
+  // E and B -- the adjoint's MFMAs of such a block (3 600 cycles) cover the latency -- and the coefficient operand two groups ahead.
+  constexpr bool LATE = F64 && NT > 12;
+  auto job = [&](int n, T (&tr)[NS], const Samples& S, Samples& Sn) {
     MM_STAMP(t_b)
     __syncthreads();  // keeps the four waves on neighbouring strips of the same rows (3-4 % faster than letting them drift)
     MM_STAMP(t_bar)
-    issue_samples(n + 1, Sn);
+    if (!LATE) issue_samples(n + 1, Sn);
     __builtin_amdgcn_sched_barrier(0);
     // ---- F: two accumulator chains (40-cycle dependent latency against a 32-cycle issue); each register goes back out for job n + DEPTH
     const unsigned nxt_off = job_off(n + DEPTH);
     const unsigned nxt_step = n + DEPTH < njobs ? step_bytes : 0u;
-    mm_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    v4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     // One fenced group per pair of k-steps: two MFMAs, their strip store, the two re-issued loads.  (Left alone -- also with
     // sched_group_barrier hints -- the scheduler holds the loads back and sends them in a burst at the end of F: the queue ran
     // down to a third of its depth in every job.)  The coefficient operand is the same for all jobs of an item: up to 112
     // vectors it lives in registers (creg); wider blocks read it from LDS four groups ahead -- LDS operations complete in order,
     // so a wait for the read of group p also waits for the strip stores and reads issued since, and a two-group lead left about
     // a hundred cycles of LDS latency exposed in every group.
-    constexpr int kLead = 4;
-    float bq[kLead + 1][2];
+    constexpr int kLead = LATE ? 2 : 4;
+    T bq[kLead + 1][2];
     if (!CREG) {
 #pragma unroll
       for (int g = 0; g < kLead; ++g)
@@ -201,7 +272,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
 #pragma unroll
     for (int s = 0; s < NS; s += 2) {
       const int p = s >> 1;
-      float c0, c1;
+      T c0, c1;
       if (CREG) {
         c0 = creg[s];
         c1 = creg[s + 1];
@@ -213,78 +284,99 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
         c0 = bq[p % (kLead + 1)][0];
         c1 = bq[p % (kLead + 1)][1];
       }
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0, tr[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1, tr[s + 1], acc1, 0, 0, 0);
-      if (GRAD) {  // steps s, s + 1 (s even) lie in the same 8-row group
-        float* w = (s & 2) ? s_w1 : s_w0;
+      acc0 = X::mfma(c0, tr[s], acc0);
+      acc1 = X::mfma(c1, tr[s + 1], acc1);
+      if (GRAD) {  // steps s, s + 1 (s even) lie in the same 8-row group (float) / pair of 2-row groups that differ in the lane part only (double)
+        T* w = s_w[s & 3];
+        T* w1 = s_w[(s + 1) & 3];
         w[s * 64] = tr[s];
-        w[(s + 1) * 64] = tr[s + 1];
+        w1[(s + 1) * 64] = tr[s + 1];
       }
-      tr[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lo, nxt_off + (unsigned)s * nxt_step, CAL_MM_NT));
-      tr[s + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lo, nxt_off + (unsigned)(s + 1) * nxt_step, CAL_MM_NT));
+      tr[s] = X::load(rs, lo, nxt_off + (unsigned)s * nxt_step);
+      tr[s + 1] = X::load(rs, lo, nxt_off + (unsigned)(s + 1) * nxt_step);
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    mm_f32x4 acc = acc0 + acc1;            // acc[r] of lane (ch, q) = v(channel ch) of column 4 q + r
+    v4 acc = acc0 + acc1;            // acc[r] of lane (ch, q) = v(channel ch) of column MmT::row_of(q, r)
     MM_STAMP(t_f)
-    // ---- E: v_permlane32_swap hands each lane the missing part of the two members it evaluates (the lower lane's acc[i] and
-    // the upper lane's acc[i + 2] stay, the other two registers cross): (re, im) of member m_a + i on both lanes, no selects
+    // ---- E.  float: v_permlane32_swap hands each lane the missing part of the two members it evaluates (the lower lane's acc[i]
+    // and the upper lane's acc[i + 2] stay, the other two registers cross): (re, im) of member m_first + i on both lanes, no
+    // selects.  double: acc[i] and acc[i + 2] ARE (re, im) of member q + 4 i.
     const unsigned ch0 = strip_of(n) * kMmStrip;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      typedef unsigned u2 __attribute__((ext_vector_type(2)));
-      const float mine_lo = acc[i], mine_hi = acc[i + 2];  // (scalars first: __builtin_bit_cast applied to a vector ELEMENT read element 0)
-      const u2 sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mine_lo), __builtin_bit_cast(unsigned, mine_hi), false, false);
-      const unsigned sw0 = sw[0], sw1 = sw[1];
-      const float vr = __builtin_bit_cast(float, sw0), vi = __builtin_bit_cast(float, sw1);
-      const float g0x = S.g0[i][0], g0y = S.g0[i][1], g1x = S.g1[i][0], g1y = S.g1[i][1];
-      const float d_r = S.dr[i], d_i = S.di[i], w = S.w[i];
+      T vr, vi;
+      if constexpr (F64) {
+        vr = acc[i];
+        vi = acc[i + 2];
+      } else {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const float mine_lo = acc[i], mine_hi = acc[i + 2];  // (scalars first: __builtin_bit_cast applied to a vector ELEMENT read element 0)
+        const u2 sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mine_lo), __builtin_bit_cast(unsigned, mine_hi), false, false);
+        const unsigned sw0 = sw[0], sw1 = sw[1];
+        vr = __builtin_bit_cast(float, sw0);
+        vi = __builtin_bit_cast(float, sw1);
+      }
+      const T g0x = S.g0[i][0], g0y = S.g0[i][1], g1x = S.g1[i][0], g1y = S.g1[i][1];
+      const T d_r = S.dr[i], d_i = S.di[i], w = S.w[i];
       // G = g0 conj(g1)   (calibration.py:1598-1601: grgr + gigi, gigr - grgi)
-      const float G_r = g0x * g1x + g0y * g1y;
-      const float G_i = g0y * g1x - g0x * g1y;
-      const float m_r = G_r * vr - G_i * vi;
-      const float m_i = G_i * vr + G_r * vi;
-      const float r_r = d_r - m_r, r_i = d_i - m_i;
+      const T G_r = g0x * g1x + g0y * g1y;
+      const T G_i = g0y * g1x - g0x * g1y;
+      const T m_r = G_r * vr - G_i * vi;
+      const T m_i = G_i * vr + G_r * vi;
+      const T r_r = d_r - m_r, r_i = d_i - m_i;
       if (!(REG && GRAD)) loss_acc[i] += (double)(w * (r_r * r_r + r_i * r_i));
       if (REG && !GRAD) {
         sr_acc[i] += (double)(w * m_r);
         si_acc[i] += (double)(w * m_i);
       }
       if (GRAD) {
-        float e_r = -2.f * w * r_r, e_i = -2.f * w * r_i;
+        T e_r = (T)-2 * w * r_r, e_i = (T)-2 * w * r_i;
         if (REG) {
-          e_r += s_al[2 * (m_a + i)] * w;
-          e_i += s_al[2 * (m_a + i) + 1] * w;
+          e_r += s_al[2 * (m_first + i * m_step)] * w;
+          e_i += s_al[2 * (m_first + i * m_step) + 1] * w;
         }
         // gbar_v = conj(G) e -> the wave's [column][channel] buffer, from where B takes it as its operand
-        s_gw[i * kMmGvPitch] = G_r * e_r + G_i * e_i;
-        s_gw[(8 + i) * kMmGvPitch] = G_r * e_i - G_i * e_r;
-        mm_f32x2 q;  // gbar_G = conj(v) e; members the set does not have: zeros to the spare row
+        s_gw[(i * m_step) * kGvPitch] = G_r * e_r + G_i * e_i;
+        s_gw[(8 + i * m_step) * kGvPitch] = G_r * e_i - G_i * e_r;
+        v2 q;  // gbar_G = conj(v) e; members the set does not have: zeros to the spare row
         q[0] = vr * e_r + vi * e_i;
         q[1] = vr * e_i - vi * e_r;
-        *reinterpret_cast<mm_f32x2*>(A.q0 + so[i] + ch0) = q;
+        *reinterpret_cast<v2*>(A.q0 + so[i] + ch0) = q;
       }
     }
     MM_STAMP(t_e)
+    if (LATE) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue_samples(n + 1, Sn);  // (Sn IS S here)
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- B: gradient tiles in pairs (independent accumulators back to back)
     if (GRAD) {
       __builtin_amdgcn_wave_barrier();
-      const mm_f32x4 gvb = *s_gr;  // lane (column, k): gbar_v of channels 4 k .. 4 k + 3
+      v4 gvb;  // lane (column, k): gbar_v of channels 4 k .. 4 k + 3
+      if constexpr (F64) {
+        const v2 g_lo = *reinterpret_cast<const v2*>(s_gr), g_hi = *reinterpret_cast<const v2*>(s_gr + 2);
+        gvb = v4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]};
+      } else {
+        gvb = *reinterpret_cast<const v4*>(s_gr);
+      }
 #pragma unroll
       for (int t = 0; t + 1 < NT; t += 2) {
-        const mm_f32x4 a0 = s_rd[t * 64];
-        const mm_f32x4 a1 = s_rd[(t + 1) * 64];
+        const v4 a0 = strip_row(t);
+        const v4 a1 = strip_row(t + 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], gvb[r], dC[t], 0, 0, 0);
-          dC[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], gvb[r], dC[t + 1], 0, 0, 0);
+          dC[t] = X::mfma(a0[r], gvb[r], dC[t]);
+          dC[t + 1] = X::mfma(a1[r], gvb[r], dC[t + 1]);
         }
+        if (F64 && NT > 8 && (t & 2)) __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler reads all 14 strip rows -- 112 registers -- ahead of the first MFMA: 56 spilled)
       }
       if (NT & 1) {
-        const mm_f32x4 a0 = s_rd[(NT - 1) * 64];
+        const v4 a0 = strip_row(NT - 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dC[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], gvb[r], dC[NT - 1], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) dC[NT - 1] = X::mfma(a0[r], gvb[r], dC[NT - 1]);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -299,7 +391,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   for (int d = 0; d < DEPTH; ++d) {
     const unsigned off = job_off(d);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) treg[d][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lo, off + (unsigned)s * step_bytes, CAL_MM_NT));
+    for (int s = 0; s < NS; ++s) treg[d][s] = X::load(rs, lo, off + (unsigned)s * step_bytes);
   }
   __builtin_amdgcn_sched_barrier(0);
 #ifdef CAL_MM_STAMP
@@ -312,6 +404,8 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
       job(n + 2, treg[2 % DEPTH], SA, SB);
       job(n + 3, treg[3 % DEPTH], SB, SA);
     }
+  } else if (LATE) {
+    for (int n = 0; n < njobs; ++n) job(n, treg[0], SA, SA);
   } else {
     for (int n = 0; n < njobs; n += 2) {  // njobs is even
       job(n, treg[0], SA, SB);
@@ -327,7 +421,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
   }
 #endif
   // ---- epilogue: loss partial of every member (into the member's own slot: members may belong to different time slices),
-  // coefficient gradients of every member.  Lane (col, kq) holds members m_a, m_a + 1 at its channels: sum over the 16 lanes of
+  // coefficient gradients of every member.  Lane (col, kq) holds its two members at its channel: sum over the 16 lanes of
   // the row, then over the four waves in order.
   if (!(REG && GRAD)) {
     constexpr int NQ = REG ? 3 : 1;  // loss (, S_r, S_i): s_red [quantity][4 waves][8 members]
@@ -338,7 +432,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
         double v = qn == 0 ? loss_acc[i] : (qn == 1 ? sr_acc[i] : si_acc[i]);
 #pragma unroll
         for (int sft = 1; sft < 16; sft <<= 1) v += __shfl_xor(v, sft, 64);
-        if (col == 0) s_red[qn * 32 + wave * 8 + m_a + i] = v;
+        if (col == 0) s_red[qn * 32 + wave * 8 + m_first + i * m_step] = v;
       }
     }
   }
@@ -350,56 +444,57 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<float>& A, const
     A.part[slot + 2] = REG ? ((s_red[64 + tid] + s_red[72 + tid]) + s_red[80 + tid]) + s_red[88 + tid] : 0.0;
   }
   if (!GRAD) return;
-  // dC[t][r] of lane (col, kq) of wave w = that wave's part of GC[16 t + 4 kq + r][col]; the four parts meet in the strip area:
+  // dC[t][r] of lane (col, kq) of wave w = that wave's part of GC[16 t + row_of(kq, r)][col]; the four parts meet in the strip area:
   // s_x[((w * NT + t) * 4 + r) * 64 + lane]
-  float* s_x = s_strips;
+  T* s_x = s_strips;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_x[((wave * NT + t) * 4 + r) * 64 + lane] = dC[t][r];
   }
   __syncthreads();
-  // thread (column tid >> 4, vector-in-tile tid & 15) sums the four parts of its 16 consecutive... one vector per tile
+  // thread (column tid >> 4, vector-in-tile tid & 15) sums the four parts of one vector per tile
   {
     const int j = tid >> 4, kk = tid & 15, m = j & 7;
     if (m < NB) {
-      float* gc = (j < 8 ? A.gcp0_r : A.gcp0_i) + s_mem[m].goff;
-      const int src_lane = j + 16 * (kk >> 2), r = kk & 3;
+      T* gc = (j < 8 ? A.gcp0_r : A.gcp0_i) + s_mem[m].goff;
+      const int src_lane = F64 ? j + 16 * (kk & 3) : j + 16 * (kk >> 2);  // kk = row_of(kq, r)
+      const int r = F64 ? kk >> 2 : kk & 3;
       for (int t = 0; t < NT; ++t) {
         const int k = 16 * t + kk;
-        const float* px = s_x + (t * 4 + r) * 64 + src_lane;
-        const float v = ((px[0] + px[NT * 256]) + px[2 * NT * 256]) + px[3 * NT * 256];
+        const T* px = s_x + (t * 4 + r) * 64 + src_lane;
+        const T v = ((px[0] + px[NT * 256]) + px[2 * NT * 256]) + px[3 * NT * 256];
         if (k < nvec) gc[k] = v;
       }
     }
   }
 }
 
-template <int MODE, bool REG>
-__global__ __launch_bounds__(kThreads, 2) void fused_multi_mfma_kernel(const FusedArgs<float> A) {
+template <typename T, int MODE, bool REG>
+__global__ __launch_bounds__(kThreads, MmT<T>::kWgPerCu) void fused_multi_mfma_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int item_idx = A.heads[blockIdx.x];
   if (item_idx < 0) return;  // an empty slot of the XCD-affine head list
   const Item it = A.items[item_idx];
   // (members of several time slices: the item runs while any of them does; a stopped member's outputs are not consumed)
   if (A.nslices == 1 && (A.state->done | A.state->done_after)) return;
-  // the ring of tile registers is 4 jobs deep up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads (7 to 14 KB) in flight per wave
+  // the ring of tile registers is 4 jobs deep up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads (7 to 14 KB; double: 14 to 28) in flight per wave
   const bool quad = ((A.fpad >> 6) & 3) == 0;  // a wave's jobs come in fours
   switch ((it.nvec + 15) >> 4) {  // wave-uniform
-    case 1: if (quad) multi_mfma_item<MODE, 1, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<MODE, 1, 2, REG>(A, it, item_idx, smem); break;
-    case 2: if (quad) multi_mfma_item<MODE, 2, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<MODE, 2, 2, REG>(A, it, item_idx, smem); break;
-    case 3: if (quad) multi_mfma_item<MODE, 3, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<MODE, 3, 2, REG>(A, it, item_idx, smem); break;
-    case 4: multi_mfma_item<MODE, 4, 2, REG>(A, it, item_idx, smem); break;
-    case 5: multi_mfma_item<MODE, 5, 2, REG>(A, it, item_idx, smem); break;
-    case 6: multi_mfma_item<MODE, 6, 2, REG>(A, it, item_idx, smem); break;
-    case 7: multi_mfma_item<MODE, 7, 2, REG>(A, it, item_idx, smem); break;
-    case 8: multi_mfma_item<MODE, 8, 1, REG>(A, it, item_idx, smem); break;
-    case 9: multi_mfma_item<MODE, 9, 1, REG>(A, it, item_idx, smem); break;
-    case 10: multi_mfma_item<MODE, 10, 1, REG>(A, it, item_idx, smem); break;
-    case 11: multi_mfma_item<MODE, 11, 1, REG>(A, it, item_idx, smem); break;
-    case 12: multi_mfma_item<MODE, 12, 1, REG>(A, it, item_idx, smem); break;
-    case 13: multi_mfma_item<MODE, 13, 1, REG>(A, it, item_idx, smem); break;
-    case 14: multi_mfma_item<MODE, 14, 1, REG>(A, it, item_idx, smem); break;
+    case 1: if (quad) multi_mfma_item<T, MODE, 1, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<T, MODE, 1, 2, REG>(A, it, item_idx, smem); break;
+    case 2: if (quad) multi_mfma_item<T, MODE, 2, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<T, MODE, 2, 2, REG>(A, it, item_idx, smem); break;
+    case 3: if (quad) multi_mfma_item<T, MODE, 3, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<T, MODE, 3, 2, REG>(A, it, item_idx, smem); break;
+    case 4: multi_mfma_item<T, MODE, 4, 2, REG>(A, it, item_idx, smem); break;
+    case 5: multi_mfma_item<T, MODE, 5, 2, REG>(A, it, item_idx, smem); break;
+    case 6: multi_mfma_item<T, MODE, 6, 2, REG>(A, it, item_idx, smem); break;
+    case 7: multi_mfma_item<T, MODE, 7, 2, REG>(A, it, item_idx, smem); break;
+    case 8: multi_mfma_item<T, MODE, 8, 1, REG>(A, it, item_idx, smem); break;
+    case 9: multi_mfma_item<T, MODE, 9, 1, REG>(A, it, item_idx, smem); break;
+    case 10: multi_mfma_item<T, MODE, 10, 1, REG>(A, it, item_idx, smem); break;
+    case 11: multi_mfma_item<T, MODE, 11, 1, REG>(A, it, item_idx, smem); break;
+    case 12: multi_mfma_item<T, MODE, 12, 1, REG>(A, it, item_idx, smem); break;
+    case 13: multi_mfma_item<T, MODE, 13, 1, REG>(A, it, item_idx, smem); break;
+    case 14: multi_mfma_item<T, MODE, 14, 1, REG>(A, it, item_idx, smem); break;
     default: break;  // the host gives this kernel no wider block
   }
 }
