@@ -672,7 +672,8 @@ def main():
             "kernel": ("fused_basis_kernel<MODE_GRAD>" if not (sharded and ntimes > 1 and args.layout == "stream") else
                        ("fused_multi_mfma_kernel<MODE_GRAD> (the slices of a rank share basis tiles: 16 right-hand sides per tile on "
                         "v_mfma_f32_16x16x4_f32; basis bytes counted once per unique tile)" if dtype == np.float32 else
-                        "fused_multi_kernel<double, MODE_GRAD> (the slices of a rank share basis tiles; basis bytes counted once per unique tile)")),
+                        "fused_multi_mfma_kernel<double, MODE_GRAD> (the slices of a rank share basis tiles: 16 right-hand sides per tile on "
+                        "v_mfma_f64_16x16x4_f64; basis bytes counted once per unique tile)")),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -154,3 +154,41 @@ def test_a_share_of_the_two_and_four_gpu_jobs_against_the_c_oracle(world, rank):
     assert np.allclose(np.sum([r[0] for r in res], axis=0), tl, rtol=1e-4)
     for a, b in ((fg_r, tg_r), (fg_i, tg_i), (fc_r, tc_r), (fc_i, tc_i)):
         assert relnorm(a, b) <= 1e-3
+
+
+def test_one_share_of_the_eight_gpu_job_in_double_precision():
+    """--precision 64 of the reference (calibration.py:1857) on the job a rank of `bench.py --gpus 8 --dtype f64` runs: the time
+    slices that share tiles go through fused_multi_mfma_kernel<double> (v_mfma_f64_16x16x4_f64, 8 members per head; HERA-350's
+    blocks of 18 .. 204 vectors are every class of that kernel up to 13 tiles, the last one with the single sample buffer).  Loss,
+    every slice's loss, all gradients and a short Adam trajectory against the fp64 C restatement at fp64 tolerances (the regularised
+    two-pass form of the kernel: tests/test_gpu_shapes.py)."""
+    import bench
+    from calamity_amd.solver import HipFitSolver
+    from oracle.ref_c import CRef
+
+    prob, start, na = bench.build_sharded_job("hera350", 5, 8, 8, per_slice=True)
+    assert prob.nslices == 8 and prob.bl_alias is not None
+    rng = np.random.default_rng(77)
+    start["g_r"] = 1.0 + 0.05 * rng.standard_normal(start["g_r"].shape)
+    start["g_i"] = 0.05 * rng.standard_normal(start["g_i"].shape)
+    single = D.FitProblem(**{k: getattr(prob, k) for k in ("nants", "nfreqs", "basis", "grp_basis", "grp_bl_start", "bl_ant0", "bl_ant1", "bl_rowblk",
+                                                            "data_r", "data_i", "wgts")})
+    c = CRef(single, np.float64, nthreads=16)
+    s = HipFitSolver(dtype=np.float64)
+    s.set_problem(prob, layout="stream")
+    s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    loss, g_r, g_i, c_r, c_i = s.eval_grads()
+    each = s.slice_losses()
+    l, og_r, og_i, oc_r, oc_i = c.loss_grads(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+    assert abs(loss - l) <= 1e-12 * abs(l) and abs(each.sum() - loss) <= 1e-12 * abs(loss), (loss, l)
+    assert abs(s.eval_loss() - l) <= 1e-12 * abs(l)
+    for a, b in ((g_r, og_r), (g_i, og_i), (c_r, oc_r), (c_i, oc_i)):
+        assert relnorm(a, b) <= 1e-11
+    s.set_optimizer("Adam", learning_rate=1e-2)
+    res = s.run_slices(4, record=True, tol=0.0)
+    got = s.get_params()
+    ref = c.fit(start["g_r"], start["g_i"], start["c_r"], start["c_i"], 4, optimizer="Adam", learning_rate=1e-2)
+    assert np.allclose(np.sum([r[0] for r in res], axis=0), ref[4], rtol=1e-10)
+    for a, b in zip(got, ref[:4]):
+        assert relnorm(a, b) <= 1e-8
+    s.close()

@@ -166,9 +166,9 @@ def test_model_and_init_on_multi_baseline_groups(dtype):
 @pytest.mark.parametrize("nslices", [3, 9, 10])
 def test_time_slices_that_share_tiles(nslices):
     """cal_problem_desc::bl_alias: the same baselines in several time slices fitted by one solver read ONE copy of their basis
-    tiles, and fused_multi_mfma_kernel (float32, at most 224 vectors) / fused_multi_kernel process a baseline's slices together
+    tiles, and fused_multi_mfma_kernel (at most 224 vectors) / fused_multi_kernel process a baseline's slices together
     (SURVEY.md section 8e "Multiple times"; calibration.py:1160-1167 loops over times).  Every tile width, sets larger than a multi
-    item holds (10 slices: 8 + 2 in float32, 4 + 4 + 2 in float64; 9 slices: the last baseline of a set is left over and runs as an
+    item holds (10 slices: 8 + 2 on the matrix-core kernel in both precisions, 4 + 4 + 2 for the 230-vector block in float64; 9 slices: the last baseline of a set is left over and runs as an
     ordinary item), loss / gradients against the C restatement of the batched problem, the regularised form
     (two passes of the same kernels: S first, then the gradients with every slice's alpha), model evaluation and initial coefficients, and a short trajectory against the one
     of the same problem WITHOUT the alias table (every baseline streaming its own copy; the loss partials are summed in another
@@ -214,6 +214,28 @@ def test_time_slices_that_share_tiles(nslices):
         for x, y in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
             assert np.linalg.norm(np.asarray(x, np.float64) - y) <= 10 * tol * np.linalg.norm(y)
         assert outs[0][3] < outs[1][3]  # one tile copy per baseline instead of one per (slice, baseline)
+
+
+def test_slices_share_tiles_on_a_band_of_six_strips_per_wave():
+    """300 channels pad to 384 = six 16-channel strips per wave: not a multiple of four, so the blocks of at most 48 vectors run
+    fused_multi_mfma_kernel's two-deep ring instead of the four-deep one (every other test here, and HERA-350's 1024 channels,
+    take the four-deep form); every class of both precisions, members 8 + 3 (float32 and float64: 16 MFMA columns in both), loss
+    and gradients against the C restatement of the batched problem, with and without the regulariser."""
+    from calamity_amd import distributed as D
+
+    nvecs = [4, 16, 17, 33, 48, 49, 64, 80, 96, 112, 113, 128, 144, 160, 176, 192, 193, 208, 224]
+    base, _ = random_problem(nvecs, [1] * len(nvecs), nants=7, nfreqs=300, seed=90)
+    parts = []
+    for t in range(11):
+        p, st = random_problem(nvecs, [1] * len(nvecs), nants=7, nfreqs=300, seed=91 + t)
+        p.basis, p.grp_basis = base.basis, base.grp_basis
+        p.bl_ant0, p.bl_ant1, p.bl_rowblk = base.bl_ant0, base.bl_ant1, base.bl_rowblk
+        p.wgts = p.wgts / 11
+        parts.append((p, st))
+    prob, start = D.batch_time_slices(parts)
+    assert prob.bl_alias is not None
+    prob.sky_r, prob.sky_i = np.concatenate([p.sky_r for p, _ in parts]), np.concatenate([p.sky_i for p, _ in parts])
+    check(prob, start, layouts=("stream",))
 
 
 def test_slices_that_share_only_some_tiles():

@@ -1,18 +1,21 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/prof_multi.sh <tag> [lib.so]
+# usage (on the GPU box, from the repo root): bash tools/prof_multi.sh <tag> [lib.so] [f32|f64]
 # Counters of the multi-slice kernels on the per-rank job of an 8-GPU run (8 time slices x 1/8 of HERA-350's baselines), each
 # group in its own rocprofv3 pass (no trace domains beside --pmc), plus a kernel trace with --stats.  Under gpurun_out/<tag>/.
 set -e
 tag=${1:-multi}
 lib=${2:-calamity_amd/csrc/libcalamity_hip.so}
+dt=${3:-f32}
+mops=SQ_INSTS_VALU_MFMA_MOPS_F32
+if [ "$dt" = f64 ]; then mops=SQ_INSTS_VALU_MFMA_MOPS_F64; fi
 cd "${GRAFT_REPO_ROOT:?}"
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
-cmd="python3 tools/kbench.py --child --lib $lib --slices 8 --steps 4"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/trace -o multi --output-format csv -- python3 tools/kbench.py --child --lib $lib --slices 8 --steps 20 > $out/trace_stdout.log 2>&1
+cmd="python3 tools/kbench.py --child --lib $lib --dtype $dt --slices 8 --steps 4"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/trace -o multi --output-format csv -- python3 tools/kbench.py --child --lib $lib --dtype $dt --slices 8 --steps 20 > $out/trace_stdout.log 2>&1
 echo "trace done"
-[ -n "$SKIP_SQ" ] || timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $out/pmc -o sq --output-format csv -- $cmd > $out/pmc_sq.log 2>&1
+[ -n "$SKIP_SQ" ] || timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES $mops SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $out/pmc -o sq --output-format csv -- $cmd > $out/pmc_sq.log 2>&1
 echo "sq done"
 [ -n "$SKIP_SQ" ] || timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM -d $out/pmc -o lds --output-format csv -- $cmd > $out/pmc_lds.log 2>&1
 echo "lds done"
