@@ -216,6 +216,7 @@ struct SolverT final : cal_solver {
   DevBuf members, heads;                       // baselines that share tiles (bl_alias): member lists of the head items, head item indices
   int nheads = 0;                              // heads[0 .. nheads_mfma): fused_multi_mfma_kernel (at most kMmMaxVec vectors); the rest: fused_multi_kernel
   int nheads_mfma = 0;
+  bool heads_one_pass = false;                 // the regularised step of the heads in ONE pass (all of them on fused_multi_mfma_kernel<.., REG = 2>)
   int mm_grid = 0;                             // workgroups of the matrix-core multi-slice launch: its head list is dealt over the 8 XCDs (-1: empty slot)
   size_t lds_multi_bytes = 0, lds_multi_mfma_bytes = 0;
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
@@ -1059,6 +1060,10 @@ struct SolverT final : cal_solver {
         }
       }
       nheads = (int)h_heads.size();
+      // the "sum" regulariser over heads: one pass with two adjoint sets when every head is on the matrix-core kernel and narrow enough
+      // for it (multi_mfma_kernels.hpp, REG == 2); else a loss pass for the slices' sums in front of the gradient pass (enqueue_pass)
+      heads_one_pass = nheads > 0 && nheads == nheads_mfma;
+      for (int head : h_heads) heads_one_pass = heads_one_pass && sorted[head].nvec <= kMmMaxVecOnePass<T>;
       // XCD-affine, antenna-grouped dispatch of the matrix-core heads: a head reads 2 gain rows per member (8 slices x 2 x 8 KB of a
       // 1024-channel band) -- a fifth of its bytes, 1.0 GB per pass of an 8-GPU rank's share against 23 MB of distinct gains, because
       // with the heads in cost order nothing a workgroup brings into its XCD's L2 is wanted by its neighbours (hit rate 17 %).
@@ -1108,10 +1113,11 @@ struct SolverT final : cal_solver {
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_kernel<T, MODE_LOSS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_bytes));
         }
         if (nheads_mfma > 0) {
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_GRAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_LOSS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_GRAD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_LOSS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_GRAD, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_LOSS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_GRAD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_LOSS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_multi_mfma_kernel<T, MODE_GRAD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi_mfma_bytes));
         }
       }
     }
@@ -1537,8 +1543,9 @@ struct SolverT final : cal_solver {
       // the two-pass form (loss pass: S; gradient pass: alpha of each member's slice from the state) -- enqueue_pass orders the passes
       if (nheads > 0) {
         if (nheads_mfma > 0) {
-          if (with_reg) hipLaunchKernelGGL((fused_multi_mfma_kernel<T, MODE, true>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
-          else hipLaunchKernelGGL((fused_multi_mfma_kernel<T, MODE, false>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
+          if (with_reg && MODE == MODE_GRAD && heads_one_pass) hipLaunchKernelGGL((fused_multi_mfma_kernel<T, MODE_GRAD, 2>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
+          else if (with_reg) hipLaunchKernelGGL((fused_multi_mfma_kernel<T, MODE, 1>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
+          else hipLaunchKernelGGL((fused_multi_mfma_kernel<T, MODE, 0>), dim3(mm_grid), dim3(kThreads), lds_multi_mfma_bytes, stream, a);
         }
         if (nheads > nheads_mfma) {
           FusedArgs<T> b = a;
@@ -1628,7 +1635,7 @@ struct SolverT final : cal_solver {
         if (grads) launch_dense<true>(m); else launch_dense<false>(m);
       }
     } else {
-      if (grads && R && nheads > 0) {
+      if (grads && R && nheads > 0 && !heads_one_pass) {
         // baselines that share tiles + the "sum" regulariser: their multi-slice kernels need alpha = 2 (S - P) of every slice BEFORE
         // the gradient pass (no second adjoint set there): a loss pass over everything, the slices' sums, alpha -- then the gradients
         launch_fused<MODE_LOSS>(a, true);
@@ -1712,7 +1719,7 @@ struct SolverT final : cal_solver {
   // exchange sits between the reduction and the update), general kernels, and not when every kernel is asked to be its own launch
   // (... nor with the regulariser over baselines that share tiles: alpha is needed between that path's two passes)
   bool one_launch_tail() const {
-    return !comm_on() && !mf_ok && tail_fits_one_launch() && launch_mode != CAL_LAUNCH_KERNELS && !(reg == CAL_REG_SUM && nheads > 0);
+    return !comm_on() && !mf_ok && tail_fits_one_launch() && launch_mode != CAL_LAUNCH_KERNELS && !(reg == CAL_REG_SUM && nheads > 0 && !heads_one_pass);
   }
   void launch_tail(const TailArgs<T>& a, unsigned grid, bool R) {
     if (R)

@@ -20,7 +20,9 @@ for line in sys.stdin:
     if cur is not None and "fused_multi_mfma" in cur:
         m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|VGPRs Spill|Occupancy \[waves/SIMD\]): (\d+)", line)
         if m and m.group(1).startswith("Occupancy"):
-            if int(m.group(2)) < 2 and "IdLi" not in cur and "<double" not in cur:  # (the fp64 instance runs one workgroup per CU by design)
+            inst = re.search(r"fused_multi_mfma_kernelI([fd])Li(\d)ELi(\d)E", cur)  # <T, MODE, REG>
+            one_wg = inst is None or inst.group(1) == "d" or inst.group(3) == "2"  # (double, and the one-pass regularised form: one workgroup per CU by design)
+            if int(m.group(2)) < 2 and not one_wg:
                 bad.append(f"{cur}: occupancy {m.group(2)} waves/SIMD (< 2)")
         elif m and int(m.group(2)) != 0:
             bad.append(f"{cur}: {m.group(1)} = {m.group(2)}")

@@ -85,14 +85,23 @@ template <> struct MmT<double> {
 
 template <typename T> inline size_t multi_mfma_lds_bytes(int nvec_max) {
   const size_t nt = (nvec_max + 15) / 16;
-  return kMmHeader + (nt * 4 * 64 + 4 * nt * 16 * 16 + 4 * 16 * MmT<T>::kGvPitch) * sizeof(T);  // coefficient operand, four strips, four gbar_v buffers
+  return kMmHeader + (nt * 4 * 64 + 4 * nt * 16 * 16 + 2 * 4 * 16 * MmT<T>::kGvPitch) * sizeof(T);  // coefficient operand, four strips, 2 x four gbar_v buffers
 }
+// widest block of the one-pass regularised form (REG == 2): two gradient sets in registers -- in double the allocator needs 40 registers
+// per tile for them and the tile ring: 10 tiles fit the 512 (232 + 256), 12 spill
+template <typename T> constexpr int kMmMaxVecOnePass = sizeof(T) == 8 ? 160 : kMmMaxVec;
 
-// REG: the "sum" regulariser (calibration.py:1623-1656) in two passes, like the dense kernels: the loss pass also sums S = sum w m of
-// every member; once the slices' alpha = 2 (S - P) are known (alpha_kernel) the gradient pass applies e = -2 w r + alpha w with the
-// alpha of each member's own slice -- no second adjoint set, the tiles stream once per pass for all members.  The gradient pass
-// then leaves the loss partials of the loss pass in place.
-template <typename T, int MODE, int NT, int DEPTH, bool REG>
+// REG, the "sum" regulariser (calibration.py:1623-1656):
+//   2  ONE pass, the form of fused_basis_kernel: the gradient pass also sums S = sum w m of every member and carries a second
+//      adjoint set for the w part (gbar_v' = conj(G) w, gbar_G' = conj(v) w -> q1, second coefficient gradients -> gcp1); the
+//      host's combine kernels fold alpha = 2 (S - P) in afterwards.  The tiles stream once per STEP, one exchange per step.
+//      Twice the gradient accumulators: one workgroup per CU in float too; double: blocks of at most kMmMaxVecOnePass (160) vectors, one
+//      sample set (LATE) in every class.
+//   1  two passes, like the dense kernels (kept for solvers that also hold heads of fused_multi_kernel, and for wider double blocks):
+//      the loss pass also sums S; once the slices' alpha are known (alpha_kernel) the gradient pass applies e = -2 w r + alpha w
+//      with the alpha of each member's own slice -- no second adjoint set.  The gradient pass then leaves the loss partials of the
+//      loss pass in place.
+template <typename T, int MODE, int NT, int DEPTH, int REG>
 __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Item& it, int item_idx, unsigned char* smem) {
   using X = MmT<T>;
   typedef typename X::v4 v4;
@@ -119,10 +128,11 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
   T* s_strips = s_c + NS * 64;                                        // [4 waves][16 NT rows][16 channels], swizzled
   T* s_strip = s_strips + wave * NT * 256;
   T* s_gv = s_strips + 4 * NT * 256 + wave * (16 * kGvPitch);          // [16 columns][16 channels] gbar_v of the current job
+  T* s_gv2 = s_gv + 4 * 16 * kGvPitch;                                 // REG == 2: the same of the w part
 
   if (tid < NB * (int)(sizeof(Member) / 4)) reinterpret_cast<int*>(s_mem)[tid] = reinterpret_cast<const int*>(A.members + it.member0)[tid];
   __syncthreads();
-  if (REG && GRAD && tid < 8) {
+  if (REG == 1 && GRAD && tid < 8) {
     const DevState* sst = A.state + (tid < NB ? s_mem[tid].slice : 0);
     s_al[2 * tid] = tid < NB ? (T)sst->alpha_r : (T)0;
     s_al[2 * tid + 1] = tid < NB ? (T)sst->alpha_i : (T)0;
@@ -188,6 +198,8 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
 
   T* s_gw = s_gv + m_first * kGvPitch + col;                                  // E: column m_first (+ i m_step, + 8), channel col
   const T* s_gr = s_gv + col * kGvPitch + 4 * kq;                             // B: column col, channels 4 kq ..
+  T* s_gw2 = s_gv2 + m_first * kGvPitch + col;
+  const T* s_gr2 = s_gv2 + col * kGvPitch + 4 * kq;
 
   const int njobs = A.fpad >> 6;  // strips per wave: even, the host gives this kernel only rows padded to a multiple of 128 channels
   // The tile loads are buffer loads: resource = this item's tiles, per-lane offset `lo` (one VGPR for the whole kernel), the
@@ -226,9 +238,14 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
     }
   };
 
-  v4 dC[NT];
+  constexpr bool R2 = REG == 2 && GRAD;
+  v4 dC[NT], dC2[R2 ? NT : 1];
 #pragma unroll
   for (int t = 0; t < NT; ++t) dC[t] = v4{0, 0, 0, 0};
+  if (R2) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dC2[R2 ? t : 0] = v4{0, 0, 0, 0};
+  }
   double loss_acc[2] = {0.0, 0.0};  // of this lane's two members: each member's loss goes to its OWN slot (its time slice's sum)
   double sr_acc[2] = {0.0, 0.0}, si_acc[2] = {0.0, 0.0};  // REG, loss pass: S = sum w m of the two members
 
@@ -241,7 +258,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
   // one job: samples S (requested one job ago), ring set D; requests the next job's samples into Sn
   // LATE (double, more than 192 vectors: 16 registers per tile, and 512 are all there is): ONE sample set, requested again between
   // E and B -- the adjoint's MFMAs of such a block (3 600 cycles) cover the latency -- and the coefficient operand two groups ahead.
-  constexpr bool LATE = F64 && NT > 12;
+  constexpr bool LATE = F64 && (NT > 12 || R2);
   auto job = [&](int n, T (&tr)[NS], const Samples& S, Samples& Sn) {
     MM_STAMP(t_b)
     __syncthreads();  // keeps the four waves on neighbouring strips of the same rows (3-4 % faster than letting them drift)
@@ -325,14 +342,14 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
       const T m_r = G_r * vr - G_i * vi;
       const T m_i = G_i * vr + G_r * vi;
       const T r_r = d_r - m_r, r_i = d_i - m_i;
-      if (!(REG && GRAD)) loss_acc[i] += (double)(w * (r_r * r_r + r_i * r_i));
-      if (REG && !GRAD) {
+      if (!(REG == 1 && GRAD)) loss_acc[i] += (double)(w * (r_r * r_r + r_i * r_i));
+      if ((REG == 1 && !GRAD) || REG == 2) {
         sr_acc[i] += (double)(w * m_r);
         si_acc[i] += (double)(w * m_i);
       }
       if (GRAD) {
         T e_r = (T)-2 * w * r_r, e_i = (T)-2 * w * r_i;
-        if (REG) {
+        if (REG == 1) {
           e_r += s_al[2 * (m_first + i * m_step)] * w;
           e_i += s_al[2 * (m_first + i * m_step) + 1] * w;
         }
@@ -343,24 +360,37 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
         q[0] = vr * e_r + vi * e_i;
         q[1] = vr * e_i - vi * e_r;
         *reinterpret_cast<v2*>(A.q0 + so[i] + ch0) = q;
+        if (R2) {  // the w part: gbar_v' = conj(G) w, gbar_G' = conj(v) w (fit_kernels.hpp, process_group_item)
+          s_gw2[(i * m_step) * kGvPitch] = G_r * w;
+          s_gw2[(8 + i * m_step) * kGvPitch] = -G_i * w;
+          v2 qw;
+          qw[0] = vr * w;
+          qw[1] = -vi * w;
+          *reinterpret_cast<v2*>(A.q1 + so[i] + ch0) = qw;
+        }
       }
     }
     MM_STAMP(t_e)
     if (LATE) {
       __builtin_amdgcn_sched_barrier(0);
-      issue_samples(n + 1, Sn);  // (Sn IS S here)
+      issue_samples(n + 1, Sn);  // (Sn IS S here: SB below is SA)
       __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- B: gradient tiles in pairs (independent accumulators back to back)
     if (GRAD) {
       __builtin_amdgcn_wave_barrier();
-      v4 gvb;  // lane (column, k): gbar_v of channels 4 k .. 4 k + 3
+      v4 gvb, gvb2 = {0, 0, 0, 0};  // lane (column, k): gbar_v of channels 4 k .. 4 k + 3
       if constexpr (F64) {
         const v2 g_lo = *reinterpret_cast<const v2*>(s_gr), g_hi = *reinterpret_cast<const v2*>(s_gr + 2);
         gvb = v4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]};
+        if (R2) {
+          const v2 h_lo = *reinterpret_cast<const v2*>(s_gr2), h_hi = *reinterpret_cast<const v2*>(s_gr2 + 2);
+          gvb2 = v4{h_lo[0], h_lo[1], h_hi[0], h_hi[1]};
+        }
       } else {
         gvb = *reinterpret_cast<const v4*>(s_gr);
+        if (R2) gvb2 = *reinterpret_cast<const v4*>(s_gr2);
       }
 #pragma unroll
       for (int t = 0; t + 1 < NT; t += 2) {
@@ -370,13 +400,20 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
         for (int r = 0; r < 4; ++r) {
           dC[t] = X::mfma(a0[r], gvb[r], dC[t]);
           dC[t + 1] = X::mfma(a1[r], gvb[r], dC[t + 1]);
+          if (R2) {
+            dC2[R2 ? t : 0] = X::mfma(a0[r], gvb2[r], dC2[R2 ? t : 0]);
+            dC2[R2 ? t + 1 : 0] = X::mfma(a1[r], gvb2[r], dC2[R2 ? t + 1 : 0]);
+          }
         }
         if (F64 && NT > 8 && (t & 2)) __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler reads all 14 strip rows -- 112 registers -- ahead of the first MFMA: 56 spilled)
       }
       if (NT & 1) {
         const v4 a0 = strip_row(NT - 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dC[NT - 1] = X::mfma(a0[r], gvb[r], dC[NT - 1]);
+        for (int r = 0; r < 4; ++r) {
+          dC[NT - 1] = X::mfma(a0[r], gvb[r], dC[NT - 1]);
+          if (R2) dC2[R2 ? NT - 1 : 0] = X::mfma(a0[r], gvb2[r], dC2[R2 ? NT - 1 : 0]);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -384,7 +421,8 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
 
   // (the prologue issues in the order of the steady state -- samples, then tiles: at the loop head the compiler's counted waits
   // must cover the entry path too, and samples requested BEHIND the tiles there made every iteration wait for all but five loads)
-  Samples SA, SB;
+  Samples SA, SB_;
+  Samples& SB = LATE ? SA : SB_;
   issue_samples(0, SA);
   __builtin_amdgcn_sched_barrier(0);  // (the scheduler is free to reorder independent loads: pin the order the waits are counted against)
 #pragma unroll
@@ -404,8 +442,8 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
       job(n + 2, treg[2 % DEPTH], SA, SB);
       job(n + 3, treg[3 % DEPTH], SB, SA);
     }
-  } else if (LATE) {
-    for (int n = 0; n < njobs; ++n) job(n, treg[0], SA, SA);
+  } else if (LATE && DEPTH == 1) {
+    for (int n = 0; n < njobs; ++n) job(n, treg[0], SA, SA);  // (not unrolled by two: the body's registers are the point of LATE)
   } else {
     for (int n = 0; n < njobs; n += 2) {  // njobs is even
       job(n, treg[0], SA, SB);
@@ -423,7 +461,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
   // ---- epilogue: loss partial of every member (into the member's own slot: members may belong to different time slices),
   // coefficient gradients of every member.  Lane (col, kq) holds its two members at its channel: sum over the 16 lanes of
   // the row, then over the four waves in order.
-  if (!(REG && GRAD)) {
+  if (!(REG == 1 && GRAD)) {
     constexpr int NQ = REG ? 3 : 1;  // loss (, S_r, S_i): s_red [quantity][4 waves][8 members]
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -437,7 +475,7 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
     }
   }
   __syncthreads();  // also: every wave has left its strip
-  if (!(REG && GRAD) && tid < NB) {
+  if (!(REG == 1 && GRAD) && tid < NB) {
     const size_t slot = (size_t)s_mem[tid].item * 4;
     A.part[slot + 0] = ((s_red[tid] + s_red[8 + tid]) + s_red[16 + tid]) + s_red[24 + tid];
     A.part[slot + 1] = REG ? ((s_red[32 + tid] + s_red[40 + tid]) + s_red[48 + tid]) + s_red[56 + tid] : 0.0;
@@ -448,16 +486,18 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
   // s_x[((w * NT + t) * 4 + r) * 64 + lane]
   T* s_x = s_strips;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  for (int set = 0; set < (R2 ? 2 : 1); ++set) {
+    if (set) __syncthreads();  // the sums of the first set have been read
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s_x[((wave * NT + t) * 4 + r) * 64 + lane] = dC[t][r];
-  }
-  __syncthreads();
-  // thread (column tid >> 4, vector-in-tile tid & 15) sums the four parts of one vector per tile
-  {
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_x[((wave * NT + t) * 4 + r) * 64 + lane] = set ? dC2[R2 ? t : 0][r] : dC[t][r];
+    }
+    __syncthreads();
+    // thread (column tid >> 4, vector-in-tile tid & 15) sums the four parts of one vector per tile
     const int j = tid >> 4, kk = tid & 15, m = j & 7;
     if (m < NB) {
-      T* gc = (j < 8 ? A.gcp0_r : A.gcp0_i) + s_mem[m].goff;
+      T* gc = (set ? (j < 8 ? A.gcp1_r : A.gcp1_i) : (j < 8 ? A.gcp0_r : A.gcp0_i)) + s_mem[m].goff;
       const int src_lane = F64 ? j + 16 * (kk & 3) : j + 16 * (kk >> 2);  // kk = row_of(kq, r)
       const int r = F64 ? kk >> 2 : kk & 3;
       for (int t = 0; t < NT; ++t) {
@@ -470,8 +510,8 @@ __device__ __forceinline__ void multi_mfma_item(const FusedArgs<T>& A, const Ite
   }
 }
 
-template <typename T, int MODE, bool REG>
-__global__ __launch_bounds__(kThreads, MmT<T>::kWgPerCu) void fused_multi_mfma_kernel(const FusedArgs<T> A) {
+template <typename T, int MODE, int REG>
+__global__ __launch_bounds__(kThreads, (REG == 2 ? 1 : MmT<T>::kWgPerCu)) void fused_multi_mfma_kernel(const FusedArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int item_idx = A.heads[blockIdx.x];
   if (item_idx < 0) return;  // an empty slot of the XCD-affine head list
@@ -480,23 +520,26 @@ __global__ __launch_bounds__(kThreads, MmT<T>::kWgPerCu) void fused_multi_mfma_k
   if (A.nslices == 1 && (A.state->done | A.state->done_after)) return;
   // the ring of tile registers is 4 jobs deep up to 48 vectors, 2 up to 112, else 1: 28 to 56 loads (7 to 14 KB; double: 14 to 28) in flight per wave
   const bool quad = ((A.fpad >> 6) & 3) == 0;  // a wave's jobs come in fours
+  constexpr bool kWide = !(REG == 2 && sizeof(T) == 8);  // classes 11 .. 14 exist (the host: kMmMaxVecOnePass)
+#define MM_CLASS(NT_, D_) multi_mfma_item<T, MODE, NT_, D_, REG>(A, it, item_idx, smem)
   switch ((it.nvec + 15) >> 4) {  // wave-uniform
-    case 1: if (quad) multi_mfma_item<T, MODE, 1, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<T, MODE, 1, 2, REG>(A, it, item_idx, smem); break;
-    case 2: if (quad) multi_mfma_item<T, MODE, 2, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<T, MODE, 2, 2, REG>(A, it, item_idx, smem); break;
-    case 3: if (quad) multi_mfma_item<T, MODE, 3, 4, REG>(A, it, item_idx, smem); else multi_mfma_item<T, MODE, 3, 2, REG>(A, it, item_idx, smem); break;
-    case 4: multi_mfma_item<T, MODE, 4, 2, REG>(A, it, item_idx, smem); break;
-    case 5: multi_mfma_item<T, MODE, 5, 2, REG>(A, it, item_idx, smem); break;
-    case 6: multi_mfma_item<T, MODE, 6, 2, REG>(A, it, item_idx, smem); break;
-    case 7: multi_mfma_item<T, MODE, 7, 2, REG>(A, it, item_idx, smem); break;
-    case 8: multi_mfma_item<T, MODE, 8, 1, REG>(A, it, item_idx, smem); break;
-    case 9: multi_mfma_item<T, MODE, 9, 1, REG>(A, it, item_idx, smem); break;
-    case 10: multi_mfma_item<T, MODE, 10, 1, REG>(A, it, item_idx, smem); break;
-    case 11: multi_mfma_item<T, MODE, 11, 1, REG>(A, it, item_idx, smem); break;
-    case 12: multi_mfma_item<T, MODE, 12, 1, REG>(A, it, item_idx, smem); break;
-    case 13: multi_mfma_item<T, MODE, 13, 1, REG>(A, it, item_idx, smem); break;
-    case 14: multi_mfma_item<T, MODE, 14, 1, REG>(A, it, item_idx, smem); break;
+    case 1: if (quad) MM_CLASS(1, 4); else MM_CLASS(1, 2); break;
+    case 2: if (quad) MM_CLASS(2, 4); else MM_CLASS(2, 2); break;
+    case 3: if (quad) MM_CLASS(3, 4); else MM_CLASS(3, 2); break;
+    case 4: MM_CLASS(4, 2); break;
+    case 5: MM_CLASS(5, 2); break;
+    case 6: MM_CLASS(6, 2); break;
+    case 7: MM_CLASS(7, 2); break;
+    case 8: MM_CLASS(8, 1); break;
+    case 9: MM_CLASS(9, 1); break;
+    case 10: MM_CLASS(10, 1); break;
+    case 11: if constexpr (kWide) MM_CLASS(11, 1); break;
+    case 12: if constexpr (kWide) MM_CLASS(12, 1); break;
+    case 13: if constexpr (kWide) MM_CLASS(13, 1); break;
+    case 14: if constexpr (kWide) MM_CLASS(14, 1); break;
     default: break;  // the host gives this kernel no wider block
   }
+#undef MM_CLASS
 }
 static_assert(kMmTiles == 14, "the dispatch above lists 14 classes");
 

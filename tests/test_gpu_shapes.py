@@ -216,26 +216,51 @@ def test_time_slices_that_share_tiles(nslices):
         assert outs[0][3] < outs[1][3]  # one tile copy per baseline instead of one per (slice, baseline)
 
 
-def test_slices_share_tiles_on_a_band_of_six_strips_per_wave():
-    """300 channels pad to 384 = six 16-channel strips per wave: not a multiple of four, so the blocks of at most 48 vectors run
+@pytest.mark.parametrize("nfreqs,nvecs", [(300, [4, 16, 17, 33, 48, 49, 64, 80, 96, 112, 113, 128, 144, 160, 176, 192, 193, 208, 224]),
+                                          (200, [3, 20, 40, 56, 57, 100, 112, 113, 129, 145, 160])])
+def test_slices_share_tiles_band_shapes_and_the_one_pass_regulariser(nfreqs, nvecs):
+    """(a) 300 channels pad to 384 = six 16-channel strips per wave: not a multiple of four, so the blocks of at most 48 vectors run
     fused_multi_mfma_kernel's two-deep ring instead of the four-deep one (every other test here, and HERA-350's 1024 channels,
-    take the four-deep form); every class of both precisions, members 8 + 3 (float32 and float64: 16 MFMA columns in both), loss
-    and gradients against the C restatement of the batched problem, with and without the regulariser."""
+    take the four-deep form); every class of both precisions, members 8 + 3 (16 MFMA columns in float32 and float64).
+    (b) Every head on the matrix-core kernel (no block wider than 224 vectors; float64: 160): the regularised gradient pass is ONE
+    pass with two adjoint sets (REG == 2: S, q1, the second coefficient gradients, folded by the combine kernels / the one-launch
+    tail) -- float32 in both cases, float64 in the second; the first case in float64 keeps the two passes.
+    Loss and gradients against the C restatement of the batched problem, with and without the regulariser, and a regularised Adam
+    trajectory against the same problem without the alias table (every baseline streams its own tiles through fused_basis_kernel)."""
     from calamity_amd import distributed as D
+    from calamity_amd.solver import HipFitSolver
 
-    nvecs = [4, 16, 17, 33, 48, 49, 64, 80, 96, 112, 113, 128, 144, 160, 176, 192, 193, 208, 224]
-    base, _ = random_problem(nvecs, [1] * len(nvecs), nants=7, nfreqs=300, seed=90)
+    nsl = 11
+    base, _ = random_problem(nvecs, [1] * len(nvecs), nants=7, nfreqs=nfreqs, seed=90)
     parts = []
-    for t in range(11):
-        p, st = random_problem(nvecs, [1] * len(nvecs), nants=7, nfreqs=300, seed=91 + t)
+    for t in range(nsl):
+        p, st = random_problem(nvecs, [1] * len(nvecs), nants=7, nfreqs=nfreqs, seed=91 + t)
         p.basis, p.grp_basis = base.basis, base.grp_basis
         p.bl_ant0, p.bl_ant1, p.bl_rowblk = base.bl_ant0, base.bl_ant1, base.bl_rowblk
-        p.wgts = p.wgts / 11
+        p.wgts = p.wgts / nsl
         parts.append((p, st))
     prob, start = D.batch_time_slices(parts)
     assert prob.bl_alias is not None
     prob.sky_r, prob.sky_i = np.concatenate([p.sky_r for p, _ in parts]), np.concatenate([p.sky_i for p, _ in parts])
     check(prob, start, layouts=("stream",))
+    plain = D.batch_time_slices(parts)[0]
+    plain.bl_alias = None
+    pri = float(np.sum(prob.sky_r * prob.wgts)), float(np.sum(prob.sky_i * prob.wgts))
+    for dtype in (np.float64, np.float32):
+        outs = []
+        for pr in (prob, plain):
+            s = HipFitSolver(dtype=dtype)
+            s.set_problem(pr, layout="stream")
+            s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+            s.set_regularization("sum", *pri)
+            s.set_optimizer("Adam", learning_rate=1e-2)
+            losses, _, _ = s.run(6, record=True, tol=0.0)
+            outs.append((losses, s.get_params()))
+            s.close()
+        tol = 1e-11 if dtype == np.float64 else 2e-5
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=tol)
+        for x, y in zip(outs[0][1], outs[1][1]):
+            assert np.linalg.norm(np.asarray(x, np.float64) - y) <= 10 * tol * np.linalg.norm(y)
 
 
 def test_slices_that_share_only_some_tiles():
