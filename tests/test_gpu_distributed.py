@@ -125,6 +125,17 @@ def test_two_self_launched_ranks_share_the_gpu_over_host_sockets():
     a = np.asarray(two["extra"]["losses"])
     assert a.shape == b.shape == (STEPS,) and a[-1] < a[0]
     np.testing.assert_allclose(a, b, rtol=2e-5)
+    # the same two ranks started the way the driver starts them: the torch launcher, whose own store listens on --master-port (the
+    # ranks' socket rendezvous must not need that port: calamity_amd/rendezvous.py)
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host"] + common,
+                              cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert launched.returncode == 0, launched.stdout[-2000:] + "\n" + launched.stderr[-4000:]
+    lines = [ln for ln in launched.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, launched.stdout[-2000:]
+    under = json.loads(lines[0])
+    assert under["n_gpus"] == 2 and under["n_ranks_seen"] == 2
+    np.testing.assert_allclose(np.asarray(under["extra"]["losses"]), b, rtol=2e-5)
     # a node with fewer GPUs than ranks is an error on every rank under the default transport -- never a one-GPU measurement
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     from calamity_amd import _lib

@@ -41,6 +41,66 @@ def test_three_ranks_meet_over_sockets(tmp_path):
         assert p.returncode == 0 and f"ok {r}" in out, err[-2000:]
 
 
+LAUNCHED = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from calamity_amd.rendezvous import SocketGroup
+g = SocketGroup()  # RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT of the launcher
+r, world = g.rank, g.world
+assert g.broadcast(b"id" * 64 if r == 0 else None, src=0) == b"id" * 64
+assert float(g.all_reduce([r + 1.0], "sum")[0]) == world * (world + 1) / 2
+g.barrier()
+g.close()
+print("ok", r, flush=True)
+"""
+
+
+def test_ranks_meet_under_the_torch_launcher_which_keeps_master_port_for_its_own_store(tmp_path):
+    """The driver starts bench.py as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py ...`: that launcher's store LISTENS on P, so rank 0 cannot bind it (round 5's first socket rendezvous
+    did, and every N > 1 run under the launcher died with EADDRINUSE).  Three ranks under the real launcher: rank 0 takes another
+    port and publishes it, the others find it."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "launched.py"
+    script.write_text(LAUNCHED.format(root=ROOT))
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert all(f"ok {r}" in res.stdout for r in range(3)), res.stdout[-2000:]
+
+
+def test_a_stale_port_file_of_an_earlier_job_is_ignored(tmp_path):
+    """Rank 0 of an earlier job died before it could remove its file: the file names a dead port.  The next job on the same
+    MASTER_PORT still meets (the later ranks' connection fails, they read the file again once rank 0 has rewritten it)."""
+    import socket
+
+    from calamity_amd import rendezvous
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    with socket.socket() as dead:
+        dead.bind(("127.0.0.1", 0))
+        stale = dead.getsockname()[1]
+    with open(rendezvous._port_file(port), "w") as f:
+        f.write(f"{stale}\n")
+    script = tmp_path / "rank.py"
+    script.write_text(RANK.format(root=ROOT))
+    late = subprocess.Popen([sys.executable, str(script), "1", "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    import time
+
+    time.sleep(1.0)  # rank 1 is already polling the stale file
+    first = subprocess.Popen([sys.executable, str(script), "0", "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    for r, p in ((1, late), (0, first)):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and f"ok {r}" in out, err[-2000:]
+
+
 def test_a_group_of_one_needs_no_socket():
     sys.path.insert(0, ROOT)
     import numpy as np
