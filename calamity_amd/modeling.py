@@ -177,13 +177,26 @@ def clear_dpss_block_cache():
         _BLOCKS.clear()
 
 
+def _block_key(delay_ns, freqs, eigenval_cutoff):
+    return ("bl_grp", delay_ns / 1e9, len(freqs), float(freqs[0]), float(freqs[-1]), eigenval_cutoff)
+
+
+def _cached_block(delay_ns, freqs, eigenval_cutoff):
+    """The block of this delay if an earlier call left it in the module's cache, else None."""
+    with _BLOCKS_LOCK:
+        blk = _BLOCKS.get(_block_key(delay_ns, freqs, eigenval_cutoff))
+        if blk is not None:
+            _BLOCKS.move_to_end(_block_key(delay_ns, freqs, eigenval_cutoff))
+    return blk
+
+
 def _dpss_block(delay_ns, freqs, eigenval_cutoff, operator_cache=None):
     """The real DPSS block of one delay half width (ns), cached by delay: modeling.py:291-301 -- within the call through
     ``operator_cache`` (baselines of one delay share ONE ndarray), across calls through the module's bounded cache."""
     if operator_cache is None:
         operator_cache = {}
     dly = delay_ns / 1e9
-    key = ("bl_grp", dly, len(freqs), float(freqs[0]), float(freqs[-1]), eigenval_cutoff)
+    key = _block_key(delay_ns, freqs, eigenval_cutoff)
     if key not in operator_cache:
         with _BLOCKS_LOCK:
             blk = _BLOCKS.get(key)
@@ -221,7 +234,8 @@ def get_redundant_grps_data(uvdata, remove_redundancy=False, tol=1.0, include_au
         present.add((j, i))
     out_grps, out_centres, out_lengths = [], [], []
     for bls, centre, length in zip(groups, centres, lengths):
-        kept = [ap for ap in (tuple(uvdata.baseline_to_antnums(bl)) for bl in bls) if ap in present]
+        a1, a2 = uvdata.baseline_to_antnums(np.asarray(bls))  # (one call per redundant set, not per baseline)
+        kept = [ap for ap in zip(np.atleast_1d(a1).tolist(), np.atleast_1d(a2).tolist()) if ap in present]
         for members in ([[ap] for ap in kept] if remove_redundancy else [kept] if kept else []):
             out_grps.append(members)
             out_centres.append(centre)
@@ -253,21 +267,24 @@ def yield_pbl_dpss_model_comps(
     freqs = _freqs_of(uvdata)
     echo(f"{datetime.datetime.now()} Computing DPSS modeling vectors...\n", verbose=verbose)
     lengths = np.linalg.norm(np.asarray(centres, dtype=np.float64).reshape(len(red_grps), -1), axis=1) if len(red_grps) else np.zeros(0)
-    delays = [dly_ns(float(bllen), horizon=horizon, min_dly=min_dly, offset=offset) for bllen in lengths]
+    # dly_ns (modeling.py:293) on the whole array of lengths: ceil(max(min_dly, length / 0.3 * horizon + offset))
+    delays = np.ceil(np.maximum(min_dly, lengths / 0.3 * horizon + offset)).tolist()
     distinct = sorted(set(delays))
-    cache = {}
 
     def block_of(dly):
         # a private operator cache per task: the shared dict is only written from this thread, below
         return _dpss_block(dly, freqs, eigenval_cutoff, {})
 
-    workers = max(1, min(len(distinct), usable_cores()))
+    # blocks an earlier call of the process left in the module's cache need no thread pool (a second HERA-350 call: all 122)
+    cache = {d: blk for d in distinct for blk in [_cached_block(d, freqs, eigenval_cutoff)] if blk is not None}
+    todo = [d for d in distinct if d not in cache]
+    workers = max(1, min(len(todo), usable_cores()))
     if workers > 1:
         with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
-            blocks = list(PBARS[notebook_progressbar](pool.map(block_of, distinct), total=len(distinct), disable=not verbose))
+            blocks = list(PBARS[notebook_progressbar](pool.map(block_of, todo), total=len(todo), disable=not verbose))
     else:
-        blocks = [block_of(d) for d in PBARS[notebook_progressbar](distinct, disable=not verbose)]
-    cache.update(zip(distinct, blocks))
+        blocks = [block_of(d) for d in PBARS[notebook_progressbar](todo, disable=not verbose)]
+    cache.update(zip(todo, blocks))
     return {(tuple(grp),): cache[dly] for grp, dly in zip(red_grps, delays)}
 
 

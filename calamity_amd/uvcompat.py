@@ -55,8 +55,12 @@ def antnums_to_baseline(a1, a2):
 
 
 def baseline_to_antnums(bl):
-    bl = int(bl) - 2 ** 16
-    return (bl // 2048 - 1, bl % 2048 - 1)
+    """One baseline number -> (ant1, ant2) ints; an array of them -> two arrays (as pyuvdata's method does)."""
+    if np.ndim(bl) == 0:
+        bl = int(bl) - 2 ** 16
+        return (bl // 2048 - 1, bl % 2048 - 1)
+    bl = np.asarray(bl, dtype=np.int64) - 2 ** 16
+    return bl // 2048 - 1, bl % 2048 - 1
 
 
 def _copy_array(a):
