@@ -13,7 +13,7 @@ CAL_F32, CAL_F64 = 0, 1
 CAL_OPT_ADAM, CAL_OPT_ADAMAX, CAL_OPT_SGD, CAL_OPT_RMSPROP, CAL_OPT_ADAGRAD, CAL_OPT_NADAM, CAL_OPT_ADADELTA, CAL_OPT_FTRL, CAL_OPT_LAMB = range(9)
 CAL_REG_NONE, CAL_REG_SUM = 0, 1
 CAL_LAYOUT_STREAM, CAL_LAYOUT_SHARED = 0, 1
-CAL_PATH_AUTO, CAL_PATH_GENERAL, CAL_PATH_DENSE, CAL_PATH_DENSE_F32 = 0, 1, 2, 3
+CAL_PATH_AUTO, CAL_PATH_GENERAL, CAL_PATH_DENSE, CAL_PATH_DENSE_F32, CAL_PATH_DENSE_SPLIT1 = 0, 1, 2, 3, 4
 CAL_LAUNCH_AUTO, CAL_LAUNCH_KERNELS, CAL_LAUNCH_ONE_TAIL, CAL_LAUNCH_GRAPH = 0, 1, 2, 3
 CAL_COMM_ID_BYTES = 128
 CAL_MAX_SLICES = 256

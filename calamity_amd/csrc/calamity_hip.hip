@@ -20,6 +20,7 @@
 #include "fit_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "split_kernels.hpp"
+#include "split2_kernels.hpp"
 #include "dense64_kernels.hpp"
 #include "multi_mfma_kernels.hpp"
 #include <cstdlib>
@@ -222,6 +223,7 @@ struct SolverT final : cal_solver {
   // dense (MFMA) path of the SHARED layout, fp32, one baseline per fitting group
   DevBuf mf_ops, mf_panels;                    // mf_ops: every basis block's packed MFMA operands (see mfma_pack_kernel / mfma_pack64_kernel)
   int mf_npanels = 0;
+  bool mf_split2 = false;                      // ... in its one-image form (split2_kernels.hpp)
   bool mf_split = false;                       // fp32: the split-bf16 kernel (split_kernels.hpp: super-panels of 4 panels) instead of fused_dense_kernel
   DevBuf mf_map;                               // [mf_grid] workgroup -> panel (-1: empty slot): XCD-affine dispatch of the dense launch
   int mf_grid = 0;
@@ -448,11 +450,14 @@ struct SolverT final : cal_solver {
     while (pw < 128 && pw < nfreqs) pw *= 2;
     if (fb_used_max > pw) return fail(CAL_ERR_INVALID, "set_problem: internal error: tile width %d exceeds the row padding %d", fb_used_max, pw);
     fpad = (nfreqs + pw - 1) / pw * pw;
-    if (d->kernel_path != CAL_PATH_AUTO && d->kernel_path != CAL_PATH_GENERAL && d->kernel_path != CAL_PATH_DENSE && d->kernel_path != CAL_PATH_DENSE_F32)
+    if (d->kernel_path != CAL_PATH_AUTO && d->kernel_path != CAL_PATH_GENERAL && d->kernel_path != CAL_PATH_DENSE && d->kernel_path != CAL_PATH_DENSE_F32 &&
+        d->kernel_path != CAL_PATH_DENSE_SPLIT1)
       return fail(CAL_ERR_INVALID, "set_problem: bad kernel_path %d", d->kernel_path);
     if (d->kernel_path == CAL_PATH_DENSE_F32 && !std::is_same<T, float>::value)
       return fail(CAL_ERR_UNSUPPORTED, "set_problem: CAL_PATH_DENSE_F32 is the fp32 kernel on v_mfma_f32_32x32x2_f32; this solver is fp64");
-    const bool forced_dense = d->kernel_path == CAL_PATH_DENSE || d->kernel_path == CAL_PATH_DENSE_F32;
+    if (d->kernel_path == CAL_PATH_DENSE_SPLIT1 && !std::is_same<T, float>::value)
+      return fail(CAL_ERR_UNSUPPORTED, "set_problem: CAL_PATH_DENSE_SPLIT1 is an fp32 kernel (split-bf16 operands); this solver is fp64");
+    const bool forced_dense = d->kernel_path == CAL_PATH_DENSE || d->kernel_path == CAL_PATH_DENSE_F32 || d->kernel_path == CAL_PATH_DENSE_SPLIT1;
     bool want_split = std::is_same<T, float>::value && d->kernel_path != CAL_PATH_DENSE_F32;
     for (int u = 0; u < nbasis && want_split; ++u) want_split = d->basis_nvec[u] <= kSplitMaxNvec;  // (wider blocks: the f32 kernel, up to 256 vectors)
     // dense (matrix-core) path: eligibility, then -- for CAL_PATH_AUTO -- whether the problem fills the chip
@@ -464,7 +469,7 @@ struct SolverT final : cal_solver {
     // ... and its packed operands (two MFMA-native copies of every unique block) with 32-bit byte offsets from one base
     long long dense_op_elems = 0;
     for (int u = 0; u < nbasis && dense_ok; ++u)  // kilobyte positions: forward + adjoint (the same count for both dtypes' layouts up to padding)
-      dense_op_elems += want_split ? split_stream_bytes(fpad, d->basis_nvec[u], (d->basis_nvec[u] + 31) / 32) / 4
+      dense_op_elems += want_split ? std::max(split_stream_bytes(fpad, d->basis_nvec[u], (d->basis_nvec[u] + 31) / 32), split2_stream_bytes(fpad, d->basis_nvec[u])) / 4
                         : std::is_same<T, float>::value
                             ? (long long)(fpad / 32) * ((d->basis_nvec[u] + 7) / 8) * 256 + (long long)(fpad / 32) * ((d->basis_nvec[u] + 31) / 32) * 4 * 256
                             : (long long)(fpad / 16) * ((d->basis_nvec[u] + 7) / 8) * 128 + (long long)(fpad / 16) * ((d->basis_nvec[u] + 15) / 16) * 2 * 128;
@@ -646,6 +651,7 @@ struct SolverT final : cal_solver {
     }
     mf_ok = false;
     mf_split = false;
+    mf_split2 = false;
     if (want_mfma && want_split) {
       if constexpr (std::is_same<T, float>::value) {
         // ---- fp32, split-bf16 operands (split_kernels.hpp): super-panels of kSpWaves panels (64 baselines) with the same basis block and slice;
@@ -654,20 +660,26 @@ struct SolverT final : cal_solver {
         struct Half { int tile0, ntiles; long long obyte; };
         std::vector<std::vector<Half>> halves(nbasis);
         long long obytes = 0;
+        const bool v2 = d->kernel_path != CAL_PATH_DENSE_SPLIT1;  // the one-image form (split2_kernels.hpp) unless the first one is asked for by name
         for (int u = 0; u < nbasis; ++u) {
           const int ntu = (d->basis_nvec[u] + 31) / 32;
           halves[u] = {Half{0, ntu, 0}};  // (kSplitNT = 8 tiles fit one item since the kernel runs one workgroup per CU)
           for (Half& h : halves[u]) {
             h.obyte = obytes;
-            obytes += split_stream_bytes(fpad, d->basis_nvec[u], h.ntiles);
+            obytes += v2 ? split2_stream_bytes(fpad, d->basis_nvec[u]) : split_stream_bytes(fpad, d->basis_nvec[u], h.ntiles);
           }
         }
         CAL_TRY(mf_ops.alloc((size_t)obytes, false));
         for (int u = 0; u < nbasis; ++u)
-          for (const Half& h : halves[u])
-            hipLaunchKernelGGL(split_pack_kernel, dim3(grid_for(split_stream_bytes(fpad, d->basis_nvec[u], h.ntiles) / 6)), dim3(256), 0, stream,
-                               raw.as<float>() + d->basis_offset[u], reinterpret_cast<unsigned short*>(mf_ops.as<unsigned char>() + h.obyte), nfreqs, fpad,
-                               d->basis_nvec[u], h.tile0, h.ntiles);
+          for (const Half& h : halves[u]) {
+            if (v2)
+              hipLaunchKernelGGL(split2_pack_kernel, dim3(grid_for((long long)fpad * 256)), dim3(256), 0, stream, raw.as<float>() + d->basis_offset[u],
+                                 mf_ops.as<unsigned char>() + h.obyte, nfreqs, fpad, d->basis_nvec[u]);
+            else
+              hipLaunchKernelGGL(split_pack_kernel, dim3(grid_for(split_stream_bytes(fpad, d->basis_nvec[u], h.ntiles) / 6)), dim3(256), 0, stream,
+                                 raw.as<float>() + d->basis_offset[u], reinterpret_cast<unsigned short*>(mf_ops.as<unsigned char>() + h.obyte), nfreqs, fpad,
+                                 d->basis_nvec[u], h.tile0, h.ntiles);
+          }
         HIP_TRY(hipGetLastError());
         std::vector<std::vector<int>> by_u((size_t)nbasis * nslices);
         for (int b = 0; b < nbls; ++b) by_u[(size_t)d->grp_basis[grp_of_bl[b]] * nslices + grp_slice[grp_of_bl[b]]].push_back(b);
@@ -706,11 +718,17 @@ struct SolverT final : cal_solver {
           }
         }
         CAL_TRY(order_panels(h_panels, h_cost, kSpWaves));
-        mf_lds_grad[0] = mf_lds_loss[0] = split_lds_bytes();
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
+        mf_lds_grad[0] = mf_lds_loss[0] = v2 ? (size_t)kS2Lds : split_lds_bytes();
+        if (v2) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
+        } else {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_grad[0]));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dense_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_loss[0]));
+        }
         mf_ok = true;
         mf_split = true;
+        mf_split2 = v2;
       }
     } else if (want_mfma) {
       if constexpr (std::is_same<T, float>::value) {
@@ -1571,7 +1589,8 @@ struct SolverT final : cal_solver {
   template <bool GRAD> void launch_dense(MfmaArgs m) {
     m.slot_map = mf_map.as<int>();
     if (mf_split) {
-      hipLaunchKernelGGL((fused_dense_split_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
+      if (mf_split2) hipLaunchKernelGGL((fused_dense_split2_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
+      else hipLaunchKernelGGL((fused_dense_split_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
       return;
     }
     hipLaunchKernelGGL((fused_dense_kernel<GRAD>), dim3(mf_grid), dim3(kDenseThreads), (GRAD ? mf_lds_grad : mf_lds_loss)[0], stream, m);
@@ -2114,7 +2133,7 @@ struct SolverT final : cal_solver {
     // forward A c and adjoint A^T gbar_v, complex x real: 4 + 4 flops per (channel, vector); the dense path's regularised step
     // runs the forward twice (loss-only pass for S, then the gradient pass) inside the timed region
     out->flops_per_launch = ((mf_ok && reg == CAL_REG_SUM) ? 12.0 : 8.0) * nfreqs * (double)ncoef;
-    out->kernel_path = mf_ok ? ((mf_split || !std::is_same<T, float>::value) ? CAL_PATH_DENSE : CAL_PATH_DENSE_F32) : CAL_PATH_GENERAL;
+    out->kernel_path = mf_ok ? ((mf_split || !std::is_same<T, float>::value) ? (mf_split && !mf_split2 ? CAL_PATH_DENSE_SPLIT1 : CAL_PATH_DENSE) : CAL_PATH_DENSE_F32) : CAL_PATH_GENERAL;
     // the dense kernels are written for two workgroups per CU (160 KB of LDS): a basis block of ~250 vectors needs more than
     // 80 KB for its coefficient panel + rings and runs one
     out->dense_wg_per_cu = mf_ok ? (mf_lds_grad[0] * 2 <= 160 * 1024 ? 2 : 1) : 0;

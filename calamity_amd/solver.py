@@ -93,7 +93,7 @@ class HipFitSolver:
             bl_rowblk=_ptr(keep[8]), bl_alias=_ptr(keep[9]), nslices=int(getattr(prob, "nslices", 1) or 1), grp_var=_ptr(keep[10]),
             layout={"stream": _lib.CAL_LAYOUT_STREAM, "shared": _lib.CAL_LAYOUT_SHARED}[layout],
             kernel_path={"auto": _lib.CAL_PATH_AUTO, "general": _lib.CAL_PATH_GENERAL, "dense": _lib.CAL_PATH_DENSE,
-                         "dense_f32": _lib.CAL_PATH_DENSE_F32}[kernel_path],
+                         "dense_f32": _lib.CAL_PATH_DENSE_F32, "dense_split1": _lib.CAL_PATH_DENSE_SPLIT1}[kernel_path],
         )
         _lib.check(self._lib.cal_solver_set_problem(self._h, C.byref(d)))
         self.problem = prob
@@ -237,7 +237,7 @@ class HipFitSolver:
         _lib.check(self._lib.cal_solver_timing_get(self._h, C.byref(t)))
         return dict(launches=t.launches, total_ms=t.total_ms, algorithmic_bytes_per_launch=t.algorithmic_bytes_per_launch,
                     basis_bytes_per_launch=t.basis_bytes_per_launch, flops_per_launch=t.flops_per_launch,
-                    kernel_path={_lib.CAL_PATH_GENERAL: "general", _lib.CAL_PATH_DENSE: "dense", _lib.CAL_PATH_DENSE_F32: "dense_f32"}[t.kernel_path],
+                    kernel_path={_lib.CAL_PATH_GENERAL: "general", _lib.CAL_PATH_DENSE: "dense", _lib.CAL_PATH_DENSE_F32: "dense_f32", _lib.CAL_PATH_DENSE_SPLIT1: "dense_split1"}[t.kernel_path],
                     dense_wg_per_cu=t.dense_wg_per_cu)
 
     def memory_bytes(self):

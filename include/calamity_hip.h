@@ -57,9 +57,12 @@ enum cal_kernel_path {
   CAL_PATH_DENSE = 2,   /* matrix-core kernel wherever the problem is eligible (SHARED layout, one baseline per fitting
                            group, basis_nvec <= 256, nfreqs > 64); CAL_ERR_UNSUPPORTED when it is not.  fp32: the split-bf16
                            kernel (six v_mfma_f32_32x32x16_bf16 per fp32 product block, four panels of a workgroup on one
-                           operand ring); fp64: v_mfma_f64_16x16x4_f64 */
-  CAL_PATH_DENSE_F32 = 3 /* fp32 only: the dense kernel on v_mfma_f32_32x32x2_f32 (one panel per workgroup) that CAL_PATH_DENSE
+                           operand image per unit of channels, read row-wise by the forward and transposed by the adjoint
+                           product); fp64: v_mfma_f64_16x16x4_f64 */
+  CAL_PATH_DENSE_F32 = 3, /* fp32 only: the dense kernel on v_mfma_f32_32x32x2_f32 (one panel per workgroup) that CAL_PATH_DENSE
                             ran before the split-bf16 kernel replaced it; kept for A/B measurements and as the accuracy yardstick */
+  CAL_PATH_DENSE_SPLIT1 = 4 /* fp32 only: the first split-bf16 kernel (two packed operand streams through an LDS ring, coefficient
+                            panels in LDS), which CAL_PATH_DENSE ran until the one-image form replaced it; kept for A/B measurements */
 };
 
 enum cal_launch_mode {

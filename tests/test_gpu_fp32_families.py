@@ -4,6 +4,8 @@ section 8(d)'s tolerances (loss 1e-5, gradients 1e-4 relative) -- VERDICT round 
   * streaming kernel (per-baseline tiles, `fused_basis_kernel`)            layout "stream", kernel_path "general"
   * the same kernel on cache-resident shared tiles                          layout "shared", kernel_path "general"
   * split-bf16 dense kernel (six v_mfma_f32_32x32x16_bf16 per product)       layout "shared", kernel_path "dense"
+    (one operand image per unit of channels, read row-wise and transposed: split2_kernels.hpp)
+  * the first split-bf16 kernel (two packed streams: split_kernels.hpp)      layout "shared", kernel_path "dense_split1"
   * fp32 dense kernel it replaced (v_mfma_f32_32x32x2_f32)                   layout "shared", kernel_path "dense_f32"
 each with and without the "sum" regulariser (two passes on the dense kernels, two adjoint sets on the streaming kernel).  The
 multi-slice kernels (time slices that share tiles) are measured in tests/test_gpu_config3.py on the per-rank workload they run.
@@ -22,7 +24,7 @@ from calamity_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 
-FAMILIES = [("stream", "general"), ("shared", "general"), ("shared", "dense"), ("shared", "dense_f32")]
+FAMILIES = [("stream", "general"), ("shared", "general"), ("shared", "dense"), ("shared", "dense_split1"), ("shared", "dense_f32")]
 TOL_LOSS, TOL_GRAD = 1e-5, 1e-4
 
 

@@ -100,7 +100,7 @@ def test_short_trajectory(dtype, optimizer, reg):
     assert relnorm(c_i, problem.coeffs_from_chunks(p, out[3])) <= tol["traj"]
 
 
-@pytest.mark.parametrize("dtype,path", [(np.float32, "dense"), (np.float32, "dense_f32"), (np.float64, "dense")])
+@pytest.mark.parametrize("dtype,path", [(np.float32, "dense"), (np.float32, "dense_split1"), (np.float32, "dense_f32"), (np.float64, "dense")])
 @pytest.mark.parametrize("reg", [False, True])
 def test_short_trajectory_dense_path(reg, dtype, path):
     """SHARED layout + one baseline per group -> the dense (matrix-core) path, fp32 and fp64 (two passes per step with the
@@ -112,7 +112,7 @@ def test_short_trajectory_dense_path(reg, dtype, path):
         maxsteps=30, optimizer="Adam", learning_rate=1e-2, sky_model_r=ch["sky_model_r"], sky_model_i=ch["sky_model_i"],
         model_regularization="sum" if reg else None,
     )
-    s = make_solver(p, start, dtype, "shared", reg, kernel_path=path)  # fp32 "dense": the split-bf16 kernel, "dense_f32": the one it replaced
+    s = make_solver(p, start, dtype, "shared", reg, kernel_path=path)  # fp32 "dense": the split-bf16 kernel (one-image form), "dense_split1": its first form, "dense_f32": the fp32 MFMA kernel
     s.set_optimizer("Adam", learning_rate=1e-2)
     s.run(1, record=False)
     losses, stopped, nupd = s.run(30, record=True, tol=1e-14)

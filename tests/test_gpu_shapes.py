@@ -83,13 +83,17 @@ def test_dense_path_vector_counts():
         p.grp_basis[g] = first.setdefault(n, g)
     check(p, start, dtypes=(np.float32, np.float64), layouts=("shared",), kernel_path="dense")
     check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense_f32")
+    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense_split1")
 
 
-def test_split_bf16_dense_kernel_vector_counts():
-    """fp32, blocks of at most 224 vectors: the split-bf16 kernel (split_kernels.hpp: super-panels of 64 baselines, forward groups of two
-    16-vector steps, adjoint groups of two 32-vector tiles) across every group count, tail and tile parity, with panels that are
-    full, ragged and empty (a block with 70 baselines = one full panel of a super-panel and one of 6), with and without the
-    regulariser; and that the path asked for is the path that ran."""
+@pytest.mark.parametrize("path", ["dense", "dense_split1"])
+def test_split_bf16_dense_kernel_vector_counts(path):
+    """fp32, blocks of at most 224 vectors: the split-bf16 kernels -- "dense": split2_kernels.hpp (super-panels of 64 baselines, one operand
+    image per unit of 64 / 32 channels read row-wise and transposed, a body per number of 32-vector tiles, coefficients in registers);
+    "dense_split1": split_kernels.hpp (forward groups of two 16-vector steps, adjoint groups of two 32-vector tiles) -- across every
+    tile count, tail and parity, both image shapes (blocks up to and beyond 128 vectors), with panels that are full, ragged and empty (a
+    block with 70 baselines = one full panel of a super-panel and one of 6), with and without the regulariser; and that the path asked for
+    is the path that ran."""
     from calamity_amd.solver import HipFitSolver
 
     nvecs = [1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 48, 64, 65, 96, 100, 128, 129, 160, 161, 192, 193, 223, 224]
@@ -100,16 +104,16 @@ def test_split_bf16_dense_kernel_vector_counts():
     for g, n in enumerate(allv):
         p.grp_basis[g] = first.setdefault(n, g)
     s = HipFitSolver(dtype=np.float32)
-    s.set_problem(p, layout="shared", kernel_path="dense")
-    assert s.timing_get()["kernel_path"] == "dense"
+    s.set_problem(p, layout="shared", kernel_path=path)
+    assert s.timing_get()["kernel_path"] == path
     s.close()
-    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense")
+    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path=path)
     # a channel count that is not a multiple of the kernel's 64-channel pairs (zero-weight padding up to 128 k)
     p, start = random_problem([5, 40, 100] * 6, [1] * 18, nants=8, nfreqs=200, seed=6)
     first = {}
     for g, n in enumerate([5, 40, 100] * 6):
         p.grp_basis[g] = first.setdefault(n, g)
-    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense")
+    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path=path)
 
 
 def test_many_channels_few_groups_split_items():

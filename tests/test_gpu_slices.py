@@ -122,7 +122,7 @@ def test_slices_launch_forms(launch):
     _compare(parts, np.float32, "stream", "general", False, run_kw, 2e-3, launch=launch, learning_rate=1e-2)
 
 
-@pytest.mark.parametrize("dtype,path", [(np.float32, "dense"), (np.float32, "dense_f32"), (np.float64, "dense")])
+@pytest.mark.parametrize("dtype,path", [(np.float32, "dense"), (np.float32, "dense_split1"), (np.float32, "dense_f32"), (np.float64, "dense")])
 @pytest.mark.parametrize("reg", [False, True])
 def test_slices_dense_kernels(dtype, path, reg):
     """The matrix-core kernels (fp32: split-bf16 and the fp32 one it replaced; fp64): panels / super-panels never mix slices, the
