@@ -106,7 +106,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("fit_kernels.hpp", "dense_kernels.hpp", "split_kernels.hpp", "dense64_kernels.hpp", "multi_mfma_kernels.hpp", "calamity_hip.hip"):
+    for name in ("fit_kernels.hpp", "dense_kernels.hpp", "split_kernels.hpp", "split2_kernels.hpp", "dense64_kernels.hpp", "multi_mfma_kernels.hpp", "calamity_hip.hip"):
         with open(os.path.join(ROOT, "calamity_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -225,13 +225,14 @@ def dense_traffic(config, dtype):
 
 
 def split_issued_flops(prob):
-    """bf16 flops the split-bf16 dense kernel ISSUES per gradient launch (split_kernels.hpp): six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16
-    block of the fp32 product, blocks padded to 16 vectors (forward) / 32 vectors (adjoint), panels to 16 and super-panels to 64 baselines."""
+    """bf16 flops the split-bf16 dense kernel ISSUES per gradient launch (split2_kernels.hpp): six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16
+    block of the fp32 product, blocks padded to 32 vectors (forward and adjoint: the body is instantiated per number of 32-vector tiles),
+    panels to 16 and super-panels to 64 baselines."""
     nv = np.asarray([b.shape[1] for b in prob.basis])
     nbl = np.bincount(prob.grp_basis[np.repeat(np.arange(prob.ngrps), np.diff(prob.grp_bl_start))], minlength=len(nv))
     fpad = -(-prob.nfreqs // 128) * 128
     waves = -(-nbl // 64) * 4
-    mfma_per_wave = (fpad // 64) * (12 * -(-nv // 16) + 24 * -(-nv // 32))
+    mfma_per_wave = (fpad // 64) * (24 * -(-nv // 32) + 24 * -(-nv // 32))  # per pair of 32-channel blocks: 2 x (2 NT steps x 6) forward, 2 x (NT tiles x 2 steps x 6) adjoint
     return float(np.sum(waves * mfma_per_wave)) * 2.0 * 32 * 32 * 16
 
 
@@ -248,7 +249,7 @@ def dense_rooflines(prob, tim, kernel_ms, dtype, config=None):
     bytes_unique = tim["algorithmic_bytes_per_launch"] - tim["basis_bytes_per_launch"] + uniq_bytes
     gbs = bytes_unique / (kernel_ms * 1e-3) / 1e9
     out = {
-        "kernel": ("fused_dense_split_kernel<GRAD> (six v_mfma_f32_32x32x16_bf16 per fp32 product block: split-bf16 operands)" if split else
+        "kernel": ("fused_dense_split2_kernel<GRAD> (six v_mfma_f32_32x32x16_bf16 per fp32 product block: split-bf16 operands, one operand image read row-wise and transposed)" if split else
                    "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)") if f32 else "fused_dense64_kernel<GRAD> (v_mfma_f64_16x16x4_f64)",
         "kernel_ms": kernel_ms,
         # the USEFUL flops (8 F sum nvec: an fp32 product per (channel, vector, re | im), forward and adjoint) against the fp32 matrix peak:
@@ -544,23 +545,25 @@ def main():
         shared.update(steps_per_s=args.steps / dt2, ms_per_step=dt2 / args.steps * 1e3, device_memory_GB=s2.memory_bytes() / 1e9)
         s2.close()
         if dtype == np.float32 and tim2["kernel_path"] == "dense":
-            # the fp32 kernel the split-bf16 one replaced, on the same problem in the same run (kernel_path "dense_f32")
-            s2 = HipFitSolver(dtype=dtype, device=0)
-            s2.set_problem(prob, layout="shared", kernel_path="dense_f32")
-            s2.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
-            s2.set_optimizer(args.optimizer, learning_rate=1e-2)
-            s2.run(max(args.warmup, 1), record=False, tol=0.0)
-            s2.timing_enable(True)
-            s2.synchronize()
-            t2 = time.perf_counter()
-            s2.run(args.steps, record=True, tol=0.0)
-            s2.synchronize()
-            dt2 = time.perf_counter() - t2
-            tim2 = s2.timing_get()
-            k2 = tim2["total_ms"] / max(tim2["launches"], 1)
-            shared["previous_f32_kernel"] = {"kernel": "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)", "kernel_ms": k2, "steps_per_s": args.steps / dt2,
-                                             "ms_per_step": dt2 / args.steps * 1e3}
-            s2.close()
+            # the kernels this one replaced, on the same problem in the same run: the fp32 MFMA kernel (kernel_path "dense_f32") and the first
+            # split-bf16 kernel with its two packed operand streams ("dense_split1")
+            for path, key, label in (("dense_f32", "previous_f32_kernel", "fused_dense_kernel<GRAD> (v_mfma_f32_32x32x2_f32)"),
+                                     ("dense_split1", "first_split_kernel", "fused_dense_split_kernel<GRAD> (split-bf16, two packed operand streams through an LDS ring)")):
+                s2 = HipFitSolver(dtype=dtype, device=0)
+                s2.set_problem(prob, layout="shared", kernel_path=path)
+                s2.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
+                s2.set_optimizer(args.optimizer, learning_rate=1e-2)
+                s2.run(max(args.warmup, 1), record=False, tol=0.0)
+                s2.timing_enable(True)
+                s2.synchronize()
+                t2 = time.perf_counter()
+                s2.run(args.steps, record=True, tol=0.0)
+                s2.synchronize()
+                dt2 = time.perf_counter() - t2
+                tim2 = s2.timing_get()
+                k2 = tim2["total_ms"] / max(tim2["launches"], 1)
+                shared[key] = {"kernel": label, "kernel_ms": k2, "steps_per_s": args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
+                s2.close()
 
     # what EVERY RANK of the driver's `--gpus 8` run executes per step, without the exchange: 8 time slices x that rank's 1/8 of the
     # baselines, the slices sharing basis tiles (fused_multi_mfma_kernel).  All eight shares are built and timed here, one after the
