@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/prof_split.sh <tag>
-# Counters of the split-bf16 dense kernel (fused_dense_split_kernel) on the HERA-350 shared-layout workload, each group in its own
+# Counters of the split-bf16 dense kernel (fused_dense_split2_kernel) on the HERA-350 shared-layout workload, each group in its own
 # rocprofv3 pass (no trace domains beside --pmc), plus a kernel trace with --stats.  Everything under gpurun_out/<tag>/.
 tag=${1:-split}
 cd "${GRAFT_REPO_ROOT:?}"
@@ -26,7 +26,7 @@ import csv, glob, collections
 a = collections.defaultdict(list)
 for f in sorted(glob.glob("$out/pmc/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "fused_dense_split_kernel<true>" in r["Kernel_Name"].replace(" ", "") or "fused_dense_split_kernelILb1" in r["Kernel_Name"]:
+        if "fused_dense_split2_kernel<true>" in r["Kernel_Name"].replace(" ", "") or "fused_dense_split2_kernelILb1" in r["Kernel_Name"]:
             a[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in a.items():
     print(f"{k:34s} {sum(v) / len(v):16.0f}  ({len(v)} launches)")
