@@ -116,6 +116,25 @@ def test_split_bf16_dense_kernel_vector_counts(path):
     check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path=path)
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_split_bf16_dense_kernel_random_problems(seed):
+    """Seeded random problems for the fp32 dense kernel of the SHARED layout (split2_kernels.hpp): 12 basis blocks of random width (1 .. 224
+    vectors: every class of the kernel, both image shapes in one launch), random numbers of baselines per block (super-panels that are full,
+    ragged or a single baseline), a band that is or is not a multiple of the 64-channel unit -- loss and gradients against the C restatement,
+    with and without the regulariser."""
+    rng = np.random.default_rng(seed)
+    widths = [int(v) for v in rng.integers(1, 225, size=12)]
+    counts = [int(v) for v in rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 90], size=12)]
+    nfreqs = int(rng.choice([130, 200, 513, 1024]))
+    allv = [n for n, r in zip(widths, counts) for _ in range(r)]
+    p, start = random_problem(allv, [1] * len(allv), nants=30, nfreqs=nfreqs, seed=100 + seed)
+    pos = 0
+    for r in counts:  # the baselines of a drawn block share ONE basis block (equal widths drawn twice stay different blocks)
+        p.grp_basis[pos : pos + r] = pos
+        pos += r
+    check(p, start, dtypes=(np.float32,), layouts=("shared",), kernel_path="dense")
+
+
 def test_many_channels_few_groups_split_items():
     """Fewer groups than workgroup slots: items are split by tiles and their coefficient gradients summed afterwards."""
     p, start = random_problem([20, 90, 250], [2, 5, 3], nants=6, nfreqs=4096, seed=4)
