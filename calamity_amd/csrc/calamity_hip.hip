@@ -235,11 +235,11 @@ struct SolverT final : cal_solver {
   static constexpr int kGraphSteps = 16;       // even: the double-buffered loop state and gains end a replay where they began
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
-    int optimizer, freeze, reg, losses_cap, st_par;
+    int optimizer, freeze, reg, losses_cap, st_par, tail, nsteps;
     const void *gains, *snap, *losses;
     bool operator==(const GraphKey& o) const {
-      return optimizer == o.optimizer && freeze == o.freeze && reg == o.reg && losses_cap == o.losses_cap && st_par == o.st_par &&
-             gains == o.gains && snap == o.snap && losses == o.losses;
+      return optimizer == o.optimizer && freeze == o.freeze && reg == o.reg && losses_cap == o.losses_cap && st_par == o.st_par && tail == o.tail &&
+             nsteps == o.nsteps && gains == o.gains && snap == o.snap && losses == o.losses;
     }
   } graph_key{};
   DevBuf agree_buf;
@@ -1851,8 +1851,11 @@ struct SolverT final : cal_solver {
   // captured launches -- buffer pointers, optimizer, frozen model, regulariser, loss-history capacity, which halves of the
   // double-buffered state and gains are current -- is the key.  kGraphSteps is even, so a replay leaves both double buffers
   // where it found them and the same graph serves the next replay.
-  int replay_steps(bool freeze_model, int cap) {
-    const GraphKey key{opt.optimizer, freeze_model ? 1 : 0, reg, cap, st_par, gains.p, gains_snap.p, losses.p};
+  // `tail`: the two-launch form of small problems (fused pass + step_tail_kernel); else the kernels of a large problem's step (fused / dense
+  // pass(es), gain_grad_kernel, finalize_kernel, the update): a host whose cores are busy elsewhere then pays ONE launch per `nsteps` steps
+  // instead of four or five per step (measured on shared boxes: 2.4-3.2 ms per step of a 0.6-ms kernel while the host was contended).
+  int replay_steps(bool freeze_model, int cap, bool tail, int nsteps) {
+    const GraphKey key{opt.optimizer, freeze_model ? 1 : 0, reg, cap, st_par, tail ? 1 : 0, nsteps, gains.p, gains_snap.p, losses.p};
     if (!graph_exec || !(key == graph_key)) {
       drop_graph();
       hipGraph_t graph = nullptr;
@@ -1869,9 +1872,9 @@ struct SolverT final : cal_solver {
       };
       HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       int rc = CAL_OK;
-      for (int k = 0; k < kGraphSteps && rc == CAL_OK; ++k) {
-        rc = enqueue_pass(true, true, cap, true);
-        if (rc == CAL_OK) rc = enqueue_tail(freeze_model, cap);
+      for (int k = 0; k < nsteps && rc == CAL_OK; ++k) {
+        rc = enqueue_pass(true, true, cap, tail);
+        if (rc == CAL_OK) rc = tail ? enqueue_tail(freeze_model, cap) : enqueue_update(freeze_model, cap);
       }
       const hipError_t e = hipStreamEndCapture(stream, &graph);
       if (rc != CAL_OK) {
@@ -2010,7 +2013,9 @@ struct SolverT final : cal_solver {
     if (tail1 && !gains_alt.p) CAL_TRY(gains_alt.alloc(gains.bytes));
     // hipGraph replay of kGraphSteps train steps at a time: the steps of such problems are bound by launch latency.  Timed
     // runs (HIP events around every fused pass) issue their launches one by one.
-    const bool replay = tail1 && !timing && (launch_mode == CAL_LAUNCH_AUTO || launch_mode == CAL_LAUNCH_GRAPH);
+    // Large problems replay too unless the step holds an exchange (a collective or a host callback is not captured): see replay_steps.
+    const bool replay = (tail1 || !comm_on()) && !timing && (launch_mode == CAL_LAUNCH_AUTO || launch_mode == CAL_LAUNCH_GRAPH);
+    const int gsteps = tail1 ? kGraphSteps : std::min(kGraphSteps, chunk & ~1);  // even: the double-buffered loop state ends a replay where it began
     int issued = 0;
     while (issued < r->nsteps) {
       const int n = std::min(chunk, r->nsteps - issued);
@@ -2022,7 +2027,7 @@ struct SolverT final : cal_solver {
       }
       int s = 0;
       if (replay) {
-        for (; s + kGraphSteps <= n; s += kGraphSteps) CAL_TRY(replay_steps(r->freeze_model != 0, cap));
+        for (; gsteps >= 2 && s + gsteps <= n; s += gsteps) CAL_TRY(replay_steps(r->freeze_model != 0, cap, tail1, gsteps));
       }
       for (; s < n; ++s) {
         CAL_TRY(enqueue_pass(true, true, cap, tail1));
