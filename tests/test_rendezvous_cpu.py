@@ -52,7 +52,8 @@ assert g.broadcast(b"id" * 64 if r == 0 else None, src=0) == b"id" * 64
 assert float(g.all_reduce([r + 1.0], "sum")[0]) == world * (world + 1) / 2
 g.barrier()
 g.close()
-print("ok", r, flush=True)
+sys.stdout.write("rank-%d-ok\n" % r)  # (ONE write: the launcher's workers share its stdout, and print() of two arguments is several)
+sys.stdout.flush()
 """
 
 
@@ -71,7 +72,7 @@ def test_ranks_meet_under_the_torch_launcher_which_keeps_master_port_for_its_own
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
-    assert all(f"ok {r}" in res.stdout for r in range(3)), res.stdout[-2000:]
+    assert all(f"rank-{r}-ok" in res.stdout for r in range(3)), res.stdout[-2000:]
 
 
 def test_a_stale_port_file_of_an_earlier_job_is_ignored(tmp_path):
