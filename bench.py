@@ -501,7 +501,7 @@ def main():
     for s in solvers:
         s.timing_enable(not launch_bound)
     if launch_bound and not sharded and args.steps >= 16:
-        run_steps(args.steps, True)  # more warm-up, of the timed call's own shape: the library captures its step graph on first use of a shape
+        run_steps(args.steps, True)  # more warm-up, of the timed call's own shape: the library captures a step graph on first use of a shape (small problems; large ones from 256 steps on)
     sync()
     t0 = time.perf_counter()
     timed_losses = run_steps(args.steps, True)

@@ -2014,8 +2014,12 @@ struct SolverT final : cal_solver {
     // hipGraph replay of kGraphSteps train steps at a time: the steps of such problems are bound by launch latency.  Timed
     // runs (HIP events around every fused pass) issue their launches one by one.
     // Large problems replay too unless the step holds an exchange (a collective or a host callback is not captured): see replay_steps.
-    const bool replay = (tail1 || !comm_on()) && !timing && (launch_mode == CAL_LAUNCH_AUTO || launch_mode == CAL_LAUNCH_GRAPH);
-    const int gsteps = tail1 ? kGraphSteps : std::min(kGraphSteps, chunk & ~1);  // even: the double-buffered loop state ends a replay where it began
+    // (capturing and instantiating the graph of a large problem's steps costs tens of milliseconds -- 40 for 16 steps of the dense path --, once
+    // per shape of call: calls of fewer than kGraphMinSteps steps launch kernel by kernel, longer ones replay 8 steps at a time)
+    constexpr int kGraphStepsLarge = 8, kGraphMinSteps = 256;
+    const bool replay = (tail1 || (!comm_on() && (r->nsteps >= kGraphMinSteps || launch_mode == CAL_LAUNCH_GRAPH))) && !timing &&
+                        (launch_mode == CAL_LAUNCH_AUTO || launch_mode == CAL_LAUNCH_GRAPH);
+    const int gsteps = tail1 ? kGraphSteps : std::min(kGraphStepsLarge, chunk & ~1);  // even: the double-buffered loop state ends a replay where it began
     int issued = 0;
     while (issued < r->nsteps) {
       const int n = std::min(chunk, r->nsteps - issued);

@@ -51,6 +51,31 @@ def test_trajectories_bit_identical_across_launch_modes(dtype, optimizer, reg, l
         assert_same(ref, run_fit(p, start, dtype, mode, optimizer=optimizer, reg=reg, layout=layout, use_min=True, tol=0.0))
 
 
+@pytest.mark.parametrize("dtype,reg", [(np.float32, False), (np.float32, True), (np.float64, False)])
+def test_dense_path_steps_replayed_from_a_graph_equal_kernel_by_kernel(dtype, reg):
+    """The matrix-core path never takes the one-launch tail; since round 5 its steps (dense pass(es), gain_grad_kernel, finalize_kernel,
+    the update) are replayed from a hipGraph as well -- 8 at a time, in calls of at least 256 steps ("auto") or always ("graph").  300
+    recorded steps with use_min: 37 replays + 4 single steps in "auto" and "graph", every kernel its own launch in "kernels": the
+    same losses, parameters and snapshots bit for bit."""
+    p, start = make_case(seed=33, with_sky=reg, nants=12, nfreqs=128)
+
+    def fit(mode):
+        s = make_solver(p, start, dtype, layout="shared", reg=reg, kernel_path="dense")
+        assert s.timing_get()["kernel_path"] == "dense"
+        s.set_launch_mode(mode)
+        s.set_optimizer("Adam", learning_rate=5e-3)
+        s.run(1, record=False)
+        losses, stopped, nupd = s.run(300, record=True, use_min=True, tol=0.0)
+        out = (losses, stopped, nupd, s.get_params(), s.get_params(which=1))
+        s.close()
+        return out
+
+    ref = fit("kernels")
+    assert len(ref[0]) == 300 and np.all(np.isfinite(ref[0])) and ref[0][-1] < ref[0][0]
+    for mode in ("auto", "graph"):
+        assert_same(ref, fit(mode))
+
+
 def test_split_groups_and_redundant_group_across_launch_modes():
     """Groups cut into several work items (partial coefficient gradients summed in the tail) and a multi-baseline group."""
     p, start = make_case(seed=5, nants=7, nfreqs=300, redundant=True)

@@ -11,7 +11,7 @@ for layout in ("shared", "stream"):
         s.set_params(start["g_r"], start["g_i"], start["c_r"], start["c_i"])
         s.set_optimizer("Adam", learning_rate=1e-3)
         s.set_launch_mode(mode)
-        n = 512 if layout == "shared" else 96
+        n = 512 if layout == "shared" else 256
         s.run(n, record=True, tol=0.0); s.synchronize()   # (creates the graph)
         t = time.perf_counter(); l, _, _ = s.run(n, record=True, tol=0.0); s.synchronize(); dt = time.perf_counter() - t
         print(layout, mode, f"{dt / n * 1e3:.4f} ms per step", f"last loss {l[-1]:.9e}", flush=True)
