@@ -2017,7 +2017,10 @@ struct SolverT final : cal_solver {
     // (capturing and instantiating the graph of a large problem's steps costs tens of milliseconds -- 40 for 16 steps of the dense path --, once
     // per shape of call: calls of fewer than kGraphMinSteps steps launch kernel by kernel, longer ones replay 8 steps at a time)
     constexpr int kGraphStepsLarge = 8, kGraphMinSteps = 256;
-    const bool replay = (tail1 || (!comm_on() && (r->nsteps >= kGraphMinSteps || launch_mode == CAL_LAUNCH_GRAPH))) && !timing &&
+    // Of the large problems only the dense path replays in "auto": measured at HERA-350 (tools/graph_ab.py) its step is the same or 0.5 % shorter
+    // from a graph, the streaming kernel's step 3-13 % LONGER (4.9 -> 5.1, 4.7 -> 5.3 ms on two boxes: what the passes leave in the caches
+    // for the kernels behind them does not survive the graph's node boundaries).
+    const bool replay = (tail1 || (!comm_on() && ((mf_ok && r->nsteps >= kGraphMinSteps) || launch_mode == CAL_LAUNCH_GRAPH))) && !timing &&
                         (launch_mode == CAL_LAUNCH_AUTO || launch_mode == CAL_LAUNCH_GRAPH);
     const int gsteps = tail1 ? kGraphSteps : std::min(kGraphStepsLarge, chunk & ~1);  // even: the double-buffered loop state ends a replay where it began
     int issued = 0;

@@ -54,7 +54,8 @@ def test_trajectories_bit_identical_across_launch_modes(dtype, optimizer, reg, l
 @pytest.mark.parametrize("dtype,reg", [(np.float32, False), (np.float32, True), (np.float64, False)])
 def test_dense_path_steps_replayed_from_a_graph_equal_kernel_by_kernel(dtype, reg):
     """The matrix-core path never takes the one-launch tail; since round 5 its steps (dense pass(es), gain_grad_kernel, finalize_kernel,
-    the update) are replayed from a hipGraph as well -- 8 at a time, in calls of at least 256 steps ("auto") or always ("graph").  300
+    the update) are replayed from a hipGraph as well -- 8 at a time, in calls of at least 256 steps ("auto") or always ("graph"; the streaming kernels
+    of large problems replay only then).  300
     recorded steps with use_min: 37 replays + 4 single steps in "auto" and "graph", every kernel its own launch in "kernels": the
     same losses, parameters and snapshots bit for bit."""
     p, start = make_case(seed=33, with_sky=reg, nants=12, nfreqs=128)
