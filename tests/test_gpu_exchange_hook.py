@@ -35,13 +35,13 @@ def run_two_ranks(case, tmp_path):
                                "--port", str(port), "--out", outs[r]], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     logs = []
-    for pr in procs:
-        try:
-            logs.append(pr.communicate(timeout=900)[0])
-        except subprocess.TimeoutExpired:
-            for q in procs:
+    try:
+        for pr in procs:
+            logs.append(pr.communicate(timeout=300)[0])
+    finally:  # (whatever ends this -- a timeout here, pytest-timeout's alarm -- no rank is left behind holding the GPU)
+        for q in procs:
+            if q.poll() is None:
                 q.kill()
-            raise
     for r, pr in enumerate(procs):
         assert pr.returncode == 0, f"rank {r} failed:\n{logs[r][-4000:]}"
     return [np.load(o) for o in outs]
